@@ -1,0 +1,124 @@
+/*
+ * srhip.h -- C ABI of libsrhip.so, the MI355X (gfx950) engine behind rusty_sr's
+ * upscale hot path.
+ *
+ * The reference (millardjn/rusty_sr v1) has no FFI/plugin seam of its own; the
+ * boundary this library replaces is the single call
+ *     let output = graph.forward(1, vec![input], &params).remove(0);
+ * at reference src/main.rs:171, together with the tensor conversions on either
+ * side of it (img_to_data main.rs:170, data_to_img main.rs:175) and the weight
+ * decode that feeds it (`<Vec<f32>>::decode::<u32>` main.rs:138,146,149,152).
+ * The conventions of that call site are kept: the caller owns `params` and all
+ * image buffers, a call is synchronous, a context is single-caller, errors are
+ * reported where the reference panics (main.rs:134-138,162,164,175).
+ *
+ * Everything is plain C: pointers, sizes, ints.  No torch / HIP types appear
+ * in a signature (`stream` is an opaque hipStream_t passed as void*; NULL =
+ * the context's own stream).  A Rust host binds this with a 30-line
+ * `extern "C"` block (INTEGRATION.md shows it).
+ *
+ * Tensor layout everywhere: NHWC, channel fastest -- alumina's
+ * DataShape::new(channels, &[W, H], n) order (reference main.rs:168).
+ * The up-scaling factor is 3 (reference main.rs:31 `const FACTOR: usize = 3`;
+ * the bundled weights only fit factor 3, network.rs:37).
+ */
+#ifndef SRHIP_H
+#define SRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_FACTOR 3
+#define SR_NUM_PARAMS 130459 /* graph.num_params() of sr_net(3, None); main.rs:162 */
+#define SR_HALO 7            /* receptive-field radius of the conv stack in input px */
+
+typedef struct sr_ctx sr_ctx;
+
+enum sr_status {
+    SR_OK = 0,
+    SR_E_INVALID = -1,     /* NULL pointer / non-positive dimension / bad channel count */
+    SR_E_PARAM_COUNT = -2, /* main.rs:162 assert_eq!(params.len(), graph.num_params()) */
+    SR_E_FACTOR = -3,      /* only factor 3 exists in the reference (main.rs:31) */
+    SR_E_NO_DEVICE = -4,   /* no gfx950 device visible: the engine has NO CPU fallback */
+    SR_E_HIP = -5,         /* a HIP runtime call failed; sr_last_hip_error() has the code */
+    SR_E_NOMEM = -6,
+    SR_E_BYTEVEC = -7,     /* main.rs:138 "ByteVec conversion failed" */
+    SR_E_HALO = -8         /* band call with a halo that is neither 0 nor >= SR_HALO */
+};
+
+/* Replaces: `<Vec<f32>>::decode::<u32>(blob)` (bytevec 0.2.0; reference
+ * main.rs:138,146,149,152).  Wire format: u32 LE n | n x u32 LE sizes (=4) |
+ * n x f32 LE.  Pass out = NULL to query *n_out.  Host-side, no GPU needed. */
+int sr_rsr_decode(const uint8_t* blob, size_t len, float* out, size_t cap, size_t* n_out);
+
+/* Replaces: `.encode::<u32>()` (reference main.rs:213), the inverse of the above.
+ * Pass out = NULL to query the byte length in *len_out. */
+int sr_rsr_encode(const float* params, size_t n, uint8_t* out, size_t cap, size_t* len_out);
+
+/* Replaces: `sr_net(FACTOR, None)` + the parameter-count assert (reference
+ * main.rs:146,162; network.rs:16-109).  Validates, selects HIP device
+ * `device`, uploads the parameters once re-packed into the MFMA B-operand
+ * layout.  Fails with SR_E_NO_DEVICE when no GPU is present. */
+int sr_create(sr_ctx** out, const float* params, size_t n_params, int factor, int device);
+void sr_destroy(sr_ctx* ctx);
+
+/* Replaces: graph.forward(n, vec![input], &params) (reference main.rs:171).
+ * in : n*h*w*3 f32 in [0,1] (what img_to_data produced), host memory.
+ * out: n*(3h)*(3w)*3 f32, pre-quantisation, host memory. */
+int sr_upscale_f32(sr_ctx* ctx, const float* in, int n, int h, int w, float* out);
+
+/* Replaces: img_to_data + graph.forward + data_to_img(..).to_rgba() (reference
+ * main.rs:170-175) as one fused device pass: u8/255 on load, and
+ * clamp(floor(255 v + 0.5)) with alpha = 255 on store.
+ * in : n*h*w*in_channels u8, in_channels 3 (RGB) or 4 (RGBA, alpha dropped).
+ * out: n*(3h)*(3w)*4 u8 RGBA.  Host memory. */
+int sr_upscale_rgba8(sr_ctx* ctx, const uint8_t* in, int in_channels, int n, int h, int w,
+                     uint8_t* out_rgba);
+
+/* Same two operations on buffers already resident in this context's device
+ * memory (HBM); asynchronous on `stream` (opaque hipStream_t; NULL = the
+ * context's stream).  These are what bench.py times and what the multi-GPU
+ * driver calls after its halo exchange. */
+int sr_upscale_f32_dev(sr_ctx* ctx, const float* d_in, int n, int h, int w, float* d_out,
+                       void* stream);
+int sr_upscale_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels, int n, int h, int w,
+                         uint8_t* d_out_rgba, void* stream);
+
+/* Row-band form for images sharded across GPUs.  d_in holds h_ext = halo_top +
+ * h_band + halo_bot input rows of ONE image of width w; halo_top / halo_bot are
+ * the rows that belong to the neighbouring bands (0 = this edge is the true
+ * image edge, where the reference's per-layer zero padding applies; otherwise
+ * must be >= SR_HALO).  d_out receives only the band's 3*h_band output rows.
+ * Bit-identical to the corresponding rows of the un-sharded call. */
+int sr_upscale_band_f32_dev(sr_ctx* ctx, const float* d_in, int h_ext, int w, int halo_top,
+                            int halo_bot, float* d_out, void* stream);
+int sr_upscale_band_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels, int h_ext, int w,
+                              int halo_top, int halo_bot, uint8_t* d_out_rgba, void* stream);
+
+/* Test hook: copy the post-activation feature maps of the most recent call
+ * (image 0) to host: which = 0..3 -> f, l1, l2, l3 (h*w*32 f32 each).  The
+ * reference exposes the same values as graph node data (network.rs:30,43-48). */
+int sr_read_feature(sr_ctx* ctx, int which, float* out_host, size_t cap_floats);
+
+/* Device time of the most recent call, measured with HIP events on the stream
+ * the kernels ran on.  stage_ms[5] = conv0, l1, l2, l3, expand stage kernels
+ * (enable with sr_set_profiling; off by default -- it inserts events).
+ * h2d / d2h are zero for the *_dev entry points. */
+int sr_set_profiling(sr_ctx* ctx, int enabled);
+int sr_last_timing(sr_ctx* ctx, double* total_ms, double stage_ms[5], double* h2d_ms,
+                   double* d2h_ms);
+
+/* Device facts for reports: name (e.g. "gfx950..."), CU count, clock MHz. */
+int sr_device_info(sr_ctx* ctx, char* name, size_t cap, int* compute_units, int* clock_mhz);
+
+int sr_last_hip_error(sr_ctx* ctx);
+const char* sr_strerror(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRHIP_H */

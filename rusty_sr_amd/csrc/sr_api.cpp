@@ -1,0 +1,399 @@
+// sr_api.cpp -- the C ABI of libsrhip.so (include/srhip.h): context, weight
+// re-packing, workspace, stage scheduling.  No CPU compute fallback exists:
+// without a HIP device sr_create fails with SR_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/srhip.h"
+#include "sr_kernels.h"
+
+namespace {
+
+// Parameter segment offsets: op insertion order of reference src/network.rs:33-72
+// (SURVEY.md 8(a) row W).
+enum : size_t {
+    OFF_CONV0 = 0, OFF_F_BIAS = 2400, OFF_F_ACTIV = 2432, OFF_EXP_BIAS = 2464,
+    OFF_L1_BIAS = 2491, OFF_L2_BIAS = 2523, OFF_L3_BIAS = 2555,
+    OFF_L1_ACTIV = 2587, OFF_L2_ACTIV = 2619, OFF_L3_ACTIV = 2651,
+    OFF_CONV1 = 2683, OFF_CONV2 = 28283, OFF_CONV3 = 53883,
+    OFF_CONV5 = 79483, OFF_CONV6 = 88699, OFF_CONV7 = 97915,
+    OFF_CONV8 = 105691, OFF_CONV9 = 114907, OFF_CONV10 = 122683, OFF_END = 130459
+};
+static_assert(OFF_END == SR_NUM_PARAMS, "parameter count");
+
+constexpr int kChunk = 1024;  // floats per tap chunk (32 cin x 32 cout)
+
+// Append the taps of one [O][KS][KS][32] convolution as B-operand chunks:
+// chunk[(c*32 + o)*4 + q] = W[o][ky][kx][4c+q], output channels >= O zero.
+void pack_conv32(std::vector<float>& dst, const float* w, int O, int ks) {
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            const size_t base = dst.size();
+            dst.resize(base + kChunk, 0.0f);
+            for (int c = 0; c < 8; ++c)
+                for (int o = 0; o < O; ++o)
+                    for (int q = 0; q < 4; ++q)
+                        dst[base + (c * 32 + o) * 4 + q] = w[(((size_t)o * ks + ky) * ks + kx) * 32 + 4 * c + q];
+        }
+}
+
+// conv0 [32][5][5][3] -> 25 taps x [h 2][o 32][q 2], cin = 2h+q, cin 3 = zero pad.
+void pack_conv0(std::vector<float>& dst, const float* w) {
+    dst.assign(25 * 128, 0.0f);
+    for (int t = 0; t < 25; ++t)
+        for (int h = 0; h < 2; ++h)
+            for (int o = 0; o < 32; ++o)
+                for (int q = 0; q < 2; ++q) {
+                    const int ci = 2 * h + q;
+                    if (ci < 3) dst[t * 128 + (h * 32 + o) * 2 + q] = w[((size_t)o * 25 + t) * 3 + ci];
+                }
+}
+
+}  // namespace
+
+struct sr_ctx {
+    int device = 0;
+    int cus = 0, clock_mhz = 0;
+    char name[128] = {0};
+    hipStream_t stream = nullptr;
+    float* d_params = nullptr;  // all packed parameters, one allocation
+    size_t off_w0 = 0, off_w[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
+    float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3
+    size_t feat_cap_px = 0;
+    void* d_in = nullptr;  size_t in_cap = 0;    // staging for the host-pointer entry points
+    void* d_out = nullptr; size_t out_cap = 0;
+    hipEvent_t ev[8] = {nullptr};
+    bool profiling = false;
+    double total_ms = 0, stage_ms[5] = {0}, h2d_ms = 0, d2h_ms = 0;
+    int last_h = 0, last_w = 0;
+    int last_hip = 0;
+};
+
+#define HIPCHK(ctx, expr)                         \
+    do {                                          \
+        hipError_t e__ = (expr);                  \
+        if (e__ != hipSuccess) {                  \
+            (ctx)->last_hip = (int)e__;           \
+            return e__ == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP; \
+        }                                         \
+    } while (0)
+
+extern "C" {
+
+const char* sr_strerror(int s) {
+    switch (s) {
+        case SR_OK: return "ok";
+        case SR_E_INVALID: return "invalid argument";
+        case SR_E_PARAM_COUNT:
+            return "Parameters selected do not have the size required by the neural net. Ensure that the "
+                   "same sample factor is used for upscaling and training";  // reference main.rs:162
+        case SR_E_FACTOR: return "only upscaling factor 3 is supported (reference main.rs:31)";
+        case SR_E_NO_DEVICE: return "no HIP (gfx950) device available; libsrhip has no CPU fallback";
+        case SR_E_HIP: return "HIP runtime error";
+        case SR_E_NOMEM: return "out of device memory";
+        case SR_E_BYTEVEC: return "ByteVec conversion failed";  // reference main.rs:138
+        case SR_E_HALO: return "band halo must be 0 (true image edge) or >= SR_HALO";
+        default: return "unknown error";
+    }
+}
+
+int sr_rsr_decode(const uint8_t* blob, size_t len, float* out, size_t cap, size_t* n_out) {
+    if (!blob || len < 4) return SR_E_BYTEVEC;
+    uint32_t n;
+    memcpy(&n, blob, 4);
+    if (len != 4 + (size_t)8 * n) return SR_E_BYTEVEC;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t sz;
+        memcpy(&sz, blob + 4 + (size_t)4 * i, 4);
+        if (sz != 4) return SR_E_BYTEVEC;
+    }
+    if (n_out) *n_out = n;
+    if (out) {
+        if (cap < n) return SR_E_INVALID;
+        memcpy(out, blob + 4 + (size_t)4 * n, (size_t)4 * n);
+    }
+    return SR_OK;
+}
+
+int sr_rsr_encode(const float* params, size_t n, uint8_t* out, size_t cap, size_t* len_out) {
+    if (n > 0xffffffffu) return SR_E_INVALID;
+    const size_t len = 4 + 8 * n;
+    if (len_out) *len_out = len;
+    if (!out) return SR_OK;
+    if (!params || cap < len) return SR_E_INVALID;
+    const uint32_t n32 = (uint32_t)n, four = 4;
+    memcpy(out, &n32, 4);
+    for (size_t i = 0; i < n; ++i) memcpy(out + 4 + 4 * i, &four, 4);
+    memcpy(out + 4 + 4 * n, params, 4 * n);
+    return SR_OK;
+}
+
+int sr_create(sr_ctx** out, const float* params, size_t n_params, int factor, int device) {
+    if (!out || !params) return SR_E_INVALID;
+    *out = nullptr;
+    if (factor != SR_FACTOR) return SR_E_FACTOR;
+    if (n_params != SR_NUM_PARAMS) return SR_E_PARAM_COUNT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SR_E_NO_DEVICE;
+    if (device < 0 || device >= ndev) return SR_E_INVALID;
+    sr_ctx* c = new (std::nothrow) sr_ctx();
+    if (!c) return SR_E_NOMEM;
+    c->device = device;
+    int rc = [&]() -> int {
+        HIPCHK(c, hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIPCHK(c, hipGetDeviceProperties(&prop, device));
+        snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+        c->cus = prop.multiProcessorCount;
+        c->clock_mhz = prop.clockRate / 1000;
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
+
+        // ---- pack every parameter once, in the layouts the kernels read
+        std::vector<float> host, w;
+        auto push = [&](const std::vector<float>& v) {
+            const size_t off = host.size();
+            host.insert(host.end(), v.begin(), v.end());
+            while (host.size() % 64) host.push_back(0.0f);  // keep 256-B alignment
+            return off;
+        };
+        auto vec32 = [&](size_t off, int n) {
+            std::vector<float> v(32, 0.0f);
+            for (int i = 0; i < n; ++i) v[i] = params[off + i];
+            return v;
+        };
+        pack_conv0(w, params + OFF_CONV0);
+        c->off_w0 = push(w);
+        w.clear(); pack_conv32(w, params + OFF_CONV1, 32, 5);
+        c->off_w[1] = push(w);
+        w.clear(); pack_conv32(w, params + OFF_CONV2, 32, 5); pack_conv32(w, params + OFF_CONV5, 32, 3);
+        c->off_w[2] = push(w);
+        w.clear(); pack_conv32(w, params + OFF_CONV3, 32, 5); pack_conv32(w, params + OFF_CONV6, 32, 3);
+        pack_conv32(w, params + OFF_CONV8, 32, 3);
+        c->off_w[3] = push(w);
+        w.clear(); pack_conv32(w, params + OFF_CONV7, 27, 3); pack_conv32(w, params + OFF_CONV9, 27, 3);
+        pack_conv32(w, params + OFF_CONV10, 27, 3);
+        c->off_w[4] = push(w);
+        const size_t boff[5] = {OFF_F_BIAS, OFF_L1_BIAS, OFF_L2_BIAS, OFF_L3_BIAS, OFF_EXP_BIAS};
+        const size_t aoff[4] = {OFF_F_ACTIV, OFF_L1_ACTIV, OFF_L2_ACTIV, OFF_L3_ACTIV};
+        for (int s = 0; s < 5; ++s) c->off_bias[s] = push(vec32(boff[s], s == 4 ? 27 : 32));
+        for (int s = 0; s < 4; ++s) c->off_beta[s] = push(vec32(aoff[s], 32));
+        HIPCHK(c, hipMalloc((void**)&c->d_params, host.size() * sizeof(float)));
+        HIPCHK(c, hipMemcpy(c->d_params, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+        return SR_OK;
+    }();
+    if (rc != SR_OK) {
+        sr_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return SR_OK;
+}
+
+void sr_destroy(sr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->d_feat) if (p) (void)hipFree(p);
+    if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sr_last_hip_error(sr_ctx* c) { return c ? c->last_hip : 0; }
+
+int sr_set_profiling(sr_ctx* c, int enabled) {
+    if (!c) return SR_E_INVALID;
+    c->profiling = enabled != 0;
+    return SR_OK;
+}
+
+int sr_device_info(sr_ctx* c, char* name, size_t cap, int* cus, int* clock_mhz) {
+    if (!c) return SR_E_INVALID;
+    if (name && cap) snprintf(name, cap, "%s", c->name);
+    if (cus) *cus = c->cus;
+    if (clock_mhz) *clock_mhz = c->clock_mhz;
+    return SR_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int ensure_features(sr_ctx* c, size_t npx) {
+    if (npx <= c->feat_cap_px) return SR_OK;
+    for (auto& p : c->d_feat) {
+        if (p) HIPCHK(c, hipFree(p));
+        p = nullptr;
+    }
+    c->feat_cap_px = 0;
+    for (auto& p : c->d_feat) HIPCHK(c, hipMalloc((void**)&p, npx * 32 * sizeof(float)));
+    c->feat_cap_px = npx;
+    return SR_OK;
+}
+
+int ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return SR_OK;
+    if (*p) HIPCHK(c, hipFree(*p));
+    *p = nullptr; *cap = 0;
+    HIPCHK(c, hipMalloc(p, bytes));
+    *cap = bytes;
+    return SR_OK;
+}
+
+// The whole conv stack on device buffers.  Rows [halo_top, H - halo_bot) of each
+// of the n images are produced; each earlier stage computes just the extra rows
+// the later ones read (f +-5, l1 +-3, l2 +-2, l3 +-1 around the band).
+int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top,
+              int halo_bot, void* d_out, bool out_u8, hipStream_t s) {
+    if (!c || !d_img || !d_out) return SR_E_INVALID;
+    if (n <= 0 || H <= 0 || W <= 0) return SR_E_INVALID;
+    if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    if ((halo_top != 0 && halo_top < SR_HALO) || (halo_bot != 0 && halo_bot < SR_HALO)) return SR_E_HALO;
+    if (halo_top < 0 || halo_bot < 0 || halo_top + halo_bot >= H) return SR_E_INVALID;
+    if ((halo_top || halo_bot) && n != 1) return SR_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!s) s = c->stream;
+    int rc = ensure_features(c, (size_t)n * H * W);
+    if (rc != SR_OK) return rc;
+
+    const int top = halo_top, bot = H - halo_bot;
+    static const int margin[5] = {5, 3, 2, 1, 0};
+    const int tiles_x = (W + 31) / 32;
+    // tile height: 8 rows when that still gives every CU two workgroups, else 4
+    const long tiles8 = (long)n * tiles_x * ((bot - top + 7) / 8);
+    const int th = tiles8 >= 2L * (c->cus > 0 ? c->cus : 256) ? 8 : 4;
+    const float* P = c->d_params;
+    const bool prof = c->profiling;
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    for (int st = 0; st < 5; ++st) {
+        int y0 = top - margin[st], y1 = bot + margin[st];
+        if (y0 < 0) y0 = 0;
+        if (y1 > H) y1 = H;
+        const int tiles_y = (y1 - y0 + th - 1) / th;
+        const int nblk = n * tiles_x * tiles_y;
+        if (st == 0) {
+            Conv0Args a{};
+            a.img = d_img; a.wpack = P + c->off_w0; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
+            a.dst = c->d_feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
+            a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+            HIPCHK(c, sr_launch_conv0(a, th, nblk, img_u8, s));
+        } else {
+            StageArgs a{};
+            float* f = c->d_feat[0]; float* l1 = c->d_feat[1]; float* l2 = c->d_feat[2]; float* l3 = c->d_feat[3];
+            switch (st) {
+                case 1: a.src[0] = f; a.dst = l1; break;
+                case 2: a.src[0] = f; a.src[1] = l1; a.dst = l2; break;
+                case 3: a.src[0] = f; a.src[1] = l1; a.src[2] = l2; a.dst = l3; break;
+                case 4: a.src[0] = l1; a.src[1] = l2; a.src[2] = l3; a.img = d_img; a.out = d_out; break;
+            }
+            a.wpack = P + c->off_w[st]; a.bias = P + c->off_bias[st];
+            a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
+            a.H = H; a.W = W; a.img_ch = img_ch;
+            a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+            HIPCHK(c, sr_launch_stage(st, a, th, nblk, img_u8, out_u8, s));
+        }
+        if (prof) HIPCHK(c, hipEventRecord(c->ev[st + 1], s));
+    }
+    c->last_h = H; c->last_w = W;
+    if (prof) {
+        HIPCHK(c, hipEventSynchronize(c->ev[5]));
+        float ms = 0;
+        for (int st = 0; st < 5; ++st) {
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[st], c->ev[st + 1]));
+            c->stage_ms[st] = ms;
+        }
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[5]));
+        c->total_ms = ms;
+    }
+    return SR_OK;
+}
+
+int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, int w, void* out, bool out_u8) {
+    if (!c || !in || !out || n <= 0 || h <= 0 || w <= 0) return SR_E_INVALID;
+    if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npx = (size_t)n * h * w;
+    const size_t in_bytes = npx * (img_u8 ? (size_t)img_ch : 3 * sizeof(float));
+    const size_t out_bytes = npx * 9 * (out_u8 ? 4 : 3 * sizeof(float));
+    int rc = ensure_buf(c, &c->d_in, &c->in_cap, in_bytes);
+    if (rc == SR_OK) rc = ensure_buf(c, &c->d_out, &c->out_cap, out_bytes);
+    if (rc != SR_OK) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev[6], s));
+    HIPCHK(c, hipMemcpyAsync(c->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipEventRecord(c->ev[7], s));
+    rc = run_stack(c, c->d_in, img_u8, img_ch, n, h, w, 0, 0, c->d_out, out_u8, s);
+    if (rc != SR_OK) return rc;
+    hipEvent_t k_end = c->ev[5];
+    HIPCHK(c, hipEventRecord(k_end, s));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[7])); c->h2d_ms = ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[7], k_end));    c->total_ms = ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, k_end, c->ev[0]));    c->d2h_ms = ms;
+    return SR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sr_upscale_f32_dev(sr_ctx* c, const float* d_in, int n, int h, int w, float* d_out, void* stream) {
+    return run_stack(c, d_in, false, 3, n, h, w, 0, 0, d_out, false, (hipStream_t)stream);
+}
+
+int sr_upscale_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, int n, int h, int w,
+                         uint8_t* d_out, void* stream) {
+    return run_stack(c, d_in, true, in_channels, n, h, w, 0, 0, d_out, true, (hipStream_t)stream);
+}
+
+int sr_upscale_band_f32_dev(sr_ctx* c, const float* d_in, int h_ext, int w, int halo_top, int halo_bot,
+                            float* d_out, void* stream) {
+    return run_stack(c, d_in, false, 3, 1, h_ext, w, halo_top, halo_bot, d_out, false, (hipStream_t)stream);
+}
+
+int sr_upscale_band_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, int h_ext, int w,
+                              int halo_top, int halo_bot, uint8_t* d_out, void* stream) {
+    return run_stack(c, d_in, true, in_channels, 1, h_ext, w, halo_top, halo_bot, d_out, true,
+                     (hipStream_t)stream);
+}
+
+int sr_upscale_f32(sr_ctx* c, const float* in, int n, int h, int w, float* out) {
+    return run_host(c, in, false, 3, n, h, w, out, false);
+}
+
+int sr_upscale_rgba8(sr_ctx* c, const uint8_t* in, int in_channels, int n, int h, int w, uint8_t* out) {
+    return run_host(c, in, true, in_channels, n, h, w, out, true);
+}
+
+int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
+    if (!c || which < 0 || which > 3 || !out_host) return SR_E_INVALID;
+    const size_t nf = (size_t)c->last_h * c->last_w * 32;
+    if (nf == 0 || cap_floats < nf || !c->d_feat[which]) return SR_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out_host, c->d_feat[which], nf * sizeof(float), hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_last_timing(sr_ctx* c, double* total_ms, double stage_ms[5], double* h2d_ms, double* d2h_ms) {
+    if (!c) return SR_E_INVALID;
+    if (total_ms) *total_ms = c->total_ms;
+    if (stage_ms) for (int i = 0; i < 5; ++i) stage_ms[i] = c->stage_ms[i];
+    if (h2d_ms) *h2d_ms = c->h2d_ms;
+    if (d2h_ms) *d2h_ms = c->d2h_ms;
+    return SR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+"""Host-side mirror of the reference's engine seam for the upscale path.
+
+Reference call site (src/main.rs:161-171):
+    assert_eq!(params.len(), graph.num_params(), ...);
+    let mut input = NodeData::new_blank(DataShape::new(CHANNELS, &[W, H], 1));
+    img_to_data(&mut input.values, &input_image);
+    let output = graph.forward(1, vec![input], &params).remove(0);
+Here `sr_net(factor)` returns a Graph whose forward() runs the hand-written
+gfx950 kernels through libsrhip's C ABI.  torch is used only for device memory
+and streams."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+FACTOR = 3    # reference main.rs:31
+CHANNELS = 3  # reference network.rs:13
+
+
+@dataclass
+class DataShape:
+    """alumina DataShape::new(channels, &[W, H], n) (reference main.rs:168)."""
+    channels: int
+    spatial_dimensions: Sequence[int]  # [W, H]
+    n: int = 1
+
+    def flat_size_single(self):
+        w, h = self.spatial_dimensions
+        return self.channels * w * h
+
+
+@dataclass
+class NodeData:
+    """alumina NodeData { shape, values } -- values are n x [y][x][c] f32."""
+    shape: DataShape
+    values: np.ndarray = field(default=None)
+
+    @staticmethod
+    def new_blank(shape: DataShape) -> "NodeData":
+        return NodeData(shape, np.zeros(shape.n * shape.flat_size_single(), dtype=np.float32))
+
+
+def img_to_data(pixels: np.ndarray) -> np.ndarray:
+    """alumina supplier::imagefolder::img_to_data (reference main.rs:170):
+    u8 RGB(A) -> f32 = u8/255, alpha dropped.  Host-side convenience for the
+    f32 entry points; the rgba8 entry points fuse this into the first kernel."""
+    px = np.asarray(pixels)
+    if px.dtype != np.uint8 or px.shape[-1] not in (3, 4):
+        raise ValueError("expected u8 pixels with 3 or 4 channels")
+    return px[..., :3].astype(np.float32) / np.float32(255.0)
+
+
+class Engine:
+    """One sr_ctx (= one GPU, one parameter set)."""
+
+    def __init__(self, params, device: int = 0, factor: int = FACTOR):
+        L = _lib.lib()
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        self._ctx = C.c_void_p()
+        _lib.check(L.sr_create(C.byref(self._ctx), p.ctypes.data_as(C.POINTER(C.c_float)), p.size, factor, device))
+        self.device = device
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.sr_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    # ---- host-memory entry points (numpy in, numpy out) --------------------
+    def upscale_f32(self, x: np.ndarray) -> np.ndarray:
+        """(n,H,W,3) or (H,W,3) f32 in [0,1] -> (n,3H,3W,3) f32 pre-quantisation."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        squeeze = x.ndim == 3
+        if squeeze:
+            x = x[None]
+        n, h, w, c = x.shape
+        if c != 3:
+            raise ValueError("expected 3 channels")
+        out = np.empty((n, 3 * h, 3 * w, 3), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        _lib.check(self._L.sr_upscale_f32(self._ctx, x.ctypes.data_as(fp), n, h, w, out.ctypes.data_as(fp)), self._ctx)
+        return out[0] if squeeze else out
+
+    def upscale_rgba8(self, px: np.ndarray) -> np.ndarray:
+        """(n,H,W,3|4) or (H,W,3|4) u8 -> (n,3H,3W,4) u8 RGBA (alpha 255)."""
+        px = np.ascontiguousarray(px, dtype=np.uint8)
+        squeeze = px.ndim == 3
+        if squeeze:
+            px = px[None]
+        n, h, w, c = px.shape
+        out = np.empty((n, 3 * h, 3 * w, 4), dtype=np.uint8)
+        u8p = C.POINTER(C.c_uint8)
+        _lib.check(self._L.sr_upscale_rgba8(self._ctx, px.ctypes.data_as(u8p), c, n, h, w, out.ctypes.data_as(u8p)), self._ctx)
+        return out[0] if squeeze else out
+
+    # ---- device-memory entry points (torch tensors on this GPU) ------------
+    @staticmethod
+    def _stream_ptr(stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        return C.c_void_p(s.cuda_stream)
+
+    def upscale_f32_dev(self, x, out=None, stream=None):
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[-1] == 3
+        n, h, w, _ = x.shape
+        if out is None:
+            out = torch.empty((n, 3 * h, 3 * w, 3), dtype=torch.float32, device=x.device)
+        _lib.check(self._L.sr_upscale_f32_dev(self._ctx, C.c_void_p(x.data_ptr()), n, h, w,
+                                              C.c_void_p(out.data_ptr()), self._stream_ptr(stream)), self._ctx)
+        return out
+
+    def upscale_rgba8_dev(self, px, out=None, stream=None):
+        import torch
+        assert px.is_cuda and px.dtype == torch.uint8 and px.is_contiguous() and px.dim() == 4
+        n, h, w, c = px.shape
+        if out is None:
+            out = torch.empty((n, 3 * h, 3 * w, 4), dtype=torch.uint8, device=px.device)
+        _lib.check(self._L.sr_upscale_rgba8_dev(self._ctx, C.c_void_p(px.data_ptr()), c, n, h, w,
+                                                C.c_void_p(out.data_ptr()), self._stream_ptr(stream)), self._ctx)
+        return out
+
+    def upscale_band_f32_dev(self, x_ext, halo_top, halo_bot, out=None, stream=None):
+        """x_ext: (h_ext,W,3) f32 rows = halo_top + band + halo_bot -> (3*band,3W,3)."""
+        import torch
+        assert x_ext.is_cuda and x_ext.dtype == torch.float32 and x_ext.is_contiguous() and x_ext.dim() == 3
+        h_ext, w, _ = x_ext.shape
+        hb = h_ext - halo_top - halo_bot
+        if out is None:
+            out = torch.empty((3 * hb, 3 * w, 3), dtype=torch.float32, device=x_ext.device)
+        _lib.check(self._L.sr_upscale_band_f32_dev(self._ctx, C.c_void_p(x_ext.data_ptr()), h_ext, w, halo_top,
+                                                   halo_bot, C.c_void_p(out.data_ptr()), self._stream_ptr(stream)),
+                   self._ctx)
+        return out
+
+    def upscale_band_rgba8_dev(self, px_ext, halo_top, halo_bot, out=None, stream=None):
+        import torch
+        assert px_ext.is_cuda and px_ext.dtype == torch.uint8 and px_ext.is_contiguous() and px_ext.dim() == 3
+        h_ext, w, c = px_ext.shape
+        hb = h_ext - halo_top - halo_bot
+        if out is None:
+            out = torch.empty((3 * hb, 3 * w, 4), dtype=torch.uint8, device=px_ext.device)
+        _lib.check(self._L.sr_upscale_band_rgba8_dev(self._ctx, C.c_void_p(px_ext.data_ptr()), c, h_ext, w,
+                                                     halo_top, halo_bot, C.c_void_p(out.data_ptr()),
+                                                     self._stream_ptr(stream)), self._ctx)
+        return out
+
+    # ---- introspection ------------------------------------------------------
+    def read_feature(self, which: int, h: int, w: int) -> np.ndarray:
+        """Post-activation node data of the last call: 0..3 = f, l1, l2, l3."""
+        out = np.empty((h, w, 32), dtype=np.float32)
+        _lib.check(self._L.sr_read_feature(self._ctx, which, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), self._ctx)
+        return out
+
+    def set_profiling(self, on: bool):
+        _lib.check(self._L.sr_set_profiling(self._ctx, int(on)))
+
+    def last_timing(self):
+        tot, h2d, d2h = C.c_double(), C.c_double(), C.c_double()
+        st = (C.c_double * 5)()
+        _lib.check(self._L.sr_last_timing(self._ctx, C.byref(tot), st, C.byref(h2d), C.byref(d2h)))
+        return {"total_ms": tot.value, "stage_ms": list(st), "h2d_ms": h2d.value, "d2h_ms": d2h.value}
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cus, mhz = C.c_int(), C.c_int()
+        _lib.check(self._L.sr_device_info(self._ctx, name, 128, C.byref(cus), C.byref(mhz)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value}
+
+
+class Graph:
+    """What `sr_net(FACTOR, None)` returns in the reference (network.rs:16-109),
+    reduced to the two methods upscale() uses: num_params() (main.rs:162) and
+    forward() (main.rs:171)."""
+
+    def __init__(self, factor: int, device: int = 0):
+        if factor != FACTOR:
+            raise _lib.SrError(_lib.SR_E_FACTOR)
+        self.factor = factor
+        self.device = device
+        self._engine: Optional[Engine] = None
+        self._params_key = None
+
+    def num_params(self) -> int:
+        return _lib.SR_NUM_PARAMS
+
+    def forward(self, n: int, inputs: List[NodeData], params) -> List[NodeData]:
+        if len(inputs) != 1:
+            raise ValueError("sr_net has exactly one input node")
+        p = np.ascontiguousarray(params, dtype=np.float32)
+        if p.size != self.num_params():
+            raise _lib.SrError(_lib.SR_E_PARAM_COUNT)
+        key = (p.size, hash(p.tobytes()))
+        if self._engine is None or key != self._params_key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = Engine(p, self.device, self.factor)
+            self._params_key = key
+        inp = inputs[0]
+        w, h = inp.shape.spatial_dimensions
+        if inp.shape.channels != CHANNELS or inp.shape.n != n:
+            raise ValueError("input shape does not match the graph's input node")
+        x = np.asarray(inp.values, dtype=np.float32).reshape(n, h, w, CHANNELS)
+        out = self._engine.upscale_f32(x)
+        return [NodeData(DataShape(CHANNELS, [w * self.factor, h * self.factor], n), out.reshape(-1))]
+
+
+def sr_net(factor: int = FACTOR, training=None, device: int = 0) -> Graph:
+    """reference network.rs:16 `pub fn sr_net(factor, training)`; inference branch only."""
+    if training is not None:
+        raise NotImplementedError("training graphs are outside the upscale hot path (SURVEY.md section 8)")
+    return Graph(factor, device)

@@ -1,0 +1,91 @@
+"""Multi-GPU sharding of the upscale path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+The reference processes one image in one process (no
+collectives exist there).  What shards is the output: every output pixel depends
+on a 15x15 input window (receptive radius SR_HALO = 7 input px through
+conv0 5x5 -> conv1 5x5 -> 3x3 -> 3x3 -> 3x3, reference network.rs:33,60-72), so
+
+  * a large image splits into contiguous ROW BANDS (rows are the slow NHWC axis, a
+    band is one contiguous byte range); each rank receives the 7 input rows above
+    and below its band from its neighbours (one batched send/recv pair per
+    neighbour, <= 160 KB each: latency- not bandwidth-bound on xGMI), recomputes
+    the overlap (14 / band_rows extra work) and writes its own 3*band rows.  No
+    other communication: bit-identical to the un-sharded result.
+  * many images are simply dealt round-robin, weights replicated (522 KB): no
+    communication at all.
+"""
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+SR_HALO = 7
+
+
+def split_rows(h: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous row bands, sizes differing by at most one row."""
+    q, r = divmod(h, world)
+    out, y = [], 0
+    for k in range(world):
+        n = q + (1 if k < r else 0)
+        out.append((y, y + n))
+        y += n
+    return out
+
+
+def round_robin(n_images: int, rank: int, world: int) -> List[int]:
+    """Throughput mode (BASELINE configs[4]): image i -> rank i mod world."""
+    return list(range(rank, n_images, world))
+
+
+class BandExchange:
+    """Persistent halo-exchange state for one rank's band of an (H, W, C) image."""
+
+    def __init__(self, band_rows: int, width: int, channels: int, dtype, device, rank: int, world: int,
+                 halo: int = SR_HALO, group=None):
+        if world > 1 and band_rows < halo:
+            raise ValueError(f"band of {band_rows} rows is narrower than the {halo}-row halo")
+        self.rank, self.world, self.halo, self.group = rank, world, halo, group
+        self.top = halo if rank > 0 else 0
+        self.bot = halo if rank < world - 1 else 0
+        self.band_rows = band_rows
+        # band lives in the middle of one buffer so the received halos land in place
+        self.ext = torch.zeros((self.top + band_rows + self.bot, width, channels), dtype=dtype, device=device)
+
+    @property
+    def band(self) -> torch.Tensor:
+        return self.ext[self.top:self.top + self.band_rows]
+
+    def exchange(self) -> torch.Tensor:
+        """Send my first/last `halo` rows to the neighbours, receive theirs. Returns ext."""
+        if self.world == 1:
+            return self.ext
+        h, ops = self.halo, []
+        band = self.band
+        if self.rank > 0:
+            ops.append(dist.P2POp(dist.isend, band[:h], self._peer(self.rank - 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, self.ext[:h], self._peer(self.rank - 1), self.group))
+        if self.rank < self.world - 1:
+            ops.append(dist.P2POp(dist.isend, band[-h:], self._peer(self.rank + 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, self.ext[-h:], self._peer(self.rank + 1), self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return self.ext
+
+    def _peer(self, group_rank: int) -> int:
+        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
+
+
+def upscale_sharded(band: torch.Tensor, rank: int, world: int,
+                    compute: Callable[[torch.Tensor, int, int], torch.Tensor],
+                    xchg: Optional[BandExchange] = None, group=None) -> torch.Tensor:
+    """One sharded upscale: `band` = this rank's (rows, W, C) slice of the image;
+    `compute(ext, halo_top, halo_bot)` maps (top+rows+bot, W, C) -> (3*rows, 3W, C')
+    (Engine.upscale_band_*_dev on a GPU).  Returns this rank's output rows."""
+    if xchg is None:
+        xchg = BandExchange(band.shape[0], band.shape[1], band.shape[2], band.dtype, band.device, rank, world,
+                            group=group)
+    xchg.band.copy_(band)
+    ext = xchg.exchange()
+    return compute(ext, xchg.top, xchg.bot)
