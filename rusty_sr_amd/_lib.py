@@ -53,6 +53,14 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m rusty_sr_amd.build` "
                 "(hipcc --offload-arch=gfx950). rusty_sr_amd has no CPU fallback.")
+        # torch ships its own copy of the HIP runtime (SONAME libamdhip64.so.7, found
+        # through its RPATH).  Load it FIRST so libsrhip's NEEDED libamdhip64.so.7
+        # resolves to that same instance; two HIP runtimes in one process cannot
+        # both own the GPU ("No HIP GPUs are available" from whichever comes second).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)  # AttributeError if the ABI is incomplete

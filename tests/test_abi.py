@@ -1,0 +1,119 @@
+"""The C-ABI boundary (include/srhip.h <-> libsrhip.so) and the host-side logic that
+needs no GPU.  Compute entry points are exercised in test_gpu_parity.py."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, gpu_available
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "srhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rusty_sr_amd import _lib
+    L = _lib.lib()
+    declared = _header_functions()
+    assert len(declared) >= 16
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/srhip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared, "python binding table out of sync with the header"
+
+
+def test_header_constants_match_binding():
+    from rusty_sr_amd import _lib
+    src = open(os.path.join(ROOT, "include", "srhip.h")).read()
+    assert int(re.search(r"#define SR_NUM_PARAMS (\d+)", src).group(1)) == _lib.SR_NUM_PARAMS == oracle.NPARAMS
+    assert int(re.search(r"#define SR_HALO (\d+)", src).group(1)) == _lib.SR_HALO == 7
+    assert int(re.search(r"#define SR_FACTOR (\d+)", src).group(1)) == _lib.SR_FACTOR == 3
+    for name, val in re.findall(r"(SR_E_[A-Z_]+) = (-\d+)", src):
+        assert getattr(_lib, name) == int(val)
+
+
+def test_rsr_decode_matches_oracle_and_roundtrips(params):
+    import rusty_sr_amd as r
+    for name in r.rsr.BUILTIN:
+        blob = open(os.path.join(ROOT, "rusty_sr_amd", "res", name + ".rsr"), "rb").read()
+        p = r.rsr.decode(blob)
+        np.testing.assert_array_equal(p, params[name])
+        assert r.rsr.encode(p) == blob  # bytevec encode::<u32> is the exact inverse (main.rs:213)
+        np.testing.assert_array_equal(r.rsr.builtin(name), p)
+    assert r.rsr.encode(np.zeros(0, np.float32)) == b"\x00\x00\x00\x00"
+    assert r.rsr.decode(b"\x00\x00\x00\x00").size == 0
+
+
+@pytest.mark.parametrize("blob", [b"", b"\x01", b"\x01\x00\x00\x00",
+                                  b"\x01\x00\x00\x00\x08\x00\x00\x00\x00\x00\x00\x00",
+                                  b"\x02\x00\x00\x00" + b"\x04\x00\x00\x00" * 2 + b"\x00" * 7])
+def test_rsr_decode_rejects_malformed(blob):
+    import rusty_sr_amd as r
+    with pytest.raises(r.SrError) as e:
+        r.rsr.decode(blob)
+    assert "ByteVec conversion failed" in str(e.value)  # reference main.rs:138 message
+
+
+def test_create_validates_before_touching_the_gpu(params):
+    import rusty_sr_amd as r
+    from rusty_sr_amd import _lib
+    p = params["imagenet"]
+    with pytest.raises(r.SrError) as e:
+        r.Engine(p[:-1])
+    assert e.value.status == _lib.SR_E_PARAM_COUNT
+    assert "Parameters selected do not have the size required by the neural net" in str(e.value)  # main.rs:162
+    with pytest.raises(r.SrError) as e:
+        r.Engine(p, factor=4)
+    assert e.value.status == _lib.SR_E_FACTOR
+    with pytest.raises(r.SrError):
+        r.sr_net(4)
+    with pytest.raises(NotImplementedError):
+        r.sr_net(3, training=(1e-6, False))
+
+
+@pytest.mark.skipif(gpu_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback(params):
+    """Without a HIP device the engine refuses loudly instead of computing on the CPU."""
+    import rusty_sr_amd as r
+    from rusty_sr_amd import _lib
+    with pytest.raises(r.SrError) as e:
+        r.Engine(params["imagenet"])
+    assert e.value.status == _lib.SR_E_NO_DEVICE
+    g = r.sr_net(3)
+    inp = r.NodeData.new_blank(r.DataShape(3, [4, 4], 1))
+    with pytest.raises(r.SrError):
+        g.forward(1, [inp], params["imagenet"])
+
+
+def test_null_arguments_are_rejected():
+    from rusty_sr_amd import _lib
+    L = _lib.lib()
+    assert L.sr_create(None, None, 0, 3, 0) == _lib.SR_E_INVALID
+    assert L.sr_upscale_f32(None, None, 1, 1, 1, None) == _lib.SR_E_INVALID
+    assert L.sr_set_profiling(None, 1) == _lib.SR_E_INVALID
+    assert L.sr_strerror(_lib.SR_E_HALO).decode().startswith("band halo")
+    L.sr_destroy(None)  # no-op
+
+
+def test_img_to_data_matches_oracle():
+    import rusty_sr_amd as r
+    rng = np.random.default_rng(1)
+    px = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    np.testing.assert_array_equal(r.img_to_data(px), oracle.img_to_data(px))
+
+
+def test_product_never_touches_the_oracle():
+    """rusty_sr_amd (and bench/entry glue outside their checker legs) must not route
+    compute through oracle/: the package may not even mention it."""
+    pkg = os.path.join(ROOT, "rusty_sr_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle", text, flags=re.M), f
+                assert "sr_oracle" not in text, f

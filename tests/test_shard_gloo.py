@@ -1,0 +1,83 @@
+"""The N>1 path on CPU: two processes, gloo backend, the same BandExchange /
+upscale_sharded code bench.py and the multi-GPU driver use -- with the CPU oracle
+standing in for Engine.upscale_band_f32_dev as the per-band compute."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from conftest import ROOT, synth_u8
+from rusty_sr_amd.shard import BandExchange, round_robin, split_rows, upscale_sharded
+
+
+def test_split_rows_and_round_robin():
+    assert split_rows(2160, 8) == [(270 * k, 270 * (k + 1)) for k in range(8)]
+    b = split_rows(1081, 4)
+    assert b[0] == (0, 271) and b[-1][1] == 1081 and all(e - s in (270, 271) for s, e in b)
+    assert sum(e - s for s, e in split_rows(17, 5)) == 17
+    assert round_robin(64, 3, 8) == list(range(3, 64, 8))
+    assert sorted(sum((round_robin(10, r, 4) for r in range(4)), [])) == list(range(10))
+
+
+def test_single_rank_is_identity():
+    x = torch.arange(5 * 4 * 3, dtype=torch.float32).reshape(5, 4, 3)
+    got = upscale_sharded(x, 0, 1, lambda ext, t, b: (ext.clone(), t, b))
+    assert torch.equal(got[0], x) and got[1:] == (0, 0)
+
+
+def test_band_narrower_than_halo_is_refused():
+    with pytest.raises(ValueError):
+        BandExchange(5, 8, 3, torch.float32, "cpu", 0, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_band(params):
+    def compute(ext, top, bot):
+        y = oracle.forward(params, ext.numpy())[0]
+        h = ext.shape[0] - top - bot
+        return torch.from_numpy(np.ascontiguousarray(y[3 * top:3 * (top + h)]))
+    return compute
+
+
+def _worker(rank, world, port, h, w, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with open(os.path.join(ROOT, "rusty_sr_amd", "res", "imagenet.rsr"), "rb") as f:
+            params = oracle.rsr_decode(f.read())
+        x = torch.from_numpy(oracle.img_to_data(synth_u8(21, 1, h, w)[0]))
+        a, b = split_rows(h, world)[rank]
+        xchg = BandExchange(b - a, w, 3, torch.float32, "cpu", rank, world)
+        assert (xchg.top, xchg.bot) == (0 if rank == 0 else 7, 0 if rank == world - 1 else 7)
+        for _ in range(2):  # the exchange state is reusable step after step
+            out = upscale_sharded(x[a:b], rank, world, _oracle_band(params), xchg)
+        # halo rows really are the neighbours' rows
+        if rank > 0:
+            assert torch.equal(xchg.ext[:7], x[a - 7:a])
+        if rank < world - 1:
+            assert torch.equal(xchg.ext[-7:], x[b:b + 7])
+        torch.save(out, os.path.join(tmp, f"out{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 40), (3, 31)])
+def test_sharded_equals_unsharded_gloo(tmp_path, params, world, h):
+    w = 24
+    mp.spawn(_worker, args=(world, _free_port(), h, w, str(tmp_path)), nprocs=world, join=True)
+    got = torch.cat([torch.load(os.path.join(tmp_path, f"out{r}.pt")) for r in range(world)]).numpy()
+    want = oracle.forward(params["imagenet"], oracle.img_to_data(synth_u8(21, 1, h, w)))[0]
+    np.testing.assert_array_equal(got, want)  # bit-identical, SURVEY.md 8(e)
