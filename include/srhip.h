@@ -14,7 +14,7 @@
  *
  * Everything is plain C: pointers, sizes, ints.  No torch / HIP types appear
  * in a signature (`stream` is an opaque hipStream_t passed as void*; NULL =
- * the context's own stream).  A Rust host binds this with a 30-line
+ * HIP's default stream).  A Rust host binds this with a 30-line
  * `extern "C"` block (INTEGRATION.md shows it).
  *
  * Tensor layout everywhere: NHWC, channel fastest -- alumina's
@@ -80,8 +80,9 @@ int sr_upscale_rgba8(sr_ctx* ctx, const uint8_t* in, int in_channels, int n, int
                      uint8_t* out_rgba);
 
 /* Same two operations on buffers already resident in this context's device
- * memory (HBM); asynchronous on `stream` (opaque hipStream_t; NULL = the
- * context's stream).  These are what bench.py times and what the multi-GPU
+ * memory (HBM); asynchronous on `stream` (opaque hipStream_t; NULL = HIP's
+ * default stream, which is also torch's default stream).  The caller orders
+ * its own producers / consumers of d_in / d_out on that stream.  These are what bench.py times and what the multi-GPU
  * driver calls after its halo exchange. */
 int sr_upscale_f32_dev(sr_ctx* ctx, const float* d_in, int n, int h, int w, float* d_out,
                        void* stream);

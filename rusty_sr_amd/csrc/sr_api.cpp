@@ -261,7 +261,8 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     if (halo_top < 0 || halo_bot < 0 || halo_top + halo_bot >= H) return SR_E_INVALID;
     if ((halo_top || halo_bot) && n != 1) return SR_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    if (!s) s = c->stream;
+    // s == nullptr is HIP's legacy default stream (what torch's default stream is);
+    // the context's own non-blocking stream is used only by the host-pointer entry points.
     int rc = ensure_features(c, (size_t)n * H * W);
     if (rc != SR_OK) return rc;
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Collapse rocprofv3 CSV output (kernel stats + counter_collection) into one
+per-kernel table: average duration and average counter value per launch."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+rows = []
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "conv" in r["Name"]:
+            rows.append((r["Name"], int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+print("== kernel-trace --stats (per launch) ==")
+for name, calls, us, pct in sorted(rows, key=lambda r: -r[3]):
+    print(f"{name:70s} calls={calls:4d} avg={us:10.1f} us  {pct:5.1f}%")
+
+agg = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if "conv" not in k:
+            continue
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("\n== PMC counters, average per launch ==")
+for k in sorted(agg):
+    print(k)
+    for cn in sorted(agg[k]):
+        v = agg[k][cn]
+        print(f"    {cn:36s} {sum(v) / len(v):18.1f}   (n={len(v)})")
+    c = {cn: sum(v) / len(v) for cn, v in agg[k].items()}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"]:
+        print(f"    -> MFMA busy / SQ busy = {c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.3f}")
+    if "FETCH_SIZE" in c:
+        print(f"    -> HBM read  ~ {2 * c['FETCH_SIZE'] / 1024:.1f} MB (FETCH_SIZE KB x2: gfx950 tallies 128-B requests at 64 B)")
+    if "WRITE_SIZE" in c:
+        print(f"    -> HBM write ~ {c['WRITE_SIZE'] / 1024:.1f} MB (uncalibrated)")

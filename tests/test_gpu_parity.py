@@ -195,7 +195,8 @@ def test_full_size_properties_1080p(engines, params):
     eng = engines["imagenet"]
     px = synth_u8(2, 1, 1080, 1920)
     xt = torch.from_numpy(px).cuda()
-    x32 = (xt[..., :3].float() / 255.0).contiguous()
+    # true IEEE division on the host (torch divides by a scalar as x * (1/255): 1 ulp off)
+    x32 = torch.from_numpy(oracle.img_to_data(px)).cuda()
     full = eng.upscale_f32_dev(x32)
     band = eng.upscale_band_f32_dev(x32[0, 500 - 7:596 + 7].contiguous(), 7, 7)
     torch.cuda.synchronize()
