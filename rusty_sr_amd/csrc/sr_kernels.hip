@@ -32,6 +32,10 @@
 
 #include "sr_kernels.h"
 
+// The reference CPU path (rustc/LLVM) never fuses a*b+c; neither may we, or the two
+// instantiations of one kernel can differ in the last bit (packed-math vs fma selection).
+#pragma clang fp contract(off)
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -156,15 +160,18 @@ __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__
     constexpr int ITEMS = G::NPIX * 8;  // 16-byte items: (pixel, cin/4)
     constexpr int ROUNDS = (ITEMS + kThreads - 1) / kThreads;
     f32x4 v[ROUNDS];
+    // branch-free: out-of-image pixels load from a clamped (valid) address and are
+    // zeroed by a select -- the reference's zero padding (Padding::Same, network.rs:33).
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k) {
-        const int item = tid + k * kThreads;
+        const int item = min(tid + k * kThreads, ITEMS - 1);
         const int p = item >> 3, c = item & 7;
         const int py = p / G::TWH, px = p - py * G::TWH;
         const int gy = y0 - G::R + py, gx = x0 - G::R + px;
-        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (item < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v[k] = *(const f32x4*)(src + (((size_t)n * H + gy) * W + gx) * 32 + c * 4);
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+        const f32x4 ld = *(const f32x4*)(src + (((size_t)n * H + cy) * W + cx) * 32 + c * 4);
+        const bool inb = (gy == cy) && (gx == cx);
+        v[k] = inb ? ld : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int k = 0; k < ROUNDS; ++k) {
@@ -174,34 +181,57 @@ __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__
     }
 }
 
+// Asynchronous 4 KB weight-chunk copy global -> LDS ring slot (LDS-DMA, no VGPR
+// round trip): each wave moves 1 KB, lane l lands at base + 16*l, which is
+// exactly the packed chunk order.  Completion is covered by the vmcnt(0) the
+// compiler places in front of the next __syncthreads().
+__device__ __forceinline__ void weight_chunk_async(char* ring_slot, const float* __restrict__ chunk,
+                                                   int wave, int lane) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(chunk + (wave * 64 + lane) * 4),
+        (__attribute__((address_space(3))) void*)(ring_slot + wave * 1024), 16, 0, 0);
+}
+
 template <int TH, int KS, int T>
 __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, char* ring,
                                           const float* __restrict__ wpack, int& gtap, int ntaps_total,
-                                          int wave, int i, int h, int tid) {
+                                          int wave, int lane) {
     using G = TileGeom<TH, KS>;
+    const int i = lane & 31, h = lane >> 5;
     const char* abase = tile + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
-            // prefetch the next tap's 4 KB weight chunk (one 16-B load per thread)
-            f32x4 wnext = {0.f, 0.f, 0.f, 0.f};
-            const bool more = gtap + 1 < ntaps_total;
-            if (more) wnext = *(const f32x4*)(wpack + (size_t)(gtap + 1) * kChunkFloats + tid * 4);
+            // next tap's 4 KB weight chunk -> the ring slot nobody reads during this tap
+            if (gtap + 1 < ntaps_total)
+                weight_chunk_async(ring + ((gtap + 1) & 1) * 4096, wpack + (size_t)(gtap + 1) * kChunkFloats, wave, lane);
             const char* wb = ring + (gtap & 1) * 4096 + (h * 32 + i) * 16;
             const char* ab = abase + (ky * G::TWH + kx) * 16;
+            // operands of channel-group rr+1 are fetched while group rr's MFMAs run
+            f32x4 b[2], av[2][T];
+            b[0] = *(const f32x4*)(wb);
+#pragma unroll
+            for (int m = 0; m < T; ++m) av[0][m] = *(const f32x4*)(ab + m * G::TWH * 16);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const f32x4 b = *(const f32x4*)(wb + rr * 1024);
+                const int cur = rr & 1, nxt = cur ^ 1;
+                if (rr < 3) {
+                    b[nxt] = *(const f32x4*)(wb + (rr + 1) * 1024);
 #pragma unroll
-                for (int m = 0; m < T; ++m) {
-                    const f32x4 av = *(const f32x4*)(ab + rr * 2 * G::PLANE + m * G::TWH * 16);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b.z, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b.w, acc[m], 0, 0, 0);
+                    for (int m = 0; m < T; ++m)
+                        av[nxt][m] = *(const f32x4*)(ab + (rr + 1) * 2 * G::PLANE + m * G::TWH * 16);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int m = 0; m < T; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m][q], b[cur][q], acc[m], 0, 0, 0);
+                // pin the interleave: one MFMA, then the next group's LDS reads (their
+                // latency hides under the remaining 4T-1 MFMAs of 64 cycles each)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (rr < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1 + T, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * T - 1, 0);
             }
-            if (more) *(f32x4*)(ring + ((gtap + 1) & 1) * 4096 + tid * 16) = wnext;
             ++gtap;
             __syncthreads();
         }
@@ -232,21 +262,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stage_kernel(StageArgs a) {
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
     // weight chunk 0 -> ring slot 0
-    *(f32x4*)(ring + tid * 16) = *(const f32x4*)(a.wpack + tid * 4);
+    weight_chunk_async(ring, a.wpack, wave, lane);
     int gtap = 0;
 
     stage_tile<TH, KS0>(tile, a.src[0], n, a.H, a.W, y0, x0, tid);
     __syncthreads();
-    conv_taps<TH, KS0, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, i, h, tid);
+    conv_taps<TH, KS0, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, lane);
     if constexpr (NSRC >= 2) {
         stage_tile<TH, 3>(tile, a.src[1], n, a.H, a.W, y0, x0, tid);
         __syncthreads();
-        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, i, h, tid);
+        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, lane);
     }
     if constexpr (NSRC >= 3) {
         stage_tile<TH, 3>(tile, a.src[2], n, a.H, a.W, y0, x0, tid);
         __syncthreads();
-        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, i, h, tid);
+        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, lane);
     }
 
     const float bias = a.bias[i];
