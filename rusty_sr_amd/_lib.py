@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsrhip.so")
+LIB_PATH = os.environ.get("SRHIP_LIB", os.path.join(HERE, "libsrhip.so"))  # override: A/B kernel experiments
 
 SR_FACTOR = 3
 SR_NUM_PARAMS = 130459

@@ -54,6 +54,24 @@ void pack_conv0(std::vector<float>& dst, const float* w) {
                 }
 }
 
+// LinearInterp x3 (network.rs:27) as a 3x3 convolution of the edge-replicated
+// 3-channel input onto the 27 expand channels: 9 taps x [h 2][o 32][q 2], cin = 2h+q.
+// Along one axis, output phase p reads inputs (i-1, i, i+1) with weights
+//   p=0: (1-t, t, 0), t = 2/3    p=1: (0, 1, 0)    p=2: (0, 1-t, t), t = 1/3
+// (half-pixel centres); the 2-D weight is the f32 product.
+void pack_lin(std::vector<float>& dst) {
+    const float t0 = 2.0f / 3.0f, t2 = 1.0f / 3.0f;
+    const float w1[3][3] = {{1.0f - t0, t0, 0.0f}, {0.0f, 1.0f, 0.0f}, {0.0f, 1.0f - t2, t2}};
+    const size_t base = dst.size();
+    dst.resize(base + 9 * 128, 0.0f);
+    for (int u = 0; u < 3; ++u)
+        for (int v = 0; v < 3; ++v)
+            for (int o = 0; o < 27; ++o) {
+                const int dy = o / 9, dx = (o % 9) / 3, c = o % 3;
+                dst[base + (u * 3 + v) * 128 + ((c >> 1) * 32 + o) * 2 + (c & 1)] = w1[dy][u] * w1[dx][v];
+            }
+}
+
 }  // namespace
 
 struct sr_ctx {
@@ -178,6 +196,7 @@ int sr_create(sr_ctx** out, const float* params, size_t n_params, int factor, in
         c->off_w[3] = push(w);
         w.clear(); pack_conv32(w, params + OFF_CONV7, 27, 3); pack_conv32(w, params + OFF_CONV9, 27, 3);
         pack_conv32(w, params + OFF_CONV10, 27, 3);
+        pack_lin(w);
         c->off_w[4] = push(w);
         const size_t boff[5] = {OFF_F_BIAS, OFF_L1_BIAS, OFF_L2_BIAS, OFF_L3_BIAS, OFF_EXP_BIAS};
         const size_t aoff[4] = {OFF_F_ACTIV, OFF_L1_ACTIV, OFF_L2_ACTIV, OFF_L3_ACTIV};
@@ -271,7 +290,8 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     const int tiles_x = (W + 31) / 32;
     // tile height: 8 rows when that still gives every CU two workgroups, else 4
     const long tiles8 = (long)n * tiles_x * ((bot - top + 7) / 8);
-    const int th = tiles8 >= 2L * (c->cus > 0 ? c->cus : 256) ? 8 : 4;
+    int th = tiles8 >= 2L * (c->cus > 0 ? c->cus : 256) ? 8 : 4;
+    if (const char* e = getenv("SRHIP_TH")) th = atoi(e) == 4 ? 4 : 8;  // experiment override
     const float* P = c->d_params;
     const bool prof = c->profiling;
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));

@@ -12,21 +12,27 @@
 //  * each stage is ONE implicit-GEMM kernel: M = 32 pixels of a tile row,
 //    N = 32 output channels, K = concatenation of every tap of every source
 //    feeding the node (the reference's "ops accumulate into a node" becomes
-//    K-concatenation; accumulators never leave registers);
+//    K-concatenation; accumulators never leave registers).  Even the bilinear
+//    x3 residual (LinearInterp, network.rs:27) is K-concatenated into the last
+//    stage: it is a fixed-weight 3x3 convolution of the edge-replicated input
+//    onto the 27 expand channels;
 //  * v_mfma_f32_32x32x2_f32 -- exact f32 (bitwise an fmaf chain), so parity with
 //    the f32 CPU path holds to rounding-order noise (~1e-6), far inside 1e-4;
+//  * MEASURED on MI355X (scripts/ubench_mfma.hip): the f32-input MFMA shares the
+//    SIMD's vector ALU -- a co-resident wave's VALU instruction costs ~10 cycles
+//    of MFMA time, nothing overlaps.  So the kernels are written to execute as
+//    few VALU instructions as possible: tile staging uses wave-uniform (SGPR) row
+//    bases + immediates, LDS operand addresses are immediates off one per-lane
+//    base, weights arrive by LDS-DMA, the epilogue stores at immediate offsets;
 //  * a workgroup (4 waves) owns a TH x 32 pixel tile; the source tile + halo is
 //    staged in LDS in a channel-group-planar layout [cin/4][pixel][4 f32] so
-//    that every A-operand fetch is one conflict-free ds_read_b128 at a
-//    compile-time offset from a per-lane base (one lane = one pixel, 16 lanes of
-//    a service group = 16 consecutive 16-B slots);
+//    that every A-operand fetch is one conflict-free ds_read_b128;
 //  * weights are pre-packed on the host into 4 KB per-tap chunks in the exact
-//    order the B-operand ds_read_b128 wants ([cin/4][cout][4]) and streamed
-//    through a 2-slot LDS ring, one chunk per tap, one barrier per tap;
-//  * LDS per workgroup <= 64 KB -> 2 workgroups per CU: one stages its tile
-//    while the other keeps the matrix pipe busy;
-//  * bias + BeLU (or bias + bilinear residual + depth-to-space [+ u8 RGBA
-//    quantisation]) are fused into the epilogue: no elementwise kernel exists.
+//    order the B-operand ds_read_b128 wants ([cin/4][cout][4]) and streamed by
+//    LDS-DMA through a 3-slot ring two taps ahead of use, one barrier per tap;
+//  * LDS per workgroup <= 68 KB -> 2 workgroups per CU (3 with 4-row tiles);
+//  * bias + BeLU (or bias + depth-to-space [+ u8 RGBA quantisation]) are fused
+//    into the epilogue: no elementwise kernel exists.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -40,16 +46,29 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Optional per-workgroup phase timestamps for scripts/timeline.hip (never compiled
+// into the product library).
+#ifdef SR_TIMELINE
+__device__ long long* g_tl;
+#define TL(k) do { if (threadIdx.x == 0) g_tl[(size_t)blockIdx.x * 16 + (k)] = (k) == 0 ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TL(k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kTW = 32;            // tile width = one MFMA M-tile of pixels
 constexpr int kChunkFloats = 1024; // one tap: 32 cin x 32 cout
+constexpr int kRingSlots = 3;      // 4 KB weight chunks: one being read, two in flight
+constexpr int kRingBytes = kRingSlots * 4096;
 
 __device__ __forceinline__ float belu(float v, float beta) {
-    // alumina BeLU (network.rs:35,54-56): beta*x + sqrt(x*x+1) - 1, kept in the
-    // same naive form as the reference; no contraction.
-    return __fadd_rn(__fadd_rn(__fmul_rn(beta, v), __fsqrt_rn(__fadd_rn(__fmul_rn(v, v), 1.0f))), -1.0f);
+    // alumina BeLU (network.rs:35,54-56): beta*x + sqrt(x*x+1) - 1, same operation
+    // order as the reference, no contraction.  sqrt is the
+    // hardware v_sqrt_f32 (1 ulp; argument >= 1): the correctly-rounded expansion
+    // costs ~12 more VALU instructions per value, each ~10 cycles of f32-MFMA time.
+    return __fadd_rn(__fadd_rn(__fmul_rn(beta, v), __builtin_amdgcn_sqrtf(__fadd_rn(__fmul_rn(v, v), 1.0f))), -1.0f);
 }
 
 // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each
@@ -66,6 +85,15 @@ __device__ __forceinline__ float load_img(const void* img, int img_ch, bool u8, 
     return ((const float*)img)[px * 3 + c];
 }
 
+// Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`
+// (row = (r&3) + 8*(r>>2); the lane's +4*h is already in `base`): compile-time
+// offsets, so each store is one instruction with an immediate.
+template <typename F>
+__device__ __forceinline__ void for_each_acc_row(F&& f) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) f(r, (r & 3) + 8 * (r >> 2));
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -79,7 +107,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     __shared__ __attribute__((aligned(16))) float s_x[NPIX * 4];
     __shared__ __attribute__((aligned(16))) float s_w[25 * 128];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -101,6 +130,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
         }
         *(f32x4*)&s_x[p * 4] = v;
     }
+    const float bias = a.bias[i], beta = a.beta[i];
     __syncthreads();
 
     f32x16 acc[T];
@@ -125,24 +155,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
         }
     }
 
-    const float bias = a.bias[i], beta = a.beta[i];
+    const bool full_x = x0 + kTW <= a.W;
 #pragma unroll
     for (int m = 0; m < T; ++m) {
         const int y = y0 + wave * T + m;
         if (y >= a.y_end) continue;
-        float* drow = a.dst + (((size_t)n * a.H + y) * a.W) * 32 + i;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (x < a.W) drow[(size_t)x * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
+        float* base = a.dst + (((size_t)n * a.H + y) * a.W + x0 + 4 * h) * 32 + i;
+        if (full_x) {
+            for_each_acc_row([&](int r, int row) { base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta); });
+        } else {
+            for_each_acc_row([&](int r, int row) {
+                if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
+            });
         }
     }
 }
 
 // ---------------------------------------------------------------------------
 // Stages 1-4: sum of up to three 32-channel convolutions (first KS0 x KS0,
-// the others 3x3) + bias, then BeLU -> NHWC feature map, or (FINAL) bilinear
-// residual + depth-to-space -> output image.
+// the others 3x3) + bias, then BeLU -> NHWC feature map, or (FINAL) + the
+// bilinear residual as a fourth K-segment, depth-to-space -> output image.
 // ---------------------------------------------------------------------------
 template <int TH, int KS>
 struct TileGeom {
@@ -153,38 +185,66 @@ struct TileGeom {
     static constexpr int PLANE = (NPIX | 1) * 16;  // bytes; odd pixel count -> conflict-free staging writes
 };
 
+// Stage one source tile (+halo) into LDS, planar [cin/4][pixel][16 B].  Wave w
+// takes tile rows w, w+4, ...: a tile row is ONE contiguous TWH*128-byte run of the
+// NHWC map, lane l moves the 16-byte pieces l, l+64, ... of it, so every load and
+// every ds_write is `wave-uniform base + per-lane constant + immediate`.  Rows /
+// columns outside the image are the reference's zero padding (Padding::Same).
 template <int TH, int KS>
 __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, int n, int H,
-                                           int W, int y0, int x0, int tid) {
+                                           int W, int y0, int x0, int wave, int lane) {
     using G = TileGeom<TH, KS>;
-    constexpr int ITEMS = G::NPIX * 8;  // 16-byte items: (pixel, cin/4)
-    constexpr int ROUNDS = (ITEMS + kThreads - 1) / kThreads;
-    f32x4 v[ROUNDS];
-    // branch-free: out-of-image pixels load from a clamped (valid) address and are
-    // zeroed by a select -- the reference's zero padding (Padding::Same, network.rs:33).
+    constexpr int ROW_ITEMS = G::TWH * 8;          // 16-byte pieces per tile row
+    constexpr int NQ = (ROW_ITEMS + 63) / 64;
+    constexpr int REM = ROW_ITEMS - (NQ - 1) * 64;  // lanes active in the last piece group
+    constexpr int RPW = (G::THH + 3) / 4;           // rows per wave
+    const int lds_lane = (lane & 7) * G::PLANE + (lane >> 3) * 16;
+    const bool interior_x = x0 >= G::R && x0 + kTW + G::R <= W;  // wave-uniform
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[RPW][NQ];
 #pragma unroll
-    for (int k = 0; k < ROUNDS; ++k) {
-        const int item = min(tid + k * kThreads, ITEMS - 1);
-        const int p = item >> 3, c = item & 7;
-        const int py = p / G::TWH, px = p - py * G::TWH;
-        const int gy = y0 - G::R + py, gx = x0 - G::R + px;
-        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-        const f32x4 ld = *(const f32x4*)(src + (((size_t)n * H + cy) * W + cx) * 32 + c * 4);
-        const bool inb = (gy == cy) && (gx == cx);
-        v[k] = inb ? ld : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int r = 0; r < RPW; ++r) {
+        const int py = wave + 4 * r, gy = y0 - G::R + py;
+        const bool row_ok = py < G::THH && gy >= 0 && gy < H;  // wave-uniform
+        const float* rowp = src + (((size_t)n * H + (row_ok ? gy : 0)) * W + (x0 - G::R)) * 32;
 #pragma unroll
-    for (int k = 0; k < ROUNDS; ++k) {
-        const int item = tid + k * kThreads;
-        const int p = item >> 3, c = item & 7;
-        if (item < ITEMS) *(f32x4*)(tile + c * G::PLANE + p * 16) = v[k];
+        for (int q = 0; q < NQ; ++q) {
+            v[r][q] = zero;
+            const int item = lane + 64 * q;
+            if (row_ok && (q < NQ - 1 || lane < REM)) {
+                if (interior_x) {
+                    v[r][q] = *(const f32x4*)(rowp + item * 4);
+                } else {
+                    const int gx = x0 - G::R + (item >> 3);
+                    if (gx >= 0 && gx < W) v[r][q] = *(const f32x4*)(rowp + item * 4);
+                }
+            }
+        }
     }
+    TL(8);
+#ifdef SR_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL(9);
+#endif
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int py = wave + 4 * r;
+        if (py < G::THH) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (q < NQ - 1 || lane < REM)
+                    *(f32x4*)(tile + lds_lane + (py * G::TWH + q * 8) * 16) = v[r][q];
+        }
+    }
+#ifdef SR_TIMELINE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TL(10);
+#endif
 }
 
 // Asynchronous 4 KB weight-chunk copy global -> LDS ring slot (LDS-DMA, no VGPR
 // round trip): each wave moves 1 KB, lane l lands at base + 16*l, which is
-// exactly the packed chunk order.  Completion is covered by the vmcnt(0) the
-// compiler places in front of the next __syncthreads().
+// exactly the packed chunk order.
 __device__ __forceinline__ void weight_chunk_async(char* ring_slot, const float* __restrict__ chunk,
                                                    int wave, int lane) {
     __builtin_amdgcn_global_load_lds(
@@ -192,61 +252,112 @@ __device__ __forceinline__ void weight_chunk_async(char* ring_slot, const float*
         (__attribute__((address_space(3))) void*)(ring_slot + wave * 1024), 16, 0, 0);
 }
 
+// Workgroup barrier that lets the newest `PENDING` LDS-DMA chunk loads stay in
+// flight across it (a plain __syncthreads() would drain them: vmcnt(0)).  All of
+// this wave's LDS reads are retired first, so the slot the next DMA overwrites
+// is no longer being read by anybody once every wave has passed.
+template <int PENDING>
+__device__ __forceinline__ void ring_barrier() {
+    if constexpr (PENDING == 1)
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// One source's KS x KS taps.  The weight chunk of tap t+2 is requested (LDS-DMA)
+// while tap t computes, so a chunk has two full taps (~4000 cycles) to land.
 template <int TH, int KS, int T>
 __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, char* ring,
-                                          const float* __restrict__ wpack, int& gtap, int ntaps_total,
-                                          int wave, int lane) {
+                                          const float* __restrict__ wpack, int& gtap, int& slot,
+                                          int ntaps_total, int wave, int lane) {
     using G = TileGeom<TH, KS>;
     const int i = lane & 31, h = lane >> 5;
+    const int wlane = (h * 32 + i) * 16;
     const char* abase = tile + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
-            // next tap's 4 KB weight chunk -> the ring slot nobody reads during this tap
-            if (gtap + 1 < ntaps_total)
-                weight_chunk_async(ring + ((gtap + 1) & 1) * 4096, wpack + (size_t)(gtap + 1) * kChunkFloats, wave, lane);
-            const char* wb = ring + (gtap & 1) * 4096 + (h * 32 + i) * 16;
+            const bool more = gtap + 2 < ntaps_total;
+            const int slot2 = slot >= 1 ? slot - 1 : slot + 2;  // (slot + 2) % 3: free since the last barrier
+            if (more)
+                weight_chunk_async(ring + slot2 * 4096, wpack + (size_t)(gtap + 2) * kChunkFloats, wave, lane);
+            const char* wb = ring + slot * 4096 + wlane;
             const char* ab = abase + (ky * G::TWH + kx) * 16;
-            // operands of channel-group rr+1 are fetched while group rr's MFMAs run
-            f32x4 b[2], av[2][T];
-            b[0] = *(const f32x4*)(wb);
-#pragma unroll
-            for (int m = 0; m < T; ++m) av[0][m] = *(const f32x4*)(ab + m * G::TWH * 16);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int cur = rr & 1, nxt = cur ^ 1;
-                if (rr < 3) {
-                    b[nxt] = *(const f32x4*)(wb + (rr + 1) * 1024);
+                const f32x4 b = *(const f32x4*)(wb + rr * 1024);
+                f32x4 av[T];
 #pragma unroll
-                    for (int m = 0; m < T; ++m)
-                        av[nxt][m] = *(const f32x4*)(ab + (rr + 1) * 2 * G::PLANE + m * G::TWH * 16);
-                }
+                for (int m = 0; m < T; ++m) av[m] = *(const f32x4*)(ab + rr * 2 * G::PLANE + m * G::TWH * 16);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int m = 0; m < T; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m][q], b[cur][q], acc[m], 0, 0, 0);
-                // pin the interleave: one MFMA, then the next group's LDS reads (their
-                // latency hides under the remaining 4T-1 MFMAs of 64 cycles each)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (rr < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1 + T, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * T - 1, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], b[q], acc[m], 0, 0, 0);
             }
             ++gtap;
-            __syncthreads();
+            slot = slot == kRingSlots - 1 ? 0 : slot + 1;
+            if (more) ring_barrier<1>(); else ring_barrier<0>();  // chunk gtap has landed everywhere
+        }
+    }
+}
+
+// Final stage only: the bilinear x3 residual (LinearInterp, network.rs:27) as nine
+// more taps of a 4-channel (RGB + zero) source.  The image tile is staged with
+// edge-REPLICATED coordinates (the interp clamps indices, it does not zero-pad),
+// the fixed weights (phase products {1/3, 2/3, 1}^2, built on the host) sit in the
+// weight pack behind the conv chunks: 9 x [cin/2][cout 32][2] floats.
+template <int TH, int T, bool IMG_U8>
+__device__ __forceinline__ void lin_taps(f32x16 (&acc)[T], char* tile, char* ring, const StageArgs& a,
+                                         const float* __restrict__ wlin, int n, int y0, int x0, int wave,
+                                         int lane, int tid) {
+    constexpr int TWH = kTW + 2, THH = TH + 2, NPIX = THH * TWH;
+    float* s_x = (float*)tile;   // [pixel][4]
+    float* s_w = (float*)ring;   // 9 x 128 floats
+    const size_t img_px0 = (size_t)n * a.H * a.W;
+    for (int k = tid; k < 9 * 128; k += kThreads) s_w[k] = wlin[k];
+    for (int p = tid; p < NPIX; p += kThreads) {
+        const int py = p / TWH, px = p - py * TWH;
+        const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
+        const size_t gp = img_px0 + (size_t)gy * a.W + gx;
+        f32x4 v;
+        v.x = load_img(a.img, a.img_ch, IMG_U8, gp, 0);
+        v.y = load_img(a.img, a.img_ch, IMG_U8, gp, 1);
+        v.z = load_img(a.img, a.img_ch, IMG_U8, gp, 2);
+        v.w = 0.f;
+        *(f32x4*)&s_x[p * 4] = v;
+    }
+    __syncthreads();
+    const int i = lane & 31, h = lane >> 5;
+    const float* xa = s_x + ((wave * T) * TWH + i) * 4 + h * 2;
+    const float* wb = s_w + (h * 32 + i) * 2;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const f32x2 b = *(const f32x2*)(wb + (ky * 3 + kx) * 128);
+#pragma unroll
+            for (int m = 0; m < T; ++m) {
+                const f32x2 av = *(const f32x2*)(xa + ((m + ky) * TWH + kx) * 4);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[m], 0, 0, 0);
+            }
         }
     }
 }
 
 template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8>
-__global__ __launch_bounds__(kThreads, 2) void conv_stage_kernel(StageArgs a) {
+__global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(StageArgs a) {
     constexpr int T = TH / 4;
     using G0 = TileGeom<TH, KS0>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tile = smem;
     char* ring = smem + 8 * G0::PLANE;  // KS0 >= 3: the first source has the largest tile
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -261,84 +372,87 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stage_kernel(StageArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    // weight chunk 0 -> ring slot 0
+    // weight chunks 0 and 1 -> ring slots 0 and 1 (every stage has >= 25 taps)
     weight_chunk_async(ring, a.wpack, wave, lane);
-    int gtap = 0;
-
-    stage_tile<TH, KS0>(tile, a.src[0], n, a.H, a.W, y0, x0, tid);
+    weight_chunk_async(ring + 4096, a.wpack + kChunkFloats, wave, lane);
+    int gtap = 0, slot = 0;
+    TL(0); TL(1);
+    stage_tile<TH, KS0>(tile, a.src[0], n, a.H, a.W, y0, x0, wave, lane);
+    const float bias = a.bias[i];
+    const float beta = FINAL ? 0.f : a.beta[i];
     __syncthreads();
-    conv_taps<TH, KS0, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, lane);
+    TL(2);
+    conv_taps<TH, KS0, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+    TL(3);
     if constexpr (NSRC >= 2) {
-        stage_tile<TH, 3>(tile, a.src[1], n, a.H, a.W, y0, x0, tid);
+        stage_tile<TH, 3>(tile, a.src[1], n, a.H, a.W, y0, x0, wave, lane);
         __syncthreads();
-        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, lane);
+        TL(4);
+        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+        TL(5);
     }
     if constexpr (NSRC >= 3) {
-        stage_tile<TH, 3>(tile, a.src[2], n, a.H, a.W, y0, x0, tid);
+        stage_tile<TH, 3>(tile, a.src[2], n, a.H, a.W, y0, x0, wave, lane);
         __syncthreads();
-        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, NTAPS, wave, lane);
+        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
     }
+    if constexpr (FINAL)
+        lin_taps<TH, T, IMG_U8>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
+    TL(6);
 
-    const float bias = a.bias[i];
+    const bool full_x = x0 + kTW <= a.W;
     if constexpr (!FINAL) {
-        const float beta = a.beta[i];
 #pragma unroll
         for (int m = 0; m < T; ++m) {
             const int y = y0 + wave * T + m;
             if (y >= a.y_end) continue;
-            float* drow = a.dst + (((size_t)n * a.H + y) * a.W) * 32 + i;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (x < a.W) drow[(size_t)x * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
+            float* base = a.dst + (((size_t)n * a.H + y) * a.W + x0 + 4 * h) * 32 + i;
+            if (full_x) {
+                for_each_acc_row([&](int r, int row) { base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta); });
+            } else {
+                for_each_acc_row([&](int r, int row) {
+                    if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
+                });
             }
         }
     } else {
-        // lane i < 27 owns expand channel i = (dy*3+dx)*3+c (network.rs:37,39).
-        // LinearInterp x3 (network.rs:27): half-pixel centres, edge clamped;
-        // phase 0: 1/3 in[i-1] + 2/3 in[i]; phase 1: in[i]; phase 2: 2/3 in[i] + 1/3 in[i+1].
+        // Expand (network.rs:39): lane i < 27 owns expand channel i = (dy*3+dx)*3+c;
+        // out[3y+dy][3x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
         const int ch = i < 27 ? i : 26;
-        const int dy = ch / 9, dx = (ch - dy * 9) / 3, c = ch - dy * 9 - dx * 3;
-        const float tyw = dy == 0 ? (2.0f / 3.0f) : (dy == 1 ? 0.0f : (1.0f / 3.0f));
-        const float txw = dx == 0 ? (2.0f / 3.0f) : (dx == 1 ? 0.0f : (1.0f / 3.0f));
-        const int oy_d = dy == 0 ? -1 : 0, ox_d = dx == 0 ? -1 : 0;
-        const size_t img_px0 = (size_t)n * a.H * a.W;
+        const int dy = ch / 9, sub = ch - dy * 9;  // sub = dx*3 + c
         const int OW = a.W * 3;
         const int h_band = a.y_end - a.y_begin;
 #pragma unroll
         for (int m = 0; m < T; ++m) {
             const int y = y0 + wave * T + m;
             if (y >= a.y_end) continue;
-            const int ya = min(max(y + oy_d, 0), a.H - 1), yb = min(max(y + oy_d + 1, 0), a.H - 1);
-            const size_t orow = ((size_t)n * h_band * 3 + (size_t)(y - a.y_begin) * 3 + dy) * OW;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int xc = min(x, a.W - 1);
-                const int xa = min(max(xc + ox_d, 0), a.W - 1), xb = min(max(xc + ox_d + 1, 0), a.W - 1);
-                const float v00 = load_img(a.img, a.img_ch, IMG_U8, img_px0 + (size_t)ya * a.W + xa, c);
-                const float v01 = load_img(a.img, a.img_ch, IMG_U8, img_px0 + (size_t)ya * a.W + xb, c);
-                const float v10 = load_img(a.img, a.img_ch, IMG_U8, img_px0 + (size_t)yb * a.W + xa, c);
-                const float v11 = load_img(a.img, a.img_ch, IMG_U8, img_px0 + (size_t)yb * a.W + xb, c);
-                const float ra = __fadd_rn(__fmul_rn(1.0f - txw, v00), __fmul_rn(txw, v01));
-                const float rb = __fadd_rn(__fmul_rn(1.0f - txw, v10), __fmul_rn(txw, v11));
-                const float lin = __fadd_rn(__fmul_rn(1.0f - tyw, ra), __fmul_rn(tyw, rb));
-                const float v = __fadd_rn(lin, __fadd_rn(acc[m][r], bias));
-                const size_t opx = orow + (size_t)x * 3 + dx;
-                if constexpr (!OUT_U8) {
-                    if (i < 27 && x < a.W) ((float*)a.out)[opx * 3 + c] = v;
+            const size_t opx = ((size_t)n * h_band * 3 + (size_t)(y - a.y_begin) * 3 + dy) * OW + 3 * (x0 + 4 * h);
+            if constexpr (!OUT_U8) {
+                float* base = (float*)a.out + opx * 3 + sub;
+                if (full_x) {
+                    for_each_acc_row([&](int r, int row) { if (i < 27) base[row * 9] = __fadd_rn(acc[m][r], bias); });
                 } else {
-                    // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255
-                    float q = floorf(__fadd_rn(__fmul_rn(255.0f, v), 0.5f));
+                    for_each_acc_row([&](int r, int row) {
+                        if (i < 27 && x0 + 4 * h + row < a.W) base[row * 9] = __fadd_rn(acc[m][r], bias);
+                    });
+                }
+            } else {
+                // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255;
+                // the lane holding c == 0 gathers G and B from its two neighbours
+                uint32_t* base = (uint32_t*)a.out + opx + sub / 3;
+                const bool writer = i < 27 && (sub % 3) == 0;
+                for_each_acc_row([&](int r, int row) {
+                    float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(acc[m][r], bias)), 0.5f));
                     q = fminf(fmaxf(q, 0.0f), 255.0f);
                     const uint32_t qi = (uint32_t)q;
                     const uint32_t g = __shfl_down(qi, 1), b = __shfl_down(qi, 2);
-                    if (i < 27 && c == 0 && x < a.W)
-                        ((uint32_t*)a.out)[opx] = qi | (g << 8) | (b << 16) | 0xff000000u;
-                }
+                    if (writer && (full_x || x0 + 4 * h + row < a.W))
+                        base[row * 3] = qi | (g << 8) | (b << 16) | 0xff000000u;
+                });
             }
         }
     }
+    TL(7);
 }
 
 // ---------------------------------------------------------------------------
@@ -346,7 +460,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_stage_kernel(StageArgs a) {
 // ---------------------------------------------------------------------------
 template <int TH, int KS0>
 static constexpr size_t stage_lds_bytes() {
-    return 8 * (size_t)TileGeom<TH, KS0>::PLANE + 2 * 4096;
+    return 8 * (size_t)TileGeom<TH, KS0>::PLANE + kRingBytes;
 }
 
 template <int TH>

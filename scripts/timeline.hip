@@ -1,0 +1,48 @@
+// Per-workgroup phase timeline of one conv stage kernel on a 1920x1080 map.
+// hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I rusty_sr_amd/csrc scripts/timeline.hip -o exp/timeline
+#define SR_TIMELINE 1
+#include "../rusty_sr_amd/csrc/sr_kernels.hip"
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+int main(int argc, char** argv) {
+    const int stage = argc > 1 ? atoi(argv[1]) : 1, th = argc > 2 ? atoi(argv[2]) : 8;
+    const int H = 1080, W = 1920;
+    const size_t npx = (size_t)H * W;
+    float *f[3], *dst, *w, *bias; void* out;
+    for (auto& p : f) { hipMalloc(&p, npx * 128); hipMemset(p, 0, npx * 128); }
+    hipMalloc(&dst, npx * 128); hipMalloc(&out, npx * 9 * 12);
+    hipMalloc(&w, 43 * 4096); hipMemset(w, 0, 43 * 4096);
+    hipMalloc(&bias, 256); hipMemset(bias, 0, 256);
+    StageArgs a{};
+    a.src[0] = f[0]; a.src[1] = f[1]; a.src[2] = f[2]; a.wpack = w; a.bias = bias; a.beta = bias; a.dst = dst;
+    a.img = f[0]; a.out = out; a.H = H; a.W = W; a.img_ch = 3; a.y_begin = 0; a.y_end = H;
+    a.tiles_x = W / 32; a.tiles_y = (H + th - 1) / th;
+    const int nblk = a.tiles_x * a.tiles_y;
+    long long* tl; hipMalloc(&tl, (size_t)nblk * 128);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
+    for (int rep = 0; rep < 3; ++rep) sr_launch_stage(stage, a, th, nblk, false, false, 0);
+    hipDeviceSynchronize();
+    std::vector<long long> h((size_t)nblk * 16);
+    hipMemcpy(h.data(), tl, (size_t)nblk * 128, hipMemcpyDeviceToHost);
+    auto stat = [&](const char* name, int k0, int k1) {
+        std::vector<long long> d;
+        for (int b = 0; b < nblk; ++b) d.push_back(h[b * 16 + k1] - h[b * 16 + k0]);
+        std::sort(d.begin(), d.end());
+        double s = 0; for (auto v : d) s += v;
+        printf("  %-28s mean %9.0f  p10 %8lld  p50 %8lld  p90 %8lld  max %8lld cycles\n", name, s / nblk,
+               d[nblk / 10], d[nblk / 2], d[nblk * 9 / 10], d[nblk - 1]);
+    };
+    printf("stage %d, TH=%d, %d workgroups (timestamps of thread 0; s_memtime shader cycles)\n", stage, th, nblk);
+    stat("stage tile src0", 1, 2); stat("taps src0", 2, 3);
+    if (stage >= 2) { stat("stage tile src1", 3, 4); stat("taps src1", 4, 5); stat("src2 (stage+taps)", 5, 6); }
+    stat("  last stage_tile: issue", stage >= 2 ? 5 : 1, 8); stat("  last stage_tile: wait", 8, 9);
+    stat("  last stage_tile: ds_write", 9, 10); if (stage == 1) stat("  last stage_tile: barrier", 10, 2);
+    stat("epilogue", 6, 7); stat("whole workgroup", 1, 7);
+    long long t0 = h[0]; for (int b = 0; b < nblk; ++b) t0 = std::min(t0, h[b * 16]);
+    std::vector<long long> starts; for (int b = 0; b < nblk; ++b) starts.push_back(h[b * 16] - t0);
+    std::sort(starts.begin(), starts.end());
+    printf("  WG start times (100 MHz ticks): first %lld, p25 %lld, p50 %lld, p75 %lld, last %lld  => kernel ~%.1f us to last start\n",
+           starts[0], starts[nblk / 4], starts[nblk / 2], starts[nblk * 3 / 4], starts[nblk - 1], starts[nblk - 1] / 100.0);
+    return 0;
+}
