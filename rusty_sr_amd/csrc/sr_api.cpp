@@ -81,8 +81,12 @@ struct sr_ctx {
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
     size_t off_w0 = 0, off_w[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
-    float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3
-    size_t feat_cap_px = 0;
+    float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3 (zero-bordered, see sr_kernels.h)
+    size_t feat_cap_px = 0;       // allocated padded pixels per map
+    int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
+    int pitch = 0; long img_stride = 0;
+    uint32_t* d_voff = nullptr;   // 2 x kVoffEntries LDS-DMA gather offsets (5x5 tile, 3x3 tile)
+    int voff_pitch = 0, voff_th = 0;
     void* d_in = nullptr;  size_t in_cap = 0;    // staging for the host-pointer entry points
     void* d_out = nullptr; size_t out_cap = 0;
     hipEvent_t ev[8] = {nullptr};
@@ -220,6 +224,7 @@ void sr_destroy(sr_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->d_feat) if (p) (void)hipFree(p);
     if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_voff) (void)hipFree(c->d_voff);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -247,15 +252,48 @@ int sr_device_info(sr_ctx* c, char* name, size_t cap, int* cus, int* clock_mhz) 
 
 namespace {
 
-int ensure_features(sr_ctx* c, size_t npx) {
-    if (npx <= c->feat_cap_px) return SR_OK;
-    for (auto& p : c->d_feat) {
-        if (p) HIPCHK(c, hipFree(p));
-        p = nullptr;
+// (Re)allocate the four zero-bordered feature maps for n images of H x W and make
+// sure every border pixel is zero.  Kernels only store inside [0,H) x [0,W), so the
+// borders stay clean until the geometry changes.
+int ensure_features(sr_ctx* c, int n, int H, int W, int tiles_x, hipStream_t s) {
+    const int pitch = tiles_x * 32 + 2 * kFeatPad;
+    const long rows = (long)H + kFeatPad + kFeatPadBottom;
+    const long img_stride = rows * pitch;
+    const size_t npx = (size_t)n * img_stride + (size_t)kFeatPad * pitch + 64;  // slack for the row above image 0
+    if (npx > c->feat_cap_px) {
+        for (auto& p : c->d_feat) {
+            if (p) HIPCHK(c, hipFree(p));
+            p = nullptr;
+        }
+        c->feat_cap_px = 0; c->geo_n = 0;
+        for (auto& p : c->d_feat) HIPCHK(c, hipMalloc((void**)&p, npx * 32 * sizeof(float)));
+        c->feat_cap_px = npx;
     }
-    c->feat_cap_px = 0;
-    for (auto& p : c->d_feat) HIPCHK(c, hipMalloc((void**)&p, npx * 32 * sizeof(float)));
-    c->feat_cap_px = npx;
+    if (c->geo_n != n || c->geo_h != H || c->geo_w != W) {
+        for (auto& p : c->d_feat) HIPCHK(c, hipMemsetAsync(p, 0, c->feat_cap_px * 32 * sizeof(float), s));
+        c->geo_n = n; c->geo_h = H; c->geo_w = W;
+    }
+    c->pitch = pitch; c->img_stride = img_stride;
+    return SR_OK;
+}
+
+// LDS-DMA gather tables for this row pitch: entry P = byte offset of tile pixel P
+// (row-major in the TWH-wide halo tile) from the tile origin; padding entries read
+// the origin (harmless) and land in the unused tail of the LDS plane.
+int ensure_voff(sr_ctx* c, int th, hipStream_t s) {
+    if (c->d_voff && c->voff_pitch == c->pitch && c->voff_th == th) return SR_OK;
+    if (!c->d_voff) HIPCHK(c, hipMalloc((void**)&c->d_voff, 2 * kVoffEntries * sizeof(uint32_t)));
+    std::vector<uint32_t> t(2 * kVoffEntries, 0u);
+    const int ks[2] = {5, 3};
+    for (int k = 0; k < 2; ++k) {
+        const int r = ks[k] / 2, twh = 32 + 2 * r, thh = th + 2 * r;
+        for (int P = 0; P < twh * thh && P < kVoffEntries; ++P)
+            t[k * kVoffEntries + P] = (uint32_t)(((size_t)(P / twh) * c->pitch + (P % twh)) * 128);
+    }
+    // pageable-host async copy is staged by the runtime before it returns
+    HIPCHK(c, hipMemcpyAsync(c->d_voff, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->voff_pitch = c->pitch; c->voff_th = th;
     return SR_OK;
 }
 
@@ -282,18 +320,22 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     HIPCHK(c, hipSetDevice(c->device));
     // s == nullptr is HIP's legacy default stream (what torch's default stream is);
     // the context's own non-blocking stream is used only by the host-pointer entry points.
-    int rc = ensure_features(c, (size_t)n * H * W);
-    if (rc != SR_OK) return rc;
-
     const int top = halo_top, bot = H - halo_bot;
     static const int margin[5] = {5, 3, 2, 1, 0};
     const int tiles_x = (W + 31) / 32;
+    int rc = ensure_features(c, n, H, W, tiles_x, s);
+    if (rc != SR_OK) return rc;
     // tile height: 8 rows when that still gives every CU two workgroups, else 4
     const long tiles8 = (long)n * tiles_x * ((bot - top + 7) / 8);
     int th = tiles8 >= 2L * (c->cus > 0 ? c->cus : 256) ? 8 : 4;
     if (const char* e = getenv("SRHIP_TH")) th = atoi(e) == 4 ? 4 : 8;  // experiment override
+    rc = ensure_voff(c, th, s);
+    if (rc != SR_OK) return rc;
     const float* P = c->d_params;
     const bool prof = c->profiling;
+    // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
+    float* feat[4];
+    for (int k = 0; k < 4; ++k) feat[k] = c->d_feat[k] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
         int y0 = top - margin[st], y1 = bot + margin[st];
@@ -304,12 +346,15 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
         if (st == 0) {
             Conv0Args a{};
             a.img = d_img; a.wpack = P + c->off_w0; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
-            a.dst = c->d_feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
+            a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
+            a.pitch = c->pitch; a.img_stride = c->img_stride;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             HIPCHK(c, sr_launch_conv0(a, th, nblk, img_u8, s));
         } else {
             StageArgs a{};
-            float* f = c->d_feat[0]; float* l1 = c->d_feat[1]; float* l2 = c->d_feat[2]; float* l3 = c->d_feat[3];
+            float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
+            a.voff5 = c->d_voff; a.voff3 = c->d_voff + kVoffEntries;
+            a.pitch = c->pitch; a.img_stride = c->img_stride;
             switch (st) {
                 case 1: a.src[0] = f; a.dst = l1; break;
                 case 2: a.src[0] = f; a.src[1] = l1; a.dst = l2; break;
@@ -404,7 +449,9 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
     if (nf == 0 || cap_floats < nf || !c->d_feat[which]) return SR_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(out_host, c->d_feat[which], nf * sizeof(float), hipMemcpyDeviceToHost));
+    const float* src = c->d_feat[which] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
+    HIPCHK(c, hipMemcpy2D(out_host, (size_t)c->last_w * 128, src, (size_t)c->pitch * 128, (size_t)c->last_w * 128,
+                          c->last_h, hipMemcpyDeviceToHost));
     return SR_OK;
 }
 

@@ -8,24 +8,37 @@ struct Conv0Args {
     const float* wpack;   // 25 taps x [cin/2][cout 32][2]  (cin 3 zero-padded to 4)
     const float* bias;    // 32
     const float* beta;    // 32
-    float* dst;           // n*H*W*32
+    float* dst;           // padded feature map (see FeatGeom), pointer to pixel (0,0) of image 0
     int H, W, img_ch;
+    int pitch;            // feature-map row pitch in pixels
+    long img_stride;      // feature-map image stride in pixels
     int y_begin, y_end;   // rows to compute
     int tiles_x, tiles_y;
 };
 
 struct StageArgs {
-    const float* src[3];  // NHWC 32-channel feature maps
+    const float* src[3];  // NHWC 32-channel feature maps, zero-bordered (pointer to pixel (0,0))
+    const uint32_t* voff5; // LDS-DMA gather tables: byte offset of tile pixel P from the tile origin,
+    const uint32_t* voff3; //   36-wide (5x5 source) and 34-wide (3x3 source) tiles, 448 entries each
     const float* wpack;   // one 4 KB chunk per tap, sources concatenated: [cin/4][cout 32][4]
     const float* bias;    // 32 (expand_bias zero-padded from 27)
     const float* beta;    // 32 (unused by the final stage)
-    float* dst;           // non-final: n*H*W*32
+    float* dst;           // non-final: padded feature map
     const void* img;      // final: the input image again (bilinear residual)
     void* out;            // final: n*(3*rows)*(3W)*3 f32 or *4 u8 RGBA, rows = y_end-y_begin
     int H, W, img_ch;
+    int pitch;            // feature-map row pitch in pixels (>= tiles_x*32 + 4)
+    long img_stride;      // feature-map image stride in pixels
     int y_begin, y_end;
     int tiles_x, tiles_y;
 };
+
+// Feature maps live in HBM with a zero border so tile staging never tests bounds:
+// rows [-kFeatPad, H + kFeatPadBottom), columns [-kFeatPad, pitch - kFeatPad); kernels only
+// ever store inside [0,H) x [0,W), so the border keeps the reference's zero padding.
+constexpr int kFeatPad = 2;          // 5x5 halo
+constexpr int kFeatPadBottom = 12;   // last tile row may start at H-1: + 8 rows + 2 halo (+2 spare)
+constexpr int kVoffEntries = 448;    // 7 groups of 64 tile pixels
 
 hipError_t sr_launch_conv0(const Conv0Args& a, int th, int nblk, bool img_u8, hipStream_t s);
 hipError_t sr_launch_stage(int stage, const StageArgs& a, int th, int nblk, bool img_u8, bool out_u8,

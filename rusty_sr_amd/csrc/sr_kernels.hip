@@ -71,6 +71,29 @@ __device__ __forceinline__ float belu(float v, float beta) {
     return __fadd_rn(__fadd_rn(__fmul_rn(beta, v), __builtin_amdgcn_sqrtf(__fadd_rn(__fmul_rn(v, v), 1.0f))), -1.0f);
 }
 
+// Two values per instruction (v_pk_mul_f32 / v_pk_add_f32): every VALU instruction
+// of the epilogue is paid for in f32-MFMA time, so halve their number.
+__device__ __forceinline__ f32x2 belu2(f32x2 v, float beta) {
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 t = v * v + one;
+    const f32x2 s = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+    const f32x2 b = {beta, beta};
+    return (b * v + s) - one;
+}
+
+// BeLU(acc + bias) of one 32x32 accumulator tile -> NHWC rows at base + row*32 floats
+// (row pairs r, r+1 are adjacent pixels); immediate-offset stores only.
+__device__ __forceinline__ void store_belu_tile(float* base, const f32x16& acc, float bias, float beta) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 bb = {bias, bias};
+        const f32x2 o = belu2(f32x2{acc[r], acc[r + 1]} + bb, beta);
+        const int row = (r & 3) + 8 * (r >> 2);
+        base[row * 32] = o.x;
+        base[(row + 1) * 32] = o.y;
+    }
+}
+
 // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each
 // XCD one contiguous run of tiles so neighbouring tiles (which share halo rows
 // and columns) hit the same 4 MiB L2.  Bijective for any grid size.
@@ -160,9 +183,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     for (int m = 0; m < T; ++m) {
         const int y = y0 + wave * T + m;
         if (y >= a.y_end) continue;
-        float* base = a.dst + (((size_t)n * a.H + y) * a.W + x0 + 4 * h) * 32 + i;
+        float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
         if (full_x) {
-            for_each_acc_row([&](int r, int row) { base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta); });
+            store_belu_tile(base, acc[m], bias, beta);
         } else {
             for_each_acc_row([&](int r, int row) {
                 if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
@@ -182,64 +205,35 @@ struct TileGeom {
     static constexpr int TWH = kTW + 2 * R;
     static constexpr int THH = TH + 2 * R;
     static constexpr int NPIX = THH * TWH;
-    static constexpr int PLANE = (NPIX | 1) * 16;  // bytes; odd pixel count -> conflict-free staging writes
+    static constexpr int NG = (NPIX + 63) / 64;    // LDS-DMA groups of 64 tile pixels
+    static constexpr int PLANE = NG * 64 * 16;     // bytes per channel-group plane
 };
 
-// Stage one source tile (+halo) into LDS, planar [cin/4][pixel][16 B].  Wave w
-// takes tile rows w, w+4, ...: a tile row is ONE contiguous TWH*128-byte run of the
-// NHWC map, lane l moves the 16-byte pieces l, l+64, ... of it, so every load and
-// every ds_write is `wave-uniform base + per-lane constant + immediate`.  Rows /
-// columns outside the image are the reference's zero padding (Padding::Same).
+// Stage one source tile (+halo) into LDS, planar [cin/4][pixel][16 B], by LDS-DMA
+// (no VGPR round trip, no VALU).  One instruction moves 16 bytes of 64 consecutive
+// tile pixels: lane l gathers channel group c of tile pixel P = 64 g + l from
+// `origin + voff[P] + 16 c`, and lands at plane c, slot P.  voff (host-built
+// table: ((P / TWH) * pitch + P % TWH) * 128) is the only per-lane operand; the
+// origin is wave-uniform.  The maps carry a zero border in HBM, so the
+// reference's zero padding (Padding::Same) needs no bounds test here.
 template <int TH, int KS>
-__device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, int n, int H,
-                                           int W, int y0, int x0, int wave, int lane) {
+__device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, const uint32_t* __restrict__ voff,
+                                           long img_stride, int pitch, int n, int y0, int x0, int wave, int lane) {
     using G = TileGeom<TH, KS>;
-    constexpr int ROW_ITEMS = G::TWH * 8;          // 16-byte pieces per tile row
-    constexpr int NQ = (ROW_ITEMS + 63) / 64;
-    constexpr int REM = ROW_ITEMS - (NQ - 1) * 64;  // lanes active in the last piece group
-    constexpr int RPW = (G::THH + 3) / 4;           // rows per wave
-    const int lds_lane = (lane & 7) * G::PLANE + (lane >> 3) * 16;
-    const bool interior_x = x0 >= G::R && x0 + kTW + G::R <= W;  // wave-uniform
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 v[RPW][NQ];
+    const char* origin = (const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32);
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int py = wave + 4 * r, gy = y0 - G::R + py;
-        const bool row_ok = py < G::THH && gy >= 0 && gy < H;  // wave-uniform
-        const float* rowp = src + (((size_t)n * H + (row_ok ? gy : 0)) * W + (x0 - G::R)) * 32;
+    for (int gi = 0; gi < (G::NG + 3) / 4; ++gi) {
+        const int g = wave + 4 * gi;  // wave-uniform
+        if (g < G::NG) {
+            const uint32_t vo = voff[g * 64 + lane];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            v[r][q] = zero;
-            const int item = lane + 64 * q;
-            if (row_ok && (q < NQ - 1 || lane < REM)) {
-                if (interior_x) {
-                    v[r][q] = *(const f32x4*)(rowp + item * 4);
-                } else {
-                    const int gx = x0 - G::R + (item >> 3);
-                    if (gx >= 0 && gx < W) v[r][q] = *(const f32x4*)(rowp + item * 4);
-                }
-            }
+            for (int c = 0; c < 8; ++c)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(origin + c * 16 + vo),
+                    (__attribute__((address_space(3))) void*)(tile + c * G::PLANE + g * 1024), 16, 0, 0);
         }
     }
     TL(8);
-#ifdef SR_TIMELINE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TL(9);
-#endif
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int py = wave + 4 * r;
-        if (py < G::THH) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (q < NQ - 1 || lane < REM)
-                    *(f32x4*)(tile + lds_lane + (py * G::TWH + q * 8) * 16) = v[r][q];
-        }
-    }
-#ifdef SR_TIMELINE
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TL(10);
-#endif
 }
 
 // Asynchronous 4 KB weight-chunk copy global -> LDS ring slot (LDS-DMA, no VGPR
@@ -348,6 +342,11 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[T], char* tile, char* rin
     }
 }
 
+// One workgroup per tile.  (Persistent variants -- a static split of the tiles
+// and a dynamic per-XCD queue -- were measured 4 % SLOWER on MI355X: the older of
+// two co-resident workgroups wins the MFMA arbitration, and a looping workgroup
+// has to drain its own epilogue stores before its next tile's DMA barrier, which
+// a retiring workgroup never waits for.)
 template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8>
 __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(StageArgs a) {
     constexpr int T = TH / 4;
@@ -359,100 +358,112 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
+    constexpr int NTAPS = KS0 * KS0 + (NSRC - 1) * 9;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int n = bid / tiles_per_img, t = bid - n * tiles_per_img;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int x0 = tx * kTW, y0 = a.y_begin + ty * TH;
-    constexpr int NTAPS = KS0 * KS0 + (NSRC - 1) * 9;
 
-    f32x16 acc[T];
-#pragma unroll
-    for (int m = 0; m < T; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-    // weight chunks 0 and 1 -> ring slots 0 and 1 (every stage has >= 25 taps)
+    // Two workgroups share each SIMD.  A wave streaming MFMAs is the older one and
+    // wins every VALU arbitration, leaving the other workgroup's staging / epilogue
+    // code roughly one issue slot per MFMA.  The matrix stream only needs one slot
+    // per 64 cycles, so the non-MFMA phases run at raised priority.
+    __builtin_amdgcn_s_setprio(3);
+    // weight chunks 0 and 1 -> ring slots 0 and 1 (every stage has >= 25 taps), first source tile
     weight_chunk_async(ring, a.wpack, wave, lane);
     weight_chunk_async(ring + 4096, a.wpack + kChunkFloats, wave, lane);
-    int gtap = 0, slot = 0;
-    TL(0); TL(1);
-    stage_tile<TH, KS0>(tile, a.src[0], n, a.H, a.W, y0, x0, wave, lane);
+    stage_tile<TH, KS0>(tile, a.src[0], KS0 == 5 ? a.voff5 : a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
     const float bias = a.bias[i];
     const float beta = FINAL ? 0.f : a.beta[i];
-    __syncthreads();
-    TL(2);
-    conv_taps<TH, KS0, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
-    TL(3);
-    if constexpr (NSRC >= 2) {
-        stage_tile<TH, 3>(tile, a.src[1], n, a.H, a.W, y0, x0, wave, lane);
-        __syncthreads();
-        TL(4);
-        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
-        TL(5);
-    }
-    if constexpr (NSRC >= 3) {
-        stage_tile<TH, 3>(tile, a.src[2], n, a.H, a.W, y0, x0, wave, lane);
-        __syncthreads();
-        conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
-    }
-    if constexpr (FINAL)
-        lin_taps<TH, T, IMG_U8>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
-    TL(6);
-
-    const bool full_x = x0 + kTW <= a.W;
-    if constexpr (!FINAL) {
+    {
+        f32x16 acc[T];
 #pragma unroll
-        for (int m = 0; m < T; ++m) {
-            const int y = y0 + wave * T + m;
-            if (y >= a.y_end) continue;
-            float* base = a.dst + (((size_t)n * a.H + y) * a.W + x0 + 4 * h) * 32 + i;
-            if (full_x) {
-                for_each_acc_row([&](int r, int row) { base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta); });
-            } else {
-                for_each_acc_row([&](int r, int row) {
-                    if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
-                });
-            }
+        for (int m = 0; m < T; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        int gtap = 0, slot = 0;
+        TL(0); TL(1);
+        ring_barrier<0>();  // every wave's tile + weight DMAs have landed
+        __builtin_amdgcn_s_setprio(0);
+        TL(2);
+        conv_taps<TH, KS0, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+        TL(3);
+        if constexpr (NSRC >= 2) {
+            __builtin_amdgcn_s_setprio(3);
+            stage_tile<TH, 3>(tile, a.src[1], a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+            ring_barrier<0>();
+            __builtin_amdgcn_s_setprio(0);
+            TL(4);
+            conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+            TL(5);
         }
-    } else {
-        // Expand (network.rs:39): lane i < 27 owns expand channel i = (dy*3+dx)*3+c;
-        // out[3y+dy][3x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
-        const int ch = i < 27 ? i : 26;
-        const int dy = ch / 9, sub = ch - dy * 9;  // sub = dx*3 + c
-        const int OW = a.W * 3;
-        const int h_band = a.y_end - a.y_begin;
+        if constexpr (NSRC >= 3) {
+            __builtin_amdgcn_s_setprio(3);
+            stage_tile<TH, 3>(tile, a.src[2], a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+            ring_barrier<0>();
+            __builtin_amdgcn_s_setprio(0);
+            conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+        }
+        __builtin_amdgcn_s_setprio(3);
+        if constexpr (FINAL)
+            lin_taps<TH, T, IMG_U8>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
+        TL(6);
+
+        const bool full_x = x0 + kTW <= a.W;
+        if constexpr (!FINAL) {
 #pragma unroll
-        for (int m = 0; m < T; ++m) {
-            const int y = y0 + wave * T + m;
-            if (y >= a.y_end) continue;
-            const size_t opx = ((size_t)n * h_band * 3 + (size_t)(y - a.y_begin) * 3 + dy) * OW + 3 * (x0 + 4 * h);
-            if constexpr (!OUT_U8) {
-                float* base = (float*)a.out + opx * 3 + sub;
+            for (int m = 0; m < T; ++m) {
+                const int y = y0 + wave * T + m;
+                if (y >= a.y_end) continue;
+                float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
                 if (full_x) {
-                    for_each_acc_row([&](int r, int row) { if (i < 27) base[row * 9] = __fadd_rn(acc[m][r], bias); });
+                    store_belu_tile(base, acc[m], bias, beta);
                 } else {
                     for_each_acc_row([&](int r, int row) {
-                        if (i < 27 && x0 + 4 * h + row < a.W) base[row * 9] = __fadd_rn(acc[m][r], bias);
+                        if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
                     });
                 }
-            } else {
-                // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255;
-                // the lane holding c == 0 gathers G and B from its two neighbours
-                uint32_t* base = (uint32_t*)a.out + opx + sub / 3;
-                const bool writer = i < 27 && (sub % 3) == 0;
-                for_each_acc_row([&](int r, int row) {
-                    float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(acc[m][r], bias)), 0.5f));
-                    q = fminf(fmaxf(q, 0.0f), 255.0f);
-                    const uint32_t qi = (uint32_t)q;
-                    const uint32_t g = __shfl_down(qi, 1), b = __shfl_down(qi, 2);
-                    if (writer && (full_x || x0 + 4 * h + row < a.W))
-                        base[row * 3] = qi | (g << 8) | (b << 16) | 0xff000000u;
-                });
+            }
+        } else {
+            // Expand (network.rs:39): lane i < 27 owns expand channel i = (dy*3+dx)*3+c;
+            // out[3y+dy][3x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
+            const int ch = i < 27 ? i : 26;
+            const int dy = ch / 9, sub = ch - dy * 9;  // sub = dx*3 + c
+            const int OW = a.W * 3;
+            const int h_band = a.y_end - a.y_begin;
+#pragma unroll
+            for (int m = 0; m < T; ++m) {
+                const int y = y0 + wave * T + m;
+                if (y >= a.y_end) continue;
+                const size_t opx = ((size_t)n * h_band * 3 + (size_t)(y - a.y_begin) * 3 + dy) * OW + 3 * (x0 + 4 * h);
+                if constexpr (!OUT_U8) {
+                    float* base = (float*)a.out + opx * 3 + sub;
+                    if (full_x) {
+                        for_each_acc_row([&](int r, int row) { if (i < 27) base[row * 9] = __fadd_rn(acc[m][r], bias); });
+                    } else {
+                        for_each_acc_row([&](int r, int row) {
+                            if (i < 27 && x0 + 4 * h + row < a.W) base[row * 9] = __fadd_rn(acc[m][r], bias);
+                        });
+                    }
+                } else {
+                    // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255;
+                    // the lane holding c == 0 gathers G and B from its two neighbours
+                    uint32_t* base = (uint32_t*)a.out + opx + sub / 3;
+                    const bool writer = i < 27 && (sub % 3) == 0;
+                    for_each_acc_row([&](int r, int row) {
+                        float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(acc[m][r], bias)), 0.5f));
+                        q = fminf(fmaxf(q, 0.0f), 255.0f);
+                        const uint32_t qi = (uint32_t)q;
+                        const uint32_t g = __shfl_down(qi, 1), b = __shfl_down(qi, 2);
+                        if (writer && (full_x || x0 + 4 * h + row < a.W))
+                            base[row * 3] = qi | (g << 8) | (b << 16) | 0xff000000u;
+                    });
+                }
             }
         }
+        TL(7);
     }
-    TL(7);
 }
 
 // ---------------------------------------------------------------------------

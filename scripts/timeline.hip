@@ -8,14 +8,21 @@
 int main(int argc, char** argv) {
     const int stage = argc > 1 ? atoi(argv[1]) : 1, th = argc > 2 ? atoi(argv[2]) : 8;
     const int H = 1080, W = 1920;
-    const size_t npx = (size_t)H * W;
+    const int pitch = W + 4; const long img_stride = (long)(H + 14) * pitch;
+    const size_t npx = (size_t)img_stride + 2 * pitch + 64;
     float *f[3], *dst, *w, *bias; void* out;
     for (auto& p : f) { hipMalloc(&p, npx * 128); hipMemset(p, 0, npx * 128); }
-    hipMalloc(&dst, npx * 128); hipMalloc(&out, npx * 9 * 12);
+    hipMalloc(&dst, npx * 128); hipMalloc(&out, (size_t)H * W * 9 * 12);
+    std::vector<uint32_t> vt(2 * kVoffEntries, 0u);
+    for (int k = 0; k < 2; ++k) { const int r = k == 0 ? 2 : 1, twh = 32 + 2 * r, thh = th + 2 * r;
+        for (int P = 0; P < twh * thh; ++P) vt[k * kVoffEntries + P] = (uint32_t)(((size_t)(P / twh) * pitch + P % twh) * 128); }
+    uint32_t* dvoff; hipMalloc(&dvoff, vt.size() * 4); hipMemcpy(dvoff, vt.data(), vt.size() * 4, hipMemcpyHostToDevice);
+    const size_t org = ((size_t)2 * pitch + 2) * 32;
     hipMalloc(&w, 43 * 4096); hipMemset(w, 0, 43 * 4096);
     hipMalloc(&bias, 256); hipMemset(bias, 0, 256);
     StageArgs a{};
-    a.src[0] = f[0]; a.src[1] = f[1]; a.src[2] = f[2]; a.wpack = w; a.bias = bias; a.beta = bias; a.dst = dst;
+    a.src[0] = f[0] + org; a.src[1] = f[1] + org; a.src[2] = f[2] + org; a.wpack = w; a.bias = bias; a.beta = bias; a.dst = dst + org;
+    a.voff5 = dvoff; a.voff3 = dvoff + kVoffEntries; a.pitch = pitch; a.img_stride = img_stride;
     a.img = f[0]; a.out = out; a.H = H; a.W = W; a.img_ch = 3; a.y_begin = 0; a.y_end = H;
     a.tiles_x = W / 32; a.tiles_y = (H + th - 1) / th;
     const int nblk = a.tiles_x * a.tiles_y;
@@ -36,8 +43,7 @@ int main(int argc, char** argv) {
     printf("stage %d, TH=%d, %d workgroups (timestamps of thread 0; s_memtime shader cycles)\n", stage, th, nblk);
     stat("stage tile src0", 1, 2); stat("taps src0", 2, 3);
     if (stage >= 2) { stat("stage tile src1", 3, 4); stat("taps src1", 4, 5); stat("src2 (stage+taps)", 5, 6); }
-    stat("  last stage_tile: issue", stage >= 2 ? 5 : 1, 8); stat("  last stage_tile: wait", 8, 9);
-    stat("  last stage_tile: ds_write", 9, 10); if (stage == 1) stat("  last stage_tile: barrier", 10, 2);
+    stat("  last stage_tile: DMA issue", stage >= 2 ? 5 : 1, 8); if (stage == 1) stat("  last stage_tile: wait+barrier", 8, 2);
     stat("epilogue", 6, 7); stat("whole workgroup", 1, 7);
     long long t0 = h[0]; for (int b = 0; b < nblk; ++b) t0 = std::min(t0, h[b * 16]);
     std::vector<long long> starts; for (int b = 0; b < nblk; ++b) starts.push_back(h[b * 16] - t0);
