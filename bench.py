@@ -57,6 +57,29 @@ def synth_u8(seed, h, w):
     return (s // 25).astype(np.uint8)
 
 
+STAGE_KERNEL = {1: "conv_stage_kernel<8, 1, 5", 2: "conv_stage_kernel<8, 2, 5", 3: "conv_stage_kernel<8, 3, 5",
+                4: "conv_stage_kernel<8, 3, 3", 0: "conv0_kernel<8"}
+
+
+def pmc_traffic(stage, H, W):
+    """HBM bytes per launch of the stage kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_latest.json = scripts/profile.sh of this same command; FETCH_SIZE x2
+    gfx950 correction + WRITE_SIZE, collected in separate passes).  Only valid for the
+    workload it was measured on (1920x1080); null otherwise."""
+    if (H, W) != (1080, 1920):
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        for name, v in d.items():
+            if STAGE_KERNEL[stage] in name and "hbm_read_bytes" in v:
+                return {"hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v.get("hbm_write_bytes", 0)),
+                        "algorithmic_bytes_per_launch": int(H * W * 128 * (min(stage, 3) + 1)),
+                        "source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(params, px_u8, budget_s=12.0):
     """Time the CPU oracle (a port of the reference semantics; the Rust reference
     itself cannot be built here) on a bounded strip of the same workload."""
@@ -182,7 +205,7 @@ def main():
         ach = flops / (stage_ms[k] / 1e3) / 1e12
         result["roofline"] = {"bound": "mfma", "kernel": f"conv_stage_kernel stage {k}", "achieved": round(ach, 2),
                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                              "traffic": None, "avg_launch_ms": round(float(stage_ms[k]), 4)}
+                              "traffic": pmc_traffic(k, H, W), "avg_launch_ms": round(float(stage_ms[k]), 4)}
         result["stages"] = [{"stage": s, "ms": round(float(stage_ms[s]), 4),
                              "tflops": round(2 * MAC_PER_PX[s] * rows[s] * W / (stage_ms[s] / 1e3) / 1e12, 2)}
                             for s in range(5)]

@@ -37,3 +37,22 @@ for k in sorted(agg):
         print(f"    -> HBM read  ~ {2 * c['FETCH_SIZE'] / 1024:.1f} MB (FETCH_SIZE KB x2: gfx950 tallies 128-B requests at 64 B)")
     if "WRITE_SIZE" in c:
         print(f"    -> HBM write ~ {c['WRITE_SIZE'] / 1024:.1f} MB (uncalibrated)")
+
+# machine-readable copy (bench.py reads the HBM traffic of the dominant kernel from it)
+import json
+js = {}
+for name, calls, us, pct in rows:
+    js.setdefault(name, {})["avg_us"] = us
+    js[name]["calls"] = calls
+for k in agg:
+    c = {cn: sum(v) / len(v) for cn, v in agg[k].items()}
+    d = js.setdefault(k, {})
+    if "FETCH_SIZE" in c:
+        d["hbm_read_bytes"] = 2 * c["FETCH_SIZE"] * 1024   # KB -> B, x2 gfx950 correction (MI355X_MICROARCH.md HBM section)
+    if "WRITE_SIZE" in c:
+        d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        d["mfma_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)  # 8 XCD GRBMs, 1024 SIMDs
+    if "SQ_LDS_BANK_CONFLICT" in c:
+        d["lds_bank_conflict_cycles"] = c["SQ_LDS_BANK_CONFLICT"]
+json.dump(js, open(os.path.join(out, "summary.json"), "w"), indent=1)
