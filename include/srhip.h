@@ -100,6 +100,16 @@ int sr_upscale_band_f32_dev(sr_ctx* ctx, const float* d_in, int h_ext, int w, in
 int sr_upscale_band_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels, int h_ext, int w,
                               int halo_top, int halo_bot, uint8_t* d_out_rgba, void* stream);
 
+/* Arithmetic of the conv stack.
+ *   SR_PRECISION_F32       (default) v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate --
+ *                          the same arithmetic class as the reference's f32 CPU path.
+ *   SR_PRECISION_SPLIT_F16 every activation / weight is carried as a pair of halves
+ *                          (hi + lo/2048, ~2^-23 relative) and each product is three f16 MFMAs with
+ *                          f32 accumulation on the matrix cores; outputs stay within the 1e-4 bar
+ *                          (tests/test_gpu_parity.py runs every parity test in both modes). */
+enum sr_precision { SR_PRECISION_F32 = 0, SR_PRECISION_SPLIT_F16 = 1 };
+int sr_set_precision(sr_ctx* ctx, int mode);
+
 /* Test hook: copy the post-activation feature maps of the most recent call
  * (image 0) to host: which = 0..3 -> f, l1, l2, l3 (h*w*32 f32 each).  The
  * reference exposes the same values as graph node data (network.rs:30,43-48). */

@@ -12,6 +12,7 @@ SR_HALO = 7
 
 SR_OK, SR_E_INVALID, SR_E_PARAM_COUNT, SR_E_FACTOR, SR_E_NO_DEVICE = 0, -1, -2, -3, -4
 SR_E_HIP, SR_E_NOMEM, SR_E_BYTEVEC, SR_E_HALO = -5, -6, -7, -8
+SR_PRECISION_F32, SR_PRECISION_SPLIT_F16 = 0, 1
 
 # every symbol include/srhip.h declares: (restype, argtypes)
 _vp, _fp, _u8p, _dp = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
@@ -28,6 +29,7 @@ SYMBOLS = {
     "sr_upscale_band_f32_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sr_upscale_band_rgba8_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_read_feature": (_i, [_vp, _i, _fp, _sz]),
+    "sr_set_precision": (_i, [_vp, _i]),
     "sr_set_profiling": (_i, [_vp, _i]),
     "sr_last_timing": (_i, [_vp, _dp, _dp, _dp, _dp]),
     "sr_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_i)]),

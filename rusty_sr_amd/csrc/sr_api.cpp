@@ -3,6 +3,7 @@
 // without a HIP device sr_create fails with SR_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +40,29 @@ void pack_conv32(std::vector<float>& dst, const float* w, int O, int ks) {
                 for (int o = 0; o < O; ++o)
                     for (int q = 0; q < 4; ++q)
                         dst[base + (c * 32 + o) * 4 + q] = w[(((size_t)o * ks + ky) * ks + kx) * 32 + 4 * c + q];
+        }
+}
+
+// Split-half flavour of pack_conv32: per tap 4 KB = [hi][lo], each
+// [cin/8 = 4][cout 32][8 halves]: w = hi + lo/2048 (see split_half in sr_kernels.hip).
+void split_half_host(float v, _Float16& hi, _Float16& lo) {
+    hi = std::fabs(v) < 6.103515625e-05f ? (_Float16)0.0f : (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * 2048.0f);
+}
+void pack_conv32_h(std::vector<float>& dst, const float* w, int O, int ks) {
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            const size_t base = dst.size();
+            dst.resize(base + kChunk, 0.0f);
+            _Float16* hp = (_Float16*)(dst.data() + base);  // 2048 halves: [0,1024) hi, [1024,2048) lo
+            for (int g = 0; g < 4; ++g)
+                for (int o = 0; o < O; ++o)
+                    for (int q = 0; q < 8; ++q) {
+                        _Float16 hi, lo;
+                        split_half_host(w[(((size_t)o * ks + ky) * ks + kx) * 32 + 8 * g + q], hi, lo);
+                        hp[(g * 32 + o) * 8 + q] = hi;
+                        hp[1024 + (g * 32 + o) * 8 + q] = lo;
+                    }
         }
 }
 
@@ -80,7 +104,8 @@ struct sr_ctx {
     char name[128] = {0};
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
-    size_t off_w0 = 0, off_w[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
+    size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
+    int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3 (zero-bordered, see sr_kernels.h)
     size_t feat_cap_px = 0;       // allocated padded pixels per map
     int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
@@ -202,6 +227,18 @@ int sr_create(sr_ctx** out, const float* params, size_t n_params, int factor, in
         pack_conv32(w, params + OFF_CONV10, 27, 3);
         pack_lin(w);
         c->off_w[4] = push(w);
+        // the same four stages again in split-half form (sr_set_precision(SR_PRECISION_SPLIT_F16))
+        w.clear(); pack_conv32_h(w, params + OFF_CONV1, 32, 5);
+        c->off_wh[1] = push(w);
+        w.clear(); pack_conv32_h(w, params + OFF_CONV2, 32, 5); pack_conv32_h(w, params + OFF_CONV5, 32, 3);
+        c->off_wh[2] = push(w);
+        w.clear(); pack_conv32_h(w, params + OFF_CONV3, 32, 5); pack_conv32_h(w, params + OFF_CONV6, 32, 3);
+        pack_conv32_h(w, params + OFF_CONV8, 32, 3);
+        c->off_wh[3] = push(w);
+        w.clear(); pack_conv32_h(w, params + OFF_CONV7, 27, 3); pack_conv32_h(w, params + OFF_CONV9, 27, 3);
+        pack_conv32_h(w, params + OFF_CONV10, 27, 3);
+        pack_lin(w);
+        c->off_wh[4] = push(w);
         const size_t boff[5] = {OFF_F_BIAS, OFF_L1_BIAS, OFF_L2_BIAS, OFF_L3_BIAS, OFF_EXP_BIAS};
         const size_t aoff[4] = {OFF_F_ACTIV, OFF_L1_ACTIV, OFF_L2_ACTIV, OFF_L3_ACTIV};
         for (int s = 0; s < 5; ++s) c->off_bias[s] = push(vec32(boff[s], s == 4 ? 27 : 32));
@@ -233,6 +270,12 @@ void sr_destroy(sr_ctx* c) {
 }
 
 int sr_last_hip_error(sr_ctx* c) { return c ? c->last_hip : 0; }
+
+int sr_set_precision(sr_ctx* c, int mode) {
+    if (!c || (mode != SR_PRECISION_F32 && mode != SR_PRECISION_SPLIT_F16)) return SR_E_INVALID;
+    c->precision = mode;
+    return SR_OK;
+}
 
 int sr_set_profiling(sr_ctx* c, int enabled) {
     if (!c) return SR_E_INVALID;
@@ -349,7 +392,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
             a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
             a.pitch = c->pitch; a.img_stride = c->img_stride;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
-            HIPCHK(c, sr_launch_conv0(a, th, nblk, img_u8, s));
+            HIPCHK(c, sr_launch_conv0(a, th, c->precision, nblk, img_u8, s));
         } else {
             StageArgs a{};
             float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
@@ -361,11 +404,11 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
                 case 3: a.src[0] = f; a.src[1] = l1; a.src[2] = l2; a.dst = l3; break;
                 case 4: a.src[0] = l1; a.src[1] = l2; a.src[2] = l3; a.img = d_img; a.out = d_out; break;
             }
-            a.wpack = P + c->off_w[st]; a.bias = P + c->off_bias[st];
+            a.wpack = P + (c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
             a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
             a.H = H; a.W = W; a.img_ch = img_ch;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
-            HIPCHK(c, sr_launch_stage(st, a, th, nblk, img_u8, out_u8, s));
+            HIPCHK(c, sr_launch_stage(st, a, th, c->precision, nblk, img_u8, out_u8, s));
         }
         if (prof) HIPCHK(c, hipEventRecord(c->ev[st + 1], s));
     }
@@ -452,6 +495,13 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
     const float* src = c->d_feat[which] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
     HIPCHK(c, hipMemcpy2D(out_host, (size_t)c->last_w * 128, src, (size_t)c->pitch * 128, (size_t)c->last_w * 128,
                           c->last_h, hipMemcpyDeviceToHost));
+    if (c->precision == SR_PRECISION_SPLIT_F16) {  // pixel = 32 hi halves + 32 lo halves -> 32 f32, in place
+        for (size_t p = 0; p < (size_t)c->last_h * c->last_w; ++p) {
+            _Float16 hl[64];
+            memcpy(hl, out_host + p * 32, 128);
+            for (int k = 0; k < 32; ++k) out_host[p * 32 + k] = (float)hl[k] + (float)hl[32 + k] * (1.0f / 2048.0f);
+        }
+    }
     return SR_OK;
 }
 

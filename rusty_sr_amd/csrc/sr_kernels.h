@@ -40,6 +40,7 @@ constexpr int kFeatPad = 2;          // 5x5 halo
 constexpr int kFeatPadBottom = 12;   // last tile row may start at H-1: + 8 rows + 2 halo (+2 spare)
 constexpr int kVoffEntries = 448;    // 7 groups of 64 tile pixels
 
-hipError_t sr_launch_conv0(const Conv0Args& a, int th, int nblk, bool img_u8, hipStream_t s);
-hipError_t sr_launch_stage(int stage, const StageArgs& a, int th, int nblk, bool img_u8, bool out_u8,
+// prec: 0 = exact f32 (v_mfma_f32_32x32x2_f32), 1 = split-half (3 x v_mfma_f32_32x32x16_f16)
+hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool img_u8, hipStream_t s);
+hipError_t sr_launch_stage(int stage, const StageArgs& a, int th, int prec, int nblk, bool img_u8, bool out_u8,
                            hipStream_t s);

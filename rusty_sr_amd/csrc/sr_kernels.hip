@@ -36,6 +36,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sr_kernels.h"
 
 // The reference CPU path (rustc/LLVM) never fuses a*b+c; neither may we, or the two
@@ -45,6 +47,8 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // Optional per-workgroup phase timestamps for scripts/timeline.hip (never compiled
 // into the product library).
@@ -108,6 +112,68 @@ __device__ __forceinline__ float load_img(const void* img, int img_ch, bool u8, 
     return ((const float*)img)[px * 3 + c];
 }
 
+// ---- split-half ("f16x3") representation -----------------------------------
+// A value v is carried as two halves: hi = half(v) (flushed to 0 below the half
+// normal range, so nothing depends on the MFMA's denormal mode) and
+// lo = half((v - hi) * 2048).  v = hi + lo/2048 to ~2^-23 relative.  A product
+// v*w is then hi_v*hi_w + (hi_v*lo_w + lo_v*hi_w)/2048 (the lo*lo term is 2^-24):
+// three v_mfma_f32_32x32x16_f16 on the real matrix cores (16x the f32-MFMA rate
+// each) with f32 accumulation, instead of 8 f32 MFMAs on the vector ALU.
+constexpr float kLoScale = 2048.0f;
+__device__ __forceinline__ void split_half(float v, _Float16& hi, _Float16& lo) {
+    hi = __builtin_fabsf(v) < 6.103515625e-05f ? (_Float16)0.0f : (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * kLoScale);
+}
+
+// BeLU(acc) of one 32x32 tile -> split-half NHWC rows.  A feature pixel is 128 B:
+// 32 hi halves then 32 lo halves.  Lane = channel j, register pair (r, r+1) = two
+// adjacent pixels: even lanes collect channels (j, j+1) of pixel `row` from their
+// odd neighbour, odd lanes channels (j-1, j) of pixel `row+1`, so every store is a
+// full dword and 16 even (odd) lanes write one contiguous 64-byte half line.
+// `base` already points at this lane's pixel (x0 + 4h + (j&1)) and channel pair.
+__device__ __forceinline__ void store_belu_tile_split(char* base, const f32x16& accm, const f32x16& accx,
+                                                      float bias, float beta, bool odd) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float v0 = belu(accm[r] + accx[r] * (1.0f / kLoScale) + bias, beta);
+        const float v1 = belu(accm[r + 1] + accx[r + 1] * (1.0f / kLoScale) + bias, beta);
+        _Float16 h0, l0, h1, l1;
+        split_half(v0, h0, l0);
+        split_half(v1, h1, l1);
+        const uint32_t mh = __builtin_bit_cast(uint32_t, f16x2{h0, h1});
+        const uint32_t ml = __builtin_bit_cast(uint32_t, f16x2{l0, l1});
+        const uint32_t ph = __shfl_xor(mh, 1), pl = __shfl_xor(ml, 1);
+        // even: (my r | partner r << 16)   odd: (partner r+1 | my r+1 << 16)
+        const uint32_t oh = odd ? ((ph >> 16) | (mh & 0xffff0000u)) : ((mh & 0xffffu) | (ph << 16));
+        const uint32_t ol = odd ? ((pl >> 16) | (ml & 0xffff0000u)) : ((ml & 0xffffu) | (pl << 16));
+        const int row = (r & 3) + 8 * (r >> 2);
+        *(uint32_t*)(base + row * 128) = oh;
+        *(uint32_t*)(base + row * 128 + 64) = ol;
+    }
+}
+
+__device__ __forceinline__ void store_belu_tile_split_masked(char* base, const f32x16& accm, const f32x16& accx,
+                                                             float bias, float beta, bool odd, int limit) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float v0 = belu(accm[r] + accx[r] * (1.0f / kLoScale) + bias, beta);
+        const float v1 = belu(accm[r + 1] + accx[r + 1] * (1.0f / kLoScale) + bias, beta);
+        _Float16 h0, l0, h1, l1;
+        split_half(v0, h0, l0);
+        split_half(v1, h1, l1);
+        const uint32_t mh = __builtin_bit_cast(uint32_t, f16x2{h0, h1});
+        const uint32_t ml = __builtin_bit_cast(uint32_t, f16x2{l0, l1});
+        const uint32_t ph = __shfl_xor(mh, 1), pl = __shfl_xor(ml, 1);
+        const uint32_t oh = odd ? ((ph >> 16) | (mh & 0xffff0000u)) : ((mh & 0xffffu) | (ph << 16));
+        const uint32_t ol = odd ? ((pl >> 16) | (ml & 0xffff0000u)) : ((ml & 0xffffu) | (pl << 16));
+        const int row = (r & 3) + 8 * (r >> 2);
+        if (row < limit) {  // `limit` = image columns left of this lane's first pixel
+            *(uint32_t*)(base + row * 128) = oh;
+            *(uint32_t*)(base + row * 128 + 64) = ol;
+        }
+    }
+}
+
 // Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`
 // (row = (r&3) + 8*(r>>2); the lane's +4*h is already in `base`): compile-time
 // offsets, so each store is one instruction with an immediate.
@@ -123,7 +189,7 @@ __device__ __forceinline__ void for_each_acc_row(F&& f) {
 // Stage 0: conv0 5x5 3->32 + bias + BeLU.  K = 25 taps x 4 (3 ch + zero pad),
 // two MFMAs per tap; x tile (with halo) and all of conv0's weights sit in LDS.
 // ---------------------------------------------------------------------------
-template <int TH, bool IMG_U8>
+template <int TH, bool IMG_U8, int PREC>
 __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     constexpr int T = TH / 4;
     constexpr int TWH = kTW + 4, THH = TH + 4, NPIX = THH * TWH;
@@ -183,13 +249,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     for (int m = 0; m < T; ++m) {
         const int y = y0 + wave * T + m;
         if (y >= a.y_end) continue;
-        float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
-        if (full_x) {
-            store_belu_tile(base, acc[m], bias, beta);
+        if constexpr (PREC == 0) {
+            float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
+            if (full_x) {
+                store_belu_tile(base, acc[m], bias, beta);
+            } else {
+                for_each_acc_row([&](int r, int row) {
+                    if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
+                });
+            }
         } else {
-            for_each_acc_row([&](int r, int row) {
-                if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
-            });
+            // split-half map; the row pitch is a multiple of 32 px (+4), so the partial
+            // last tile column may be written in full: the overhang lands in the zero
+            // border's columns >= W... which must stay zero -> mask by zeroing instead
+            f32x16 zero, am = acc[m];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            char* base = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h + (i & 1)) * 32) + (i & ~1) * 2;
+            if (full_x) {
+                store_belu_tile_split(base, am, zero, bias, beta, i & 1);
+            } else {
+                store_belu_tile_split_masked(base, am, zero, bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)));
+            }
         }
     }
 }
@@ -298,6 +379,51 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, ch
     }
 }
 
+// Split-half flavour of conv_taps: the LDS tile planes 0-3 hold the hi halves of
+// cin groups 0-7 / 8-15 / 16-23 / 24-31, planes 4-7 the lo halves; a weight chunk
+// is [hi: 4 x 32 cout x 8 halves][lo: same].  Per tap and tile row: 2 K-steps of
+// 16 cin x 3 products = 6 v_mfma_f32_32x32x16_f16 (192 cycles vs 1024 for f32).
+template <int TH, int KS, int T>
+__device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T], const char* tile, char* ring,
+                                            const float* __restrict__ wpack, int& gtap, int& slot,
+                                            int ntaps_total, int wave, int lane) {
+    using G = TileGeom<TH, KS>;
+    const int i = lane & 31, h = lane >> 5;
+    const int wlane = (h * 32 + i) * 16;
+    const char* abase = tile + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
+    for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const bool more = gtap + 2 < ntaps_total;
+            const int slot2 = slot >= 1 ? slot - 1 : slot + 2;
+            if (more)
+                weight_chunk_async(ring + slot2 * 4096, wpack + (size_t)(gtap + 2) * kChunkFloats, wave, lane);
+            const char* wb = ring + slot * 4096 + wlane;
+            const char* ab = abase + (ky * G::TWH + kx) * 16;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const f16x8 bh = *(const f16x8*)(wb + kk * 1024);
+                const f16x8 bl = *(const f16x8*)(wb + 2048 + kk * 1024);
+                f16x8 ah[T], al[T];
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    ah[m] = *(const f16x8*)(ab + (kk * 2) * G::PLANE + m * G::TWH * 16);
+                    al[m] = *(const f16x8*)(ab + (4 + kk * 2) * G::PLANE + m * G::TWH * 16);
+                }
+#pragma unroll
+                for (int m = 0; m < T; ++m) accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, accm[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, accx[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, accx[m], 0, 0, 0);
+            }
+            ++gtap;
+            slot = slot == kRingSlots - 1 ? 0 : slot + 1;
+            if (more) ring_barrier<1>(); else ring_barrier<0>();
+        }
+    }
+}
+
 // Final stage only: the bilinear x3 residual (LinearInterp, network.rs:27) as nine
 // more taps of a 4-channel (RGB + zero) source.  The image tile is staged with
 // edge-REPLICATED coordinates (the interp clamps indices, it does not zero-pad),
@@ -347,7 +473,7 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[T], char* tile, char* rin
 // two co-resident workgroups wins the MFMA arbitration, and a looping workgroup
 // has to drain its own epilogue stores before its next tile's DMA barrier, which
 // a retiring workgroup never waits for.)
-template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8>
+template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC>
 __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(StageArgs a) {
     constexpr int T = TH / 4;
     using G0 = TileGeom<TH, KS0>;
@@ -377,17 +503,25 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
     const float bias = a.bias[i];
     const float beta = FINAL ? 0.f : a.beta[i];
     {
-        f32x16 acc[T];
+        f32x16 acc[T], accx[PREC == 1 ? T : 1];  // accx: the cross products of the split-half mode, x2048
 #pragma unroll
         for (int m = 0; m < T; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[m][r] = 0.f;
+                if constexpr (PREC == 1) accx[m][r] = 0.f;
+            }
         int gtap = 0, slot = 0;
+        auto taps = [&](auto ks_tag) {
+            constexpr int KS = decltype(ks_tag)::value;
+            if constexpr (PREC == 0) conv_taps<TH, KS, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+            else conv_taps_h<TH, KS, T>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+        };
         TL(0); TL(1);
         ring_barrier<0>();  // every wave's tile + weight DMAs have landed
         __builtin_amdgcn_s_setprio(0);
         TL(2);
-        conv_taps<TH, KS0, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+        taps(std::integral_constant<int, KS0>{});
         TL(3);
         if constexpr (NSRC >= 2) {
             __builtin_amdgcn_s_setprio(3);
@@ -395,7 +529,7 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
             ring_barrier<0>();
             __builtin_amdgcn_s_setprio(0);
             TL(4);
-            conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+            taps(std::integral_constant<int, 3>{});
             TL(5);
         }
         if constexpr (NSRC >= 3) {
@@ -403,7 +537,7 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
             stage_tile<TH, 3>(tile, a.src[2], a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
             ring_barrier<0>();
             __builtin_amdgcn_s_setprio(0);
-            conv_taps<TH, 3, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+            taps(std::integral_constant<int, 3>{});
         }
         __builtin_amdgcn_s_setprio(3);
         if constexpr (FINAL)
@@ -416,16 +550,28 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
             for (int m = 0; m < T; ++m) {
                 const int y = y0 + wave * T + m;
                 if (y >= a.y_end) continue;
-                float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
-                if (full_x) {
-                    store_belu_tile(base, acc[m], bias, beta);
+                if constexpr (PREC == 0) {
+                    float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
+                    if (full_x) {
+                        store_belu_tile(base, acc[m], bias, beta);
+                    } else {
+                        for_each_acc_row([&](int r, int row) {
+                            if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
+                        });
+                    }
                 } else {
-                    for_each_acc_row([&](int r, int row) {
-                        if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
-                    });
+                    char* base = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h + (i & 1)) * 32) + (i & ~1) * 2;
+                    if (full_x) store_belu_tile_split(base, acc[m], accx[m], bias, beta, i & 1);
+                    else store_belu_tile_split_masked(base, acc[m], accx[m], bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)));
                 }
             }
         } else {
+            if constexpr (PREC == 1) {
+#pragma unroll
+                for (int m = 0; m < T; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][r] = acc[m][r] + accx[m][r] * (1.0f / kLoScale);
+            }
             // Expand (network.rs:39): lane i < 27 owns expand channel i = (dy*3+dx)*3+c;
             // out[3y+dy][3x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
             const int ch = i < 27 ? i : 26;
@@ -474,17 +620,18 @@ static constexpr size_t stage_lds_bytes() {
     return 8 * (size_t)TileGeom<TH, KS0>::PLANE + kRingBytes;
 }
 
-template <int TH>
+template <int TH, int PREC>
 static hipError_t launch_conv0_t(const Conv0Args& a, int nblk, bool img_u8, hipStream_t s) {
     if (img_u8)
-        hipLaunchKernelGGL((conv0_kernel<TH, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((conv0_kernel<TH, true, PREC>), dim3(nblk), dim3(kThreads), 0, s, a);
     else
-        hipLaunchKernelGGL((conv0_kernel<TH, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((conv0_kernel<TH, false, PREC>), dim3(nblk), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t sr_launch_conv0(const Conv0Args& a, int th, int nblk, bool img_u8, hipStream_t s) {
-    return th == 8 ? launch_conv0_t<8>(a, nblk, img_u8, s) : launch_conv0_t<4>(a, nblk, img_u8, s);
+hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool img_u8, hipStream_t s) {
+    if (prec == 0) return th == 8 ? launch_conv0_t<8, 0>(a, nblk, img_u8, s) : launch_conv0_t<4, 0>(a, nblk, img_u8, s);
+    return th == 8 ? launch_conv0_t<8, 1>(a, nblk, img_u8, s) : launch_conv0_t<4, 1>(a, nblk, img_u8, s);
 }
 
 template <typename K>
@@ -499,23 +646,26 @@ static hipError_t launch_with_lds(K kern, const StageArgs& a, int nblk, size_t l
     return hipGetLastError();
 }
 
-template <int TH>
+template <int TH, int PREC>
 static hipError_t launch_stage_t(int stage, const StageArgs& a, int nblk, bool img_u8, bool out_u8,
                                  hipStream_t s) {
     switch (stage) {
-        case 1: return launch_with_lds(conv_stage_kernel<TH, 1, 5, false, false, false>, a, nblk, stage_lds_bytes<TH, 5>(), s);
-        case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false>, a, nblk, stage_lds_bytes<TH, 5>(), s);
-        case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 1: return launch_with_lds(conv_stage_kernel<TH, 1, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
         case 4:
-            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true>, a, nblk, stage_lds_bytes<TH, 3>(), s);
-            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false>, a, nblk, stage_lds_bytes<TH, 3>(), s);
+            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC>, a, nblk, stage_lds_bytes<TH, 3>(), s);
+            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 3>(), s);
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t sr_launch_stage(int stage, const StageArgs& a, int th, int nblk, bool img_u8, bool out_u8,
+hipError_t sr_launch_stage(int stage, const StageArgs& a, int th, int prec, int nblk, bool img_u8, bool out_u8,
                            hipStream_t s) {
-    return th == 8 ? launch_stage_t<8>(stage, a, nblk, img_u8, out_u8, s)
-                   : launch_stage_t<4>(stage, a, nblk, img_u8, out_u8, s);
+    if (prec == 0)
+        return th == 8 ? launch_stage_t<8, 0>(stage, a, nblk, img_u8, out_u8, s)
+                       : launch_stage_t<4, 0>(stage, a, nblk, img_u8, out_u8, s);
+    return th == 8 ? launch_stage_t<8, 1>(stage, a, nblk, img_u8, out_u8, s)
+                   : launch_stage_t<4, 1>(stage, a, nblk, img_u8, out_u8, s);
 }

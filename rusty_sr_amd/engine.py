@@ -56,13 +56,21 @@ def img_to_data(pixels: np.ndarray) -> np.ndarray:
 class Engine:
     """One sr_ctx (= one GPU, one parameter set)."""
 
-    def __init__(self, params, device: int = 0, factor: int = FACTOR):
+    PRECISIONS = {"f32": _lib.SR_PRECISION_F32, "split_f16": _lib.SR_PRECISION_SPLIT_F16}
+
+    def __init__(self, params, device: int = 0, factor: int = FACTOR, precision: str = "f32"):
         L = _lib.lib()
         p = np.ascontiguousarray(params, dtype=np.float32)
         self._ctx = C.c_void_p()
         _lib.check(L.sr_create(C.byref(self._ctx), p.ctypes.data_as(C.POINTER(C.c_float)), p.size, factor, device))
         self.device = device
         self._L = L
+        self.set_precision(precision)
+
+    def set_precision(self, precision: str):
+        """"f32": exact-f32 MFMA (default).  "split_f16": hi/lo half pairs, 3 f16 MFMAs per product."""
+        _lib.check(self._L.sr_set_precision(self._ctx, self.PRECISIONS[precision]))
+        self.precision = precision
 
     def close(self):
         if getattr(self, "_ctx", None):

@@ -14,10 +14,12 @@ TOL = 1e-4          # north_star tolerance, pre-quantisation f32
 TIGHT = 2e-5        # what exact-f32 MFMA actually achieves (rounding-order noise only)
 
 
-@pytest.fixture(scope="module")
-def engines(params):
+@pytest.fixture(scope="module", params=["f32", "split_f16"])
+def engines(params, request):
+    """Every parity test runs in both arithmetic modes of the engine: exact-f32 MFMA
+    and split-half (3 f16 MFMAs per product); the bar is the same."""
     import rusty_sr_amd as r
-    e = {k: r.Engine(v, device=0) for k, v in params.items()}
+    e = {k: r.Engine(v, device=0, precision=request.param) for k, v in params.items()}
     yield e
     for x in e.values():
         x.close()
