@@ -116,8 +116,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--io", choices=["rgba8", "f32"], default="rgba8")
     ap.add_argument("--weights", default="imagenet")
-    ap.add_argument("--precision", choices=["f32", "split_f16"], default=os.environ.get("SRHIP_PRECISION", "f32"),
-                    help="f32: exact-f32 MFMA.  split_f16: hi/lo half pairs, 3 f16 MFMAs per product (same 1e-4 parity bar)")
+    ap.add_argument("--precision", choices=["f32", "split_f16"], default=os.environ.get("SRHIP_PRECISION", "split_f16"),
+                    help="split_f16 (default): hi/lo half pairs, 3 f16 MFMAs per product on the matrix cores -- the fastest "
+                         "mode that passes the north-star parity bar (<= 1e-4; measured <= 2e-5, every GPU parity test runs "
+                         "in both modes).  f32: exact-f32 MFMA (vector-ALU rate); reported beside it at N=1.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -226,6 +228,30 @@ def main():
         result["hbm"] = {"algorithmic_GBps": round(io_bytes / (ms_per_step / 1e3) / 1e9, 2), "peak_GBps": PEAK_HBM_GBPS,
                          "note": "compulsory image I/O only; the path is MFMA-bound (2170 FLOP/B)"}
         result["device"] = eng.device_info()
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # the other arithmetic mode on the same resident image, same number of steps
+        other = "f32" if args.precision == "split_f16" else "split_f16"
+        eng.set_precision(other)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        oms = (time.perf_counter() - t0) / args.steps * 1e3
+        eng.set_profiling(True)
+        run(xchg.ext); torch.cuda.synchronize()
+        ost = eng.last_timing()["stage_ms"]
+        eng.set_profiling(False)
+        eng.set_precision(args.precision)
+        peak_o = PEAK_F32_MFMA_TFLOPS if other == "f32" else PEAK_F16_MFMA_TFLOPS
+        ach_o = 2 * MAC_PER_PX[3] * H * W / (ost[3] / 1e3) / 1e12
+        result["other_precision"] = {"precision": other, "value": round((3 * H) * (3 * W) / 1e6 / (oms / 1e3), 2),
+                                     "unit": "output MP/s", "ms_per_step": round(oms, 4),
+                                     "stage3_tflops": round(ach_o, 2), "stage3_frac_of_peak": round(ach_o / peak_o, 4),
+                                     "peak": peak_o}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(params, px)

@@ -110,6 +110,7 @@ struct sr_ctx {
     size_t feat_cap_px = 0;       // allocated padded pixels per map
     int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
     int pitch = 0; long img_stride = 0;
+    int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
     uint32_t* d_voff = nullptr;   // 2 x kVoffEntries LDS-DMA gather offsets (5x5 tile, 3x3 tile)
     int voff_pitch = 0, voff_th = 0;
     void* d_in = nullptr;  size_t in_cap = 0;    // staging for the host-pointer entry points
@@ -243,6 +244,7 @@ int sr_create(sr_ctx** out, const float* params, size_t n_params, int factor, in
         const size_t aoff[4] = {OFF_F_ACTIV, OFF_L1_ACTIV, OFF_L2_ACTIV, OFF_L3_ACTIV};
         for (int s = 0; s < 5; ++s) c->off_bias[s] = push(vec32(boff[s], s == 4 ? 27 : 32));
         for (int s = 0; s < 4; ++s) c->off_beta[s] = push(vec32(aoff[s], 32));
+        HIPCHK(c, hipMalloc((void**)&c->d_queue, 5 * 8 * sizeof(int)));
         HIPCHK(c, hipMalloc((void**)&c->d_params, host.size() * sizeof(float)));
         HIPCHK(c, hipMemcpy(c->d_params, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
         return SR_OK;
@@ -262,6 +264,7 @@ void sr_destroy(sr_ctx* c) {
     for (auto& p : c->d_feat) if (p) (void)hipFree(p);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_voff) (void)hipFree(c->d_voff);
+    if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -379,6 +382,8 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
     float* feat[4];
     for (int k = 0; k < 4; ++k) feat[k] = c->d_feat[k] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
+    const bool persist = c->precision == SR_PRECISION_SPLIT_F16;  // see conv_stage_kernel
+    if (persist) HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of all stages
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
         int y0 = top - margin[st], y1 = bot + margin[st];
@@ -408,7 +413,13 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
             a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
             a.H = H; a.W = W; a.img_ch = img_ch;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
-            HIPCHK(c, sr_launch_stage(st, a, th, c->precision, nblk, img_u8, out_u8, s));
+            a.n_img = n; a.queue = c->d_queue + st * 8;
+            int grid = nblk;
+            if (persist) {  // the workgroups that are co-resident: 2 per CU with 8-row tiles, 3 with 4-row tiles
+                const int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);
+                if (grid > resident) grid = resident;
+            }
+            HIPCHK(c, sr_launch_stage(st, a, th, c->precision, grid, img_u8, out_u8, s));
         }
         if (prof) HIPCHK(c, hipEventRecord(c->ev[st + 1], s));
     }

@@ -31,6 +31,8 @@ struct StageArgs {
     long img_stride;      // feature-map image stride in pixels
     int y_begin, y_end;
     int tiles_x, tiles_y;
+    int n_img;            // images in the batch (tiles = n_img * tiles_x * tiles_y)
+    int* queue;           // persistent form: 8 per-XCD tile-queue heads, zeroed before the launch
 };
 
 // Feature maps live in HBM with a zero border so tile staging never tests bounds:

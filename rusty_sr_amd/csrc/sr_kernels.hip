@@ -37,6 +37,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "sr_kernels.h"
 
@@ -64,7 +65,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kTW = 32;            // tile width = one MFMA M-tile of pixels
 constexpr int kChunkFloats = 1024; // one tap: 32 cin x 32 cout
-constexpr int kRingSlots = 3;      // 4 KB weight chunks: one being read, two in flight
+constexpr int kRingSlots = 5;      // 4 KB weight chunks: one being read, up to four in flight
+constexpr int kRingAhead = 4;      // tap t requests the chunk of tap t + kRingAhead
 constexpr int kRingBytes = kRingSlots * 4096;
 
 __device__ __forceinline__ float belu(float v, float beta) {
@@ -333,12 +335,36 @@ __device__ __forceinline__ void weight_chunk_async(char* ring_slot, const float*
 // is no longer being read by anybody once every wave has passed.
 template <int PENDING>
 __device__ __forceinline__ void ring_barrier() {
-    if constexpr (PENDING == 1)
-        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    static_assert(PENDING >= 0 && PENDING <= 3, "");
+    if constexpr (PENDING == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    else if constexpr (PENDING == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (PENDING == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// Ring bookkeeping shared by both tap loops: at tap `gtap` (its chunk sits in
+// `slot`) request chunk gtap + kRingAhead into the slot freed by the previous
+// barrier; after the tap's MFMAs, wait until chunk gtap + 1 has landed, i.e. until
+// at most `chunks requested after it` DMAs remain in flight.
+__device__ __forceinline__ void ring_request(char* ring, const float* __restrict__ wpack, int gtap, int slot,
+                                             int ntaps_total, int wave, int lane) {
+    if (gtap + kRingAhead < ntaps_total) {
+        int s2 = slot + kRingAhead;
+        if (s2 >= kRingSlots) s2 -= kRingSlots;
+        weight_chunk_async(ring + s2 * 4096, wpack + (size_t)(gtap + kRingAhead) * kChunkFloats, wave, lane);
+    }
+}
+__device__ __forceinline__ void ring_advance(int& gtap, int& slot, int ntaps_total) {
+    // chunks still allowed in flight after chunk gtap+1 is complete: those of taps gtap+2 .. min(gtap+4, last)
+    const int pending = min(kRingAhead - 1, ntaps_total - 2 - gtap);
+    ++gtap;
+    slot = slot == kRingSlots - 1 ? 0 : slot + 1;
+    if (pending >= 3) ring_barrier<3>();
+    else if (pending == 2) ring_barrier<2>();
+    else if (pending == 1) ring_barrier<1>();
+    else ring_barrier<0>();
 }
 
 // One source's KS x KS taps.  The weight chunk of tap t+2 is requested (LDS-DMA)
@@ -354,10 +380,7 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, ch
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
-            const bool more = gtap + 2 < ntaps_total;
-            const int slot2 = slot >= 1 ? slot - 1 : slot + 2;  // (slot + 2) % 3: free since the last barrier
-            if (more)
-                weight_chunk_async(ring + slot2 * 4096, wpack + (size_t)(gtap + 2) * kChunkFloats, wave, lane);
+            ring_request(ring, wpack, gtap, slot, ntaps_total, wave, lane);
             const char* wb = ring + slot * 4096 + wlane;
             const char* ab = abase + (ky * G::TWH + kx) * 16;
 #pragma unroll
@@ -372,9 +395,7 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, ch
                     for (int m = 0; m < T; ++m)
                         acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], b[q], acc[m], 0, 0, 0);
             }
-            ++gtap;
-            slot = slot == kRingSlots - 1 ? 0 : slot + 1;
-            if (more) ring_barrier<1>(); else ring_barrier<0>();  // chunk gtap has landed everywhere
+            ring_advance(gtap, slot, ntaps_total);  // chunk gtap has landed everywhere
         }
     }
 }
@@ -383,6 +404,10 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, ch
 // cin groups 0-7 / 8-15 / 16-23 / 24-31, planes 4-7 the lo halves; a weight chunk
 // is [hi: 4 x 32 cout x 8 halves][lo: same].  Per tap and tile row: 2 K-steps of
 // 16 cin x 3 products = 6 v_mfma_f32_32x32x16_f16 (192 cycles vs 1024 for f32).
+// (A hand software-pipelined form -- all operand reads of tap t+1 in flight under
+// tap t's MFMAs, two register sets -- measured no faster and spilled; hipcc
+// re-orders the stream anyway.  Getting past ~45 % MFMA utilisation here needs an
+// assembly-level schedule: next round.)
 template <int TH, int KS, int T>
 __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T], const char* tile, char* ring,
                                             const float* __restrict__ wpack, int& gtap, int& slot,
@@ -394,10 +419,7 @@ __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T]
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
-            const bool more = gtap + 2 < ntaps_total;
-            const int slot2 = slot >= 1 ? slot - 1 : slot + 2;
-            if (more)
-                weight_chunk_async(ring + slot2 * 4096, wpack + (size_t)(gtap + 2) * kChunkFloats, wave, lane);
+            ring_request(ring, wpack, gtap, slot, ntaps_total, wave, lane);
             const char* wb = ring + slot * 4096 + wlane;
             const char* ab = abase + (ky * G::TWH + kx) * 16;
 #pragma unroll
@@ -417,9 +439,7 @@ __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T]
 #pragma unroll
                 for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, accx[m], 0, 0, 0);
             }
-            ++gtap;
-            slot = slot == kRingSlots - 1 ? 0 : slot + 1;
-            if (more) ring_barrier<1>(); else ring_barrier<0>();
+            ring_advance(gtap, slot, ntaps_total);
         }
     }
 }
@@ -468,41 +488,83 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[T], char* tile, char* rin
     }
 }
 
-// One workgroup per tile.  (Persistent variants -- a static split of the tiles
-// and a dynamic per-XCD queue -- were measured 4 % SLOWER on MI355X: the older of
-// two co-resident workgroups wins the MFMA arbitration, and a looping workgroup
-// has to drain its own epilogue stores before its next tile's DMA barrier, which
-// a retiring workgroup never waits for.)
-template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC>
+// Dynamic tile queue for the persistent form.  The tiles are cut into 8 contiguous
+// runs, one per XCD (the dispatcher places block b on XCD b % 8: neighbouring tiles
+// share halo rows in that XCD's L2); each run has a head counter in HBM (zeroed by
+// the host before the launch).  A workgroup pulls from its own XCD's run and, once
+// that is exhausted, steals from the others.
+__device__ __forceinline__ void run_of_xcd(int x, int ntiles, int& start, int& count) {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    count = q + (x < r ? 1 : 0);
+    start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+}
+__device__ __forceinline__ int queue_resolve(int* queue, int xcd, int ntiles, int idx) {
+    int start, count;
+    run_of_xcd(xcd, ntiles, start, count);
+    if (idx < count) return start + idx;
+    for (int k = 1; k < 8; ++k) {  // steal (tail of the launch only)
+        const int x = (xcd + k) & 7;
+        run_of_xcd(x, ntiles, start, count);
+        const int j = atomicAdd(&queue[x], 1);
+        if (j < count) return start + j;
+    }
+    return -1;
+}
+
+// PERSIST = false: one workgroup per tile (grid = tiles, XCD-remapped).  Best for the
+// exact-f32 mode, where a tile lasts ~45 us and persistent forms measured 4 % slower.
+// PERSIST = true: grid = co-resident workgroups, tiles pulled from the queue, and the
+// next tile's DMA is requested before the current tile's epilogue.  Best for the
+// split-half mode, whose tiles last ~14 us: with one tile per workgroup 30 % of the
+// workgroup slots sat empty between a retire and the next dispatch.
+template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, bool PERSIST>
 __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(StageArgs a) {
     constexpr int T = TH / 4;
     using G0 = TileGeom<TH, KS0>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tile = smem;
     char* ring = smem + 8 * G0::PLANE;  // KS0 >= 3: the first source has the largest tile
+    volatile int* s_next = (volatile int*)(ring + kRingBytes);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     constexpr int NTAPS = KS0 * KS0 + (NSRC - 1) * 9;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n = bid / tiles_per_img, t = bid - n * tiles_per_img;
-    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-    const int x0 = tx * kTW, y0 = a.y_begin + ty * TH;
+    const int ntiles = tiles_per_img * a.n_img;
+    const int xcd = blockIdx.x & 7;
+    const float bias = a.bias[i];
+    const float beta = FINAL ? 0.f : a.beta[i];
+
+    // request everything the first phase of tile `t` needs: weight chunks 0..3 and the first source tile
+    int n = 0, x0 = 0, y0 = 0;
+    auto request_tile = [&](int t) {
+        n = t / tiles_per_img;
+        const int r = t - n * tiles_per_img, ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        x0 = tx * kTW; y0 = a.y_begin + ty * TH;
+#pragma unroll
+        for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
+        stage_tile<TH, KS0>(tile, a.src[0], KS0 == 5 ? a.voff5 : a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+    };
 
     // Two workgroups share each SIMD.  A wave streaming MFMAs is the older one and
     // wins every VALU arbitration, leaving the other workgroup's staging / epilogue
     // code roughly one issue slot per MFMA.  The matrix stream only needs one slot
     // per 64 cycles, so the non-MFMA phases run at raised priority.
     __builtin_amdgcn_s_setprio(3);
-    // weight chunks 0 and 1 -> ring slots 0 and 1 (every stage has >= 25 taps), first source tile
-    weight_chunk_async(ring, a.wpack, wave, lane);
-    weight_chunk_async(ring + 4096, a.wpack + kChunkFloats, wave, lane);
-    stage_tile<TH, KS0>(tile, a.src[0], KS0 == 5 ? a.voff5 : a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
-    const float bias = a.bias[i];
-    const float beta = FINAL ? 0.f : a.beta[i];
-    {
+    int cur;
+    if constexpr (PERSIST) {
+        if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
+        __syncthreads();
+        cur = *s_next;
+        if (cur < 0) return;
+    } else {
+        cur = xcd_remap(blockIdx.x, gridDim.x);
+    }
+    request_tile(cur);
+
+    while (true) {
+        const int tn = n, tx0 = x0, ty0 = y0;  // this tile (request_tile below overwrites n, x0, y0)
         f32x16 acc[T], accx[PREC == 1 ? T : 1];  // accx: the cross products of the split-half mode, x2048
 #pragma unroll
         for (int m = 0; m < T; ++m)
@@ -518,14 +580,17 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
             else conv_taps_h<TH, KS, T>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
         };
         TL(0); TL(1);
-        ring_barrier<0>();  // every wave's tile + weight DMAs have landed
+        ring_barrier<0>();  // every wave's tile + weight DMAs (and earlier stores) have landed
+        int pulled = 0;     // ask for the next tile now; the answer is looked at after this source's taps
+        if constexpr (PERSIST) { if (tid == 0) pulled = atomicAdd(&a.queue[xcd], 1); }
         __builtin_amdgcn_s_setprio(0);
         TL(2);
         taps(std::integral_constant<int, KS0>{});
+        if constexpr (PERSIST) { if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, pulled); }
         TL(3);
         if constexpr (NSRC >= 2) {
             __builtin_amdgcn_s_setprio(3);
-            stage_tile<TH, 3>(tile, a.src[1], a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+            stage_tile<TH, 3>(tile, a.src[1], a.voff3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
             ring_barrier<0>();
             __builtin_amdgcn_s_setprio(0);
             TL(4);
@@ -534,16 +599,28 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
         }
         if constexpr (NSRC >= 3) {
             __builtin_amdgcn_s_setprio(3);
-            stage_tile<TH, 3>(tile, a.src[2], a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+            stage_tile<TH, 3>(tile, a.src[2], a.voff3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
             ring_barrier<0>();
             __builtin_amdgcn_s_setprio(0);
             taps(std::integral_constant<int, 3>{});
         }
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (FINAL)
-            lin_taps<TH, T, IMG_U8>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
+        if constexpr (FINAL) {
+            lin_taps<TH, T, IMG_U8>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, tn, ty0, tx0, wave, lane, tid);
+            if constexpr (PERSIST) __syncthreads();  // everybody is done reading the image tile / lin weights
+        }
         TL(6);
-
+        bool more_tiles = false;
+        if constexpr (PERSIST) {
+            // the LDS tile and ring are free (last tap's barrier): request the next tile's
+            // weights and first source NOW so the DMA runs under this tile's epilogue
+            if constexpr (NSRC == 1 && !FINAL) __syncthreads();  // publish s_next (later sources' barriers do it otherwise)
+            cur = *s_next;
+            more_tiles = cur >= 0;
+            if (more_tiles) request_tile(cur);
+        }
+        {
+        const int n = tn, x0 = tx0, y0 = ty0;
         const bool full_x = x0 + kTW <= a.W;
         if constexpr (!FINAL) {
 #pragma unroll
@@ -608,7 +685,9 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
                 }
             }
         }
+        }
         TL(7);
+        if (!more_tiles) break;
     }
 }
 
@@ -617,7 +696,7 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
 // ---------------------------------------------------------------------------
 template <int TH, int KS0>
 static constexpr size_t stage_lds_bytes() {
-    return 8 * (size_t)TileGeom<TH, KS0>::PLANE + kRingBytes;
+    return 8 * (size_t)TileGeom<TH, KS0>::PLANE + kRingBytes + 16;  // + next-tile mailbox
 }
 
 template <int TH, int PREC>
@@ -650,12 +729,12 @@ template <int TH, int PREC>
 static hipError_t launch_stage_t(int stage, const StageArgs& a, int nblk, bool img_u8, bool out_u8,
                                  hipStream_t s) {
     switch (stage) {
-        case 1: return launch_with_lds(conv_stage_kernel<TH, 1, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
-        case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
-        case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 1: return launch_with_lds(conv_stage_kernel<TH, 1, 5, false, false, false, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 5>(), s);
         case 4:
-            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC>, a, nblk, stage_lds_bytes<TH, 3>(), s);
-            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 3>(), s);
+            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 3>(), s);
+            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 3>(), s);
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }

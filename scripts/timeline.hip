@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <vector>
 int main(int argc, char** argv) {
-    const int stage = argc > 1 ? atoi(argv[1]) : 1, th = argc > 2 ? atoi(argv[2]) : 8;
+    const int stage = argc > 1 ? atoi(argv[1]) : 1, th = argc > 2 ? atoi(argv[2]) : 8, prec = argc > 3 ? atoi(argv[3]) : 0;
     const int H = 1080, W = 1920;
     const int pitch = W + 4; const long img_stride = (long)(H + 14) * pitch;
     const size_t npx = (size_t)img_stride + 2 * pitch + 64;
@@ -25,10 +25,10 @@ int main(int argc, char** argv) {
     a.voff5 = dvoff; a.voff3 = dvoff + kVoffEntries; a.pitch = pitch; a.img_stride = img_stride;
     a.img = f[0]; a.out = out; a.H = H; a.W = W; a.img_ch = 3; a.y_begin = 0; a.y_end = H;
     a.tiles_x = W / 32; a.tiles_y = (H + th - 1) / th;
-    const int nblk = a.tiles_x * a.tiles_y;
+    const int nblk = a.tiles_x * a.tiles_y; a.n_img = 1; int* dq; hipMalloc(&dq, 64); hipMemset(dq, 0, 64); a.queue = dq;
     long long* tl; hipMalloc(&tl, (size_t)nblk * 128);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
-    for (int rep = 0; rep < 3; ++rep) sr_launch_stage(stage, a, th, nblk, false, false, 0);
+    for (int rep = 0; rep < 3; ++rep) sr_launch_stage(stage, a, th, prec, nblk, false, false, 0);
     hipDeviceSynchronize();
     std::vector<long long> h((size_t)nblk * 16);
     hipMemcpy(h.data(), tl, (size_t)nblk * 128, hipMemcpyDeviceToHost);
@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
         printf("  %-28s mean %9.0f  p10 %8lld  p50 %8lld  p90 %8lld  max %8lld cycles\n", name, s / nblk,
                d[nblk / 10], d[nblk / 2], d[nblk * 9 / 10], d[nblk - 1]);
     };
-    printf("stage %d, TH=%d, %d workgroups (timestamps of thread 0; s_memtime shader cycles)\n", stage, th, nblk);
+    printf("prec %d, ", prec); printf("stage %d, TH=%d, %d workgroups (timestamps of thread 0; s_memtime shader cycles)\n", stage, th, nblk);
     stat("stage tile src0", 1, 2); stat("taps src0", 2, 3);
     if (stage >= 2) { stat("stage tile src1", 3, 4); stat("taps src1", 4, 5); stat("src2 (stage+taps)", 5, 6); }
     stat("  last stage_tile: DMA issue", stage >= 2 ? 5 : 1, 8); if (stage == 1) stat("  last stage_tile: wait+barrier", 8, 2);
