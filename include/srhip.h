@@ -66,6 +66,22 @@ int sr_rsr_encode(const float* params, size_t n, uint8_t* out, size_t cap, size_
 int sr_create(sr_ctx** out, const float* params, size_t n_params, int factor, int device);
 void sr_destroy(sr_ctx* ctx);
 
+/* The reference's upscale() picks one of three graphs (main.rs:133-158):
+ *   SR_GRAPH_SR_NET      sr_net(FACTOR, None)      network.rs:16-109   130459 params
+ *   SR_GRAPH_BILINEAR    bilinear_net(FACTOR)      network.rs:111-123  `-p bilinear`, 0 params
+ *                        sRGB->linear, bilinear x3, linear->sRGB
+ *   SR_GRAPH_DOWNSAMPLE  downsample_net(FACTOR)    network.rs:125-138  `-d`, 0 params
+ *                        sRGB->linear, mean over non-overlapping 3x3 blocks, linear->sRGB;
+ *                        output (h/3) x (w/3), remainder rows / columns dropped
+ * sr_create_graph replaces the `(params, graph)` selection + the count assert
+ * (main.rs:162): n_params must equal sr_num_params(graph).  Every sr_upscale_*
+ * entry point below then means `graph.forward` for whichever graph the context
+ * holds (for SR_GRAPH_DOWNSAMPLE the output is n*(h/3)*(w/3) pixels); the band
+ * entry points exist for SR_GRAPH_SR_NET only. */
+enum sr_graph { SR_GRAPH_SR_NET = 0, SR_GRAPH_BILINEAR = 1, SR_GRAPH_DOWNSAMPLE = 2 };
+int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_params, int factor, int device);
+int sr_num_params(int graph); /* graph.num_params(); -1 for an unknown graph */
+
 /* Replaces: graph.forward(n, vec![input], &params) (reference main.rs:171).
  * in : n*h*w*3 f32 in [0,1] (what img_to_data produced), host memory.
  * out: n*(3h)*(3w)*3 f32, pre-quantisation, host memory. */

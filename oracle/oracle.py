@@ -82,6 +82,10 @@ def _bind(L):
         f = getattr(L, "sr_oracle_forward" + suf)
         f.restype = c.c_int
         f.argtypes = [fp, c.c_size_t, rp, c.c_int, c.c_int, c.c_int, rp, rp]
+        for nm in ("sr_oracle_bilinear", "sr_oracle_downsample"):
+            q = getattr(L, nm + suf)
+            q.restype = c.c_int
+            q.argtypes = [rp, c.c_int, c.c_int, c.c_int, rp]
         g = getattr(L, "sr_oracle_img_to_data" + suf)
         g.restype = None
         g.argtypes = [u8p, c.c_int, c.c_size_t, rp]
@@ -142,6 +146,30 @@ def forward(params, x, f64=False, native=False):
 
 def forward_taps(params, x, f64=False):
     return _forward(params, x, f64, True, False)
+
+
+def _aux(name, x, f64, out_shape):
+    L = lib()
+    dt, ct, suf = (np.float64, ctypes.c_double, "_f64") if f64 else (np.float32, ctypes.c_float, "")
+    x = np.ascontiguousarray(x, dtype=dt)
+    if x.ndim == 3:
+        x = x[None]
+    n, H, W, _ = x.shape
+    out = np.empty((n,) + out_shape(H, W) + (3,), dtype=dt)
+    rc = getattr(L, name + suf)(_ptr(x, ct), n, H, W, _ptr(out, ct))
+    if rc != 0:
+        raise ValueError(f"{name} failed ({rc})")
+    return out
+
+
+def bilinear(x, f64=False):
+    """bilinear_net(3) (reference network.rs:111-123): sRGB->linear, x3 bilinear, ->sRGB."""
+    return _aux("sr_oracle_bilinear", x, f64, lambda H, W: (3 * H, 3 * W))
+
+
+def downsample(x, f64=False):
+    """downsample_net(3) (reference network.rs:125-138): sRGB->linear, 3x3 mean pool, ->sRGB."""
+    return _aux("sr_oracle_downsample", x, f64, lambda H, W: (H // 3, W // 3))
 
 
 def img_to_data(px: np.ndarray) -> np.ndarray:

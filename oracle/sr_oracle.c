@@ -290,4 +290,63 @@ void SYM(sr_oracle_data_to_rgba8)(const real* v, size_t npx, uint8_t* out) {
     }
 }
 
+/* ---- alumina SrgbToLinear / LinearToSrgb (reference network.rs:117,119,133,135):
+ * the IEC 61966-2-1 piecewise transfer curve.  alumina's exact constants are not
+ * visible (crate absent); this curve reproduces docs/logo_lin.png to knife-edge
+ * level, so it is pinned up to quantiser rounding. */
+#ifdef SR_REAL_DOUBLE
+#define POW pow
+#else
+#define POW powf
+#endif
+static inline real srgb_to_linear(real s) {
+    return s <= (real)0.04045 ? s / (real)12.92 : POW((s + (real)0.055) / (real)1.055, (real)2.4);
+}
+static inline real linear_to_srgb(real l) {
+    return l <= (real)0.0031308 ? (real)12.92 * l : (real)1.055 * POW(l, (real)1 / (real)2.4) - (real)0.055;
+}
+
+/* ---- bilinear_net(3) (reference network.rs:111-123; `-p bilinear`, main.rs:153-155):
+ * out = LinearToSrgb(LinearInterp3(SrgbToLinear(in))).  in n*H*W*3 -> out n*3H*3W*3. */
+int SYM(sr_oracle_bilinear)(const real* in, int n, int H, int W, real* out) {
+    if (n < 0 || H <= 0 || W <= 0) return -2;
+    const size_t npx = (size_t)H * W;
+    real* lin = (real*)malloc(sizeof(real) * npx * SR_CH);
+    if (!lin) return -3;
+    for (int b = 0; b < n; ++b) {
+        const real* x = in + (size_t)b * npx * SR_CH;
+        real* o = out + (size_t)b * npx * SR_CH * 9;
+        for (size_t k = 0; k < npx * SR_CH; ++k) lin[k] = srgb_to_linear(x[k]);
+        memset(o, 0, sizeof(real) * npx * SR_CH * 9);
+        linterp3_acc(lin, H, W, o);
+        for (size_t k = 0; k < npx * SR_CH * 9; ++k) o[k] = linear_to_srgb(o[k]);
+    }
+    free(lin);
+    return 0;
+}
+
+/* ---- downsample_net(3) (reference network.rs:125-138; `-d`, main.rs:139-141):
+ * out = LinearToSrgb(Pooling3x3(SrgbToLinear(in))), Pooling = mean over
+ * non-overlapping 3x3 blocks.  UNPINNED: no reference image exercises it, and the
+ * behaviour for sizes not divisible by 3 is unknown; this restatement drops the
+ * remainder rows/columns (output floor(H/3) x floor(W/3)). */
+int SYM(sr_oracle_downsample)(const real* in, int n, int H, int W, real* out) {
+    if (n < 0 || H < 3 || W < 3) return -2;
+    const int OH = H / 3, OW = W / 3;
+    for (int b = 0; b < n; ++b) {
+        const real* x = in + (size_t)b * H * W * SR_CH;
+        real* o = out + (size_t)b * OH * OW * SR_CH;
+        for (int y = 0; y < OH; ++y)
+            for (int xx = 0; xx < OW; ++xx)
+                for (int c = 0; c < SR_CH; ++c) {
+                    real acc = 0;
+                    for (int dy = 0; dy < 3; ++dy)
+                        for (int dx = 0; dx < 3; ++dx)
+                            acc += srgb_to_linear(x[((size_t)(3 * y + dy) * W + 3 * xx + dx) * SR_CH + c]);
+                    o[((size_t)y * OW + xx) * SR_CH + c] = linear_to_srgb(acc / (real)9);
+                }
+    }
+    return 0;
+}
+
 int SYM(sr_oracle_num_params)(void) { return SR_NPARAMS; }

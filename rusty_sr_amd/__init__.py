@@ -3,6 +3,6 @@ millardjn/rusty_sr v1.  The compute lives in libsrhip.so (hand-written HIP,
 C ABI in include/srhip.h); this package is the thin host side."""
 from . import rsr  # noqa: F401
 from .engine import (  # noqa: F401
-    CHANNELS, FACTOR, DataShape, Engine, Graph, NodeData, img_to_data, sr_net,
+    CHANNELS, FACTOR, DataShape, Engine, Graph, NodeData, bilinear_net, downsample_net, img_to_data, sr_net,
 )
 from ._lib import SrError  # noqa: F401

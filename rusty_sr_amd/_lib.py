@@ -13,6 +13,7 @@ SR_HALO = 7
 SR_OK, SR_E_INVALID, SR_E_PARAM_COUNT, SR_E_FACTOR, SR_E_NO_DEVICE = 0, -1, -2, -3, -4
 SR_E_HIP, SR_E_NOMEM, SR_E_BYTEVEC, SR_E_HALO = -5, -6, -7, -8
 SR_PRECISION_F32, SR_PRECISION_SPLIT_F16 = 0, 1
+SR_GRAPH_SR_NET, SR_GRAPH_BILINEAR, SR_GRAPH_DOWNSAMPLE = 0, 1, 2
 
 # every symbol include/srhip.h declares: (restype, argtypes)
 _vp, _fp, _u8p, _dp = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
@@ -21,6 +22,8 @@ SYMBOLS = {
     "sr_rsr_decode": (_i, [_u8p, _sz, _fp, _sz, C.POINTER(_sz)]),
     "sr_rsr_encode": (_i, [_fp, _sz, _u8p, _sz, C.POINTER(_sz)]),
     "sr_create": (_i, [C.POINTER(_vp), _fp, _sz, _i, _i]),
+    "sr_create_graph": (_i, [C.POINTER(_vp), _i, _fp, _sz, _i, _i]),
+    "sr_num_params": (_i, [_i]),
     "sr_destroy": (None, [_vp]),
     "sr_upscale_f32": (_i, [_vp, _fp, _i, _i, _i, _fp]),
     "sr_upscale_rgba8": (_i, [_vp, _u8p, _i, _i, _i, _i, _u8p]),

@@ -32,5 +32,33 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+CLI = os.path.join(HERE, "bin", "rusty_sr")
+PNGLIB = os.path.join(HERE, "libsrpng.so")
+
+
+def build_host(force=False, verbose=False):
+    """g++ -> rusty_sr_amd/bin/rusty_sr (the CLI with the reference's argv surface; links
+    libsrhip.so via $ORIGIN/..) and rusty_sr_amd/libsrpng.so (the PNG codec alone, for tests)."""
+    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "png.cpp")]
+    deps = srcs + [os.path.join(HOST, "png.hpp"), os.path.join(HERE, "..", "include", "srhip.h"), LIB]
+    if not force and os.path.exists(CLI) and os.path.exists(PNGLIB) and \
+            all(os.path.getmtime(d) <= min(os.path.getmtime(CLI), os.path.getmtime(PNGLIB)) for d in deps):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    res = os.path.join(HERE, "res")
+    cmds = [
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", srcs[1], "-lz", "-o", PNGLIB],
+        ["g++", "-O2", "-std=c++17", f'-DSR_RES_DIR="{res}"', *srcs, "-L", HERE, "-lsrhip", "-lz",
+         "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", CLI],
+    ]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

@@ -106,6 +106,7 @@ struct sr_ctx {
     float* d_params = nullptr;  // all packed parameters, one allocation
     size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
+    int graph = SR_GRAPH_SR_NET;
     float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3 (zero-bordered, see sr_kernels.h)
     size_t feat_cap_px = 0;       // allocated padded pixels per map
     int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
@@ -182,16 +183,24 @@ int sr_rsr_encode(const float* params, size_t n, uint8_t* out, size_t cap, size_
 }
 
 int sr_create(sr_ctx** out, const float* params, size_t n_params, int factor, int device) {
-    if (!out || !params) return SR_E_INVALID;
+    return sr_create_graph(out, SR_GRAPH_SR_NET, params, n_params, factor, device);
+}
+
+int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_params, int factor, int device) {
+    if (!out) return SR_E_INVALID;
     *out = nullptr;
+    if (graph != SR_GRAPH_SR_NET && graph != SR_GRAPH_BILINEAR && graph != SR_GRAPH_DOWNSAMPLE) return SR_E_INVALID;
     if (factor != SR_FACTOR) return SR_E_FACTOR;
-    if (n_params != SR_NUM_PARAMS) return SR_E_PARAM_COUNT;
+    // main.rs:162 assert_eq!(params.len(), graph.num_params()): 130459 for sr_net, 0 for the other two
+    if (n_params != (graph == SR_GRAPH_SR_NET ? (size_t)SR_NUM_PARAMS : 0)) return SR_E_PARAM_COUNT;
+    if (graph == SR_GRAPH_SR_NET && !params) return SR_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SR_E_NO_DEVICE;
     if (device < 0 || device >= ndev) return SR_E_INVALID;
     sr_ctx* c = new (std::nothrow) sr_ctx();
     if (!c) return SR_E_NOMEM;
     c->device = device;
+    c->graph = graph;
     int rc = [&]() -> int {
         HIPCHK(c, hipSetDevice(device));
         hipDeviceProp_t prop;
@@ -202,6 +211,7 @@ int sr_create(sr_ctx** out, const float* params, size_t n_params, int factor, in
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
 
+        if (graph != SR_GRAPH_SR_NET) return SR_OK;  // parameter-free graphs need nothing else
         // ---- pack every parameter once, in the layouts the kernels read
         std::vector<float> host, w;
         auto push = [&](const std::vector<float>& v) {
@@ -273,6 +283,8 @@ void sr_destroy(sr_ctx* c) {
 }
 
 int sr_last_hip_error(sr_ctx* c) { return c ? c->last_hip : 0; }
+
+int sr_num_params(int graph) { return graph == SR_GRAPH_SR_NET ? SR_NUM_PARAMS : (graph == SR_GRAPH_BILINEAR || graph == SR_GRAPH_DOWNSAMPLE ? 0 : -1); }
 
 int sr_set_precision(sr_ctx* c, int mode) {
     if (!c || (mode != SR_PRECISION_F32 && mode != SR_PRECISION_SPLIT_F16)) return SR_E_INVALID;
@@ -360,6 +372,16 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     if (!c || !d_img || !d_out) return SR_E_INVALID;
     if (n <= 0 || H <= 0 || W <= 0) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    if (c->graph != SR_GRAPH_SR_NET) {  // bilinear_net / downsample_net: one elementwise kernel
+        if (halo_top || halo_bot) return SR_E_INVALID;
+        if (c->graph == SR_GRAPH_DOWNSAMPLE && (H < 3 || W < 3)) return SR_E_INVALID;
+        if (img_u8 != out_u8) return SR_E_INVALID;
+        HIPCHK(c, hipSetDevice(c->device));
+        AuxArgs a{d_img, d_out, n, H, W, img_ch};
+        HIPCHK(c, sr_launch_aux(c->graph, a, img_u8, out_u8, s));
+        c->last_h = H; c->last_w = W;
+        return SR_OK;
+    }
     if ((halo_top != 0 && halo_top < SR_HALO) || (halo_bot != 0 && halo_bot < SR_HALO)) return SR_E_HALO;
     if (halo_top < 0 || halo_bot < 0 || halo_top + halo_bot >= H) return SR_E_INVALID;
     if ((halo_top || halo_bot) && n != 1) return SR_E_INVALID;
@@ -443,7 +465,8 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, i
     HIPCHK(c, hipSetDevice(c->device));
     const size_t npx = (size_t)n * h * w;
     const size_t in_bytes = npx * (img_u8 ? (size_t)img_ch : 3 * sizeof(float));
-    const size_t out_bytes = npx * 9 * (out_u8 ? 4 : 3 * sizeof(float));
+    const size_t out_px = c->graph == SR_GRAPH_DOWNSAMPLE ? (size_t)n * (h / 3) * (w / 3) : npx * 9;
+    const size_t out_bytes = out_px * (out_u8 ? 4 : 3 * sizeof(float));
     int rc = ensure_buf(c, &c->d_in, &c->in_cap, in_bytes);
     if (rc == SR_OK) rc = ensure_buf(c, &c->d_out, &c->out_cap, out_bytes);
     if (rc != SR_OK) return rc;

@@ -42,6 +42,13 @@ constexpr int kFeatPad = 2;          // 5x5 halo
 constexpr int kFeatPadBottom = 12;   // last tile row may start at H-1: + 8 rows + 2 halo (+2 spare)
 constexpr int kVoffEntries = 448;    // 7 groups of 64 tile pixels
 
+struct AuxArgs {          // bilinear_net / downsample_net (parameter-free graphs)
+    const void* img;      // n*H*W*3 f32 or n*H*W*img_ch u8
+    void* out;            // bilinear: n*3H*3W*(3 f32 | 4 u8); downsample: n*(H/3)*(W/3)*(3 f32 | 4 u8)
+    int n, H, W, img_ch;
+};
+hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, hipStream_t s);  // graph: 1 bilinear, 2 downsample
+
 // prec: 0 = exact f32 (v_mfma_f32_32x32x2_f32), 1 = split-half (3 x v_mfma_f32_32x32x16_f16)
 hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool img_u8, hipStream_t s);
 hipError_t sr_launch_stage(int stage, const StageArgs& a, int th, int prec, int nblk, bool img_u8, bool out_u8,

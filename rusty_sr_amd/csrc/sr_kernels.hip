@@ -692,6 +692,87 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
 }
 
 // ---------------------------------------------------------------------------
+// The two parameter-free graphs of the reference: bilinear_net (network.rs:111-123,
+// `-p bilinear`) and downsample_net (network.rs:125-138, `-d`).  Elementwise,
+// HBM-trivial: one thread per output pixel.
+// ---------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float srgb_to_linear(float s) {  // alumina SrgbToLinear: IEC 61966-2-1
+    return s <= 0.04045f ? s / 12.92f : powf((s + 0.055f) / 1.055f, 2.4f);
+}
+__device__ __forceinline__ float linear_to_srgb(float l) {  // alumina LinearToSrgb
+    return l <= 0.0031308f ? 12.92f * l : 1.055f * powf(l, 1.0f / 2.4f) - 0.055f;
+}
+__device__ __forceinline__ uint32_t quant_u8(float v) {  // data_to_img (main.rs:175)
+    return (uint32_t)fminf(fmaxf(floorf(255.0f * v + 0.5f), 0.0f), 255.0f);
+}
+}  // namespace
+
+template <bool IMG_U8, bool OUT_U8>
+__global__ __launch_bounds__(256) void bilinear_srgb_kernel(AuxArgs a) {
+    const size_t total = (size_t)a.n * a.H * 3 * a.W * 3;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int OW = a.W * 3, OH = a.H * 3;
+        const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), n = (int)(idx / ((size_t)OW * OH));
+        const int x = ox / 3, px = ox - 3 * x, y = oy / 3, py = oy - 3 * y;
+        // LinearInterp x3 (network.rs:118), same phase weights as the oracle's linterp3_acc
+        const float tx = px == 0 ? 2.0f / 3.0f : (px == 1 ? 0.0f : 1.0f / 3.0f);
+        const float ty = py == 0 ? 2.0f / 3.0f : (py == 1 ? 0.0f : 1.0f / 3.0f);
+        const int xa = min(max(x + (px == 0 ? -1 : 0), 0), a.W - 1), xb = min(max(x + (px == 0 ? 0 : 1), 0), a.W - 1);
+        const int ya = min(max(y + (py == 0 ? -1 : 0), 0), a.H - 1), yb = min(max(y + (py == 0 ? 0 : 1), 0), a.H - 1);
+        const size_t p0 = (size_t)n * a.H * a.W;
+        float o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v00 = srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)ya * a.W + xa, c));
+            const float v01 = srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)ya * a.W + xb, c));
+            const float v10 = srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)yb * a.W + xa, c));
+            const float v11 = srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)yb * a.W + xb, c));
+            const float ra = (1.0f - tx) * v00 + tx * v01, rb = (1.0f - tx) * v10 + tx * v11;
+            o[c] = linear_to_srgb((1.0f - ty) * ra + ty * rb);
+        }
+        if constexpr (OUT_U8) ((uint32_t*)a.out)[idx] = quant_u8(o[0]) | (quant_u8(o[1]) << 8) | (quant_u8(o[2]) << 16) | 0xff000000u;
+        else { float* d = (float*)a.out + idx * 3; d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; }
+    }
+}
+
+template <bool IMG_U8, bool OUT_U8>
+__global__ __launch_bounds__(256) void downsample_srgb_kernel(AuxArgs a) {
+    const int OH = a.H / 3, OW = a.W / 3;  // remainder rows / columns dropped (unpinned, see oracle)
+    const size_t total = (size_t)a.n * OH * OW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), n = (int)(idx / ((size_t)OW * OH));
+        const size_t p0 = (size_t)n * a.H * a.W;
+        float o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float acc = 0.f;
+            for (int dy = 0; dy < 3; ++dy)
+                for (int dx = 0; dx < 3; ++dx)
+                    acc += srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)(3 * oy + dy) * a.W + 3 * ox + dx, c));
+            o[c] = linear_to_srgb(acc / 9.0f);
+        }
+        if constexpr (OUT_U8) ((uint32_t*)a.out)[idx] = quant_u8(o[0]) | (quant_u8(o[1]) << 8) | (quant_u8(o[2]) << 16) | 0xff000000u;
+        else { float* d = (float*)a.out + idx * 3; d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; }
+    }
+}
+
+hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, hipStream_t s) {
+    const size_t total = graph == 1 ? (size_t)a.n * a.H * 3 * a.W * 3 : (size_t)a.n * (a.H / 3) * (a.W / 3);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    if (grid == 0) return hipSuccess;
+    if (img_u8 != out_u8) return hipErrorInvalidValue;
+    if (graph == 1) {
+        if (img_u8) hipLaunchKernelGGL((bilinear_srgb_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((bilinear_srgb_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (img_u8) hipLaunchKernelGGL((downsample_srgb_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((downsample_srgb_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // host-side launchers (called from sr_api.cpp through sr_kernels.h)
 // ---------------------------------------------------------------------------
 template <int TH, int KS0>

@@ -58,11 +58,15 @@ class Engine:
 
     PRECISIONS = {"f32": _lib.SR_PRECISION_F32, "split_f16": _lib.SR_PRECISION_SPLIT_F16}
 
-    def __init__(self, params, device: int = 0, factor: int = FACTOR, precision: str = "f32"):
+    GRAPHS = {"sr_net": _lib.SR_GRAPH_SR_NET, "bilinear": _lib.SR_GRAPH_BILINEAR, "downsample": _lib.SR_GRAPH_DOWNSAMPLE}
+
+    def __init__(self, params=(), device: int = 0, factor: int = FACTOR, precision: str = "f32", graph: str = "sr_net"):
         L = _lib.lib()
         p = np.ascontiguousarray(params, dtype=np.float32)
         self._ctx = C.c_void_p()
-        _lib.check(L.sr_create(C.byref(self._ctx), p.ctypes.data_as(C.POINTER(C.c_float)), p.size, factor, device))
+        self.graph = graph
+        _lib.check(L.sr_create_graph(C.byref(self._ctx), self.GRAPHS[graph],
+                                     p.ctypes.data_as(C.POINTER(C.c_float)) if p.size else None, p.size, factor, device))
         self.device = device
         self._L = L
         self.set_precision(precision)
@@ -71,6 +75,9 @@ class Engine:
         """"f32": exact-f32 MFMA (default).  "split_f16": hi/lo half pairs, 3 f16 MFMAs per product."""
         _lib.check(self._L.sr_set_precision(self._ctx, self.PRECISIONS[precision]))
         self.precision = precision
+
+    def _out_hw(self, h, w):
+        return (h // 3, w // 3) if self.graph == "downsample" else (3 * h, 3 * w)
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -89,7 +96,8 @@ class Engine:
         n, h, w, c = x.shape
         if c != 3:
             raise ValueError("expected 3 channels")
-        out = np.empty((n, 3 * h, 3 * w, 3), dtype=np.float32)
+        oh, ow = self._out_hw(h, w)
+        out = np.empty((n, oh, ow, 3), dtype=np.float32)
         fp = C.POINTER(C.c_float)
         _lib.check(self._L.sr_upscale_f32(self._ctx, x.ctypes.data_as(fp), n, h, w, out.ctypes.data_as(fp)), self._ctx)
         return out[0] if squeeze else out
@@ -101,7 +109,8 @@ class Engine:
         if squeeze:
             px = px[None]
         n, h, w, c = px.shape
-        out = np.empty((n, 3 * h, 3 * w, 4), dtype=np.uint8)
+        oh, ow = self._out_hw(h, w)
+        out = np.empty((n, oh, ow, 4), dtype=np.uint8)
         u8p = C.POINTER(C.c_uint8)
         _lib.check(self._L.sr_upscale_rgba8(self._ctx, px.ctypes.data_as(u8p), c, n, h, w, out.ctypes.data_as(u8p)), self._ctx)
         return out[0] if squeeze else out
@@ -118,7 +127,7 @@ class Engine:
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[-1] == 3
         n, h, w, _ = x.shape
         if out is None:
-            out = torch.empty((n, 3 * h, 3 * w, 3), dtype=torch.float32, device=x.device)
+            out = torch.empty((n,) + self._out_hw(h, w) + (3,), dtype=torch.float32, device=x.device)
         _lib.check(self._L.sr_upscale_f32_dev(self._ctx, C.c_void_p(x.data_ptr()), n, h, w,
                                               C.c_void_p(out.data_ptr()), self._stream_ptr(stream)), self._ctx)
         return out
@@ -128,7 +137,7 @@ class Engine:
         assert px.is_cuda and px.dtype == torch.uint8 and px.is_contiguous() and px.dim() == 4
         n, h, w, c = px.shape
         if out is None:
-            out = torch.empty((n, 3 * h, 3 * w, 4), dtype=torch.uint8, device=px.device)
+            out = torch.empty((n,) + self._out_hw(h, w) + (4,), dtype=torch.uint8, device=px.device)
         _lib.check(self._L.sr_upscale_rgba8_dev(self._ctx, C.c_void_p(px.data_ptr()), c, n, h, w,
                                                 C.c_void_p(out.data_ptr()), self._stream_ptr(stream)), self._ctx)
         return out
@@ -216,6 +225,16 @@ class Graph:
         x = np.asarray(inp.values, dtype=np.float32).reshape(n, h, w, CHANNELS)
         out = self._engine.upscale_f32(x)
         return [NodeData(DataShape(CHANNELS, [w * self.factor, h * self.factor], n), out.reshape(-1))]
+
+
+def bilinear_net(factor: int = FACTOR, device: int = 0) -> "Engine":
+    """reference network.rs:111 `pub fn bilinear_net(factor)` (`-p bilinear`): parameter-free."""
+    return Engine((), device, factor, graph="bilinear")
+
+
+def downsample_net(factor: int = FACTOR, device: int = 0) -> "Engine":
+    """reference network.rs:125 `pub fn downsample_net(factor)` (`-d`): parameter-free."""
+    return Engine((), device, factor, graph="downsample")
 
 
 def sr_net(factor: int = FACTOR, training=None, device: int = 0) -> Graph:

@@ -1,0 +1,162 @@
+// rusty_sr -- host CLI with the argv surface of millardjn/rusty_sr v1
+// (reference src/main.rs:33-178), driving the MI355X engine through libsrhip's C ABI.
+//
+//   rusty_sr <INPUT_FILE> <OUTPUT_FILE> [-p imagenet|imagenetlinear|anime|bilinear] [-c FILE] [-d]
+//
+// Differences from the reference, all outside the hot path: PNG only (own codec over
+// zlib; the reference's `image` crate also reads JPEG etc.), the `train` sub-command
+// is not part of this build, and three extra options that cannot collide with the
+// reference's (-p -c -d): --device N, --precision f32|split_f16, --timing.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/srhip.h"
+#include "png.hpp"
+
+// The three parameter sets the reference embeds with include_bytes! (main.rs:26-28)
+#define EMBED(sym, path)                                                                    \
+    asm(".section .rodata\n.global " #sym "_begin\n" #sym "_begin:\n.incbin \"" path "\"\n" \
+        ".global " #sym "_end\n" #sym "_end:\n.byte 0\n.previous\n");                      \
+    extern "C" const unsigned char sym##_begin[], sym##_end[];
+EMBED(imagenet_rsr, SR_RES_DIR "/imagenet.rsr")
+EMBED(imagenetlinear_rsr, SR_RES_DIR "/imagenetlinear.rsr")
+EMBED(anime_rsr, SR_RES_DIR "/anime.rsr")
+
+namespace {
+
+const char* kUsage =
+    "Rusty SR v0.1.1 (MI355X engine)\n"
+    "A convolutional neural network trained to upscale images\n\n"
+    "USAGE:\n    rusty_sr [FLAGS] [OPTIONS] <INPUT_FILE> <OUTPUT_FILE>\n    rusty_sr train ...   (not part of this build)\n\n"
+    "FLAGS:\n    -d, --downsample    Perform downscaling rather than upscaling\n    -h, --help          Prints help information\n"
+    "    -V, --version       Prints version information\n        --timing        Print device / transfer times on stderr\n\n"
+    "OPTIONS:\n    -c, --custom <PARAMETER_FILE>    Sets a custom parameter file (.rsr) to use with the neural net\n"
+    "    -p, --parameters <PARAMETERS>    Sets which built-in parameters to use with the neural net [values: imagenet,\n"
+    "                                     imagenetlinear, anime, bilinear]\n"
+    "        --device <N>                 HIP device index [default: 0]\n"
+    "        --precision <MODE>           f32 (exact) or split_f16 (2x faster, same 1e-4 parity bar) [default: f32]\n\n"
+    "ARGS:\n    <INPUT_FILE>     Sets the input image to upscale\n    <OUTPUT_FILE>    Sets the output file to write/overwrite (.png recommended)\n";
+
+[[noreturn]] void die(const std::string& msg, int code = 1) {
+    fprintf(stderr, "error: %s\n", msg.c_str());
+    exit(code);
+}
+[[noreturn]] void usage_error(const std::string& msg) {
+    fprintf(stderr, "error: %s\n\nUSAGE:\n    rusty_sr [FLAGS] [OPTIONS] <INPUT_FILE> <OUTPUT_FILE>\n\nFor more information try --help\n", msg.c_str());
+    exit(2);
+}
+
+std::vector<float> decode_rsr(const unsigned char* blob, size_t len) {
+    size_t n = 0;
+    if (sr_rsr_decode(blob, len, nullptr, 0, &n) != SR_OK) die("ByteVec conversion failed");  // main.rs:138
+    std::vector<float> p(n);
+    if (sr_rsr_decode(blob, len, p.data(), n, &n) != SR_OK) die("ByteVec conversion failed");
+    return p;
+}
+
+bool ends_with_png(const std::string& s) {
+    if (s.size() < 4) return false;
+    std::string e = s.substr(s.size() - 4);
+    for (auto& ch : e) ch = (char)tolower(ch);
+    return e == ".png";
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::vector<std::string> pos;
+    std::string parameters, custom, precision = "f32";
+    bool has_p = false, has_c = false, downsample = false, timing = false;
+    int device = 0;
+    if (argc >= 2 && !strcmp(argv[1], "train"))  // main.rs:119-121
+        die("the `train` sub-command is not part of this build (the MI355X engine covers the upscale path only)", 2);
+    for (int k = 1; k < argc; ++k) {
+        const std::string a = argv[k];
+        auto value = [&](const char* name) -> std::string {
+            if (k + 1 >= argc) usage_error(std::string("The argument '") + name + "' requires a value but none was supplied");
+            return argv[++k];
+        };
+        if (a == "-h" || a == "--help") { fputs(kUsage, stdout); return 0; }
+        else if (a == "-V" || a == "--version") { puts("Rusty SR v0.1.1"); return 0; }
+        else if (a == "-d" || a == "--downsample") downsample = true;
+        else if (a == "--timing") timing = true;
+        else if (a == "-p" || a == "--parameters") { parameters = value("--parameters <PARAMETERS>"); has_p = true; }
+        else if (a.rfind("--parameters=", 0) == 0) { parameters = a.substr(13); has_p = true; }
+        else if (a == "-c" || a == "--custom") { custom = value("--custom <PARAMETER_FILE>"); has_c = true; }
+        else if (a.rfind("--custom=", 0) == 0) { custom = a.substr(9); has_c = true; }
+        else if (a == "--device") device = atoi(value("--device <N>").c_str());
+        else if (a == "--precision") precision = value("--precision <MODE>");
+        else if (a.size() > 1 && a[0] == '-') usage_error("Found argument '" + a + "' which wasn't expected, or isn't valid in this context");
+        else pos.push_back(a);
+    }
+    // clap rules of the reference: possible_values (main.rs:54), conflicts (main.rs:58,66), required positionals
+    if (has_p && parameters != "imagenet" && parameters != "imagenetlinear" && parameters != "anime" && parameters != "bilinear")
+        usage_error("'" + parameters + "' isn't a valid value for '--parameters <PARAMETERS>'\n\t[values: anime, bilinear, imagenet, imagenetlinear]");
+    if (has_c && has_p) usage_error("The argument '--custom <PARAMETER_FILE>' cannot be used with '--parameters <PARAMETERS>'");
+    if (downsample && (has_p || has_c)) usage_error("The argument '--downsample' cannot be used with '--parameters <PARAMETERS>' or '--custom <PARAMETER_FILE>'");
+    if (pos.size() < 2) usage_error("The following required arguments were not provided:\n    <INPUT_FILE>\n    <OUTPUT_FILE>");
+    if (pos.size() > 2) usage_error("Found argument '" + pos[2] + "' which wasn't expected, or isn't valid in this context");
+    if (precision != "f32" && precision != "split_f16") usage_error("'" + precision + "' isn't a valid value for '--precision <MODE>'");
+
+    // ---- parameters + graph (main.rs:133-158), same progress text
+    std::vector<float> params;
+    int graph = SR_GRAPH_SR_NET;
+    if (has_c) {
+        FILE* f = fopen(custom.c_str(), "rb");
+        if (!f) die("Error opening parameter file");  // main.rs:134
+        std::vector<unsigned char> data;
+        unsigned char tmp[65536];
+        size_t n;
+        while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) data.insert(data.end(), tmp, tmp + n);
+        fclose(f);
+        printf("Upscaling using custom neural net parameters...");
+        params = decode_rsr(data.data(), data.size());
+    } else if (downsample) {
+        printf("Downsampling using average pooling of linear RGB values...");
+        graph = SR_GRAPH_DOWNSAMPLE;
+    } else if (!has_p || parameters == "imagenet") {
+        printf("Upscaling using imagenet neural net parameters...");
+        params = decode_rsr(imagenet_rsr_begin, imagenet_rsr_end - imagenet_rsr_begin);
+    } else if (parameters == "imagenetlinear") {
+        printf("Upscaling using linear loss imagenet neural net parameters...");
+        params = decode_rsr(imagenetlinear_rsr_begin, imagenetlinear_rsr_end - imagenetlinear_rsr_begin);
+    } else if (parameters == "anime") {
+        printf("Upscaling using anime neural net parameters...");
+        params = decode_rsr(anime_rsr_begin, anime_rsr_end - anime_rsr_begin);
+    } else {
+        printf("Upscaling using bilinear interpolation...");
+        graph = SR_GRAPH_BILINEAR;
+    }
+    fflush(stdout);
+
+    sr_ctx* ctx = nullptr;
+    int rc = sr_create_graph(&ctx, graph, params.empty() ? nullptr : params.data(), params.size(), SR_FACTOR, device);
+    if (rc != SR_OK) die(sr_strerror(rc));  // SR_E_PARAM_COUNT carries the text of main.rs:162
+    if (graph == SR_GRAPH_SR_NET) sr_set_precision(ctx, precision == "f32" ? SR_PRECISION_F32 : SR_PRECISION_SPLIT_F16);
+
+    srpng::Image in;
+    std::string err;
+    if (!srpng::decode_file(pos[0], in, err)) die("Error opening input image file. (" + err + ")");  // main.rs:164
+    if (!ends_with_png(pos[1])) die("Could not write output file (only .png output is supported by this build)");
+    if (graph == SR_GRAPH_DOWNSAMPLE && (in.w < 3 || in.h < 3)) die("input image is smaller than one 3x3 pooling block");
+
+    const int ow = graph == SR_GRAPH_DOWNSAMPLE ? in.w / 3 : in.w * 3, oh = graph == SR_GRAPH_DOWNSAMPLE ? in.h / 3 : in.h * 3;
+    std::vector<uint8_t> out((size_t)ow * oh * 4);
+    // img_to_data + graph.forward + data_to_img(..).to_rgba(), fused on the device (main.rs:168-175)
+    rc = sr_upscale_rgba8(ctx, in.rgba.data(), 4, 1, in.h, in.w, out.data());
+    if (rc != SR_OK) die(std::string(sr_strerror(rc)) + (rc == SR_E_HIP ? " (hipError " + std::to_string(sr_last_hip_error(ctx)) + ")" : ""));
+    if (timing) {
+        double tot = 0, h2d = 0, d2h = 0;
+        sr_last_timing(ctx, &tot, nullptr, &h2d, &d2h);
+        fprintf(stderr, "\n[timing] %dx%d -> %dx%d: kernels %.3f ms, h2d %.3f ms, d2h %.3f ms\n", in.w, in.h, ow, oh, tot, h2d, d2h);
+    }
+    printf(" Writing file...");
+    fflush(stdout);
+    if (!srpng::encode_file(pos[1], out.data(), ow, oh, err)) die("Could not write output file (" + err + ")");  // main.rs:175
+    puts(" Done");
+    sr_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,23 @@
+// png.hpp -- minimal PNG codec over zlib for the rusty_sr host CLI.
+// Stands in for the `image` crate calls of the reference (image::open main.rs:164,
+// DynamicImage::to_rgba().save main.rs:175).  Decodes non-interlaced and Adam7
+// PNGs of colour types 0/2/3/4/6 at 1..16 bits to RGBA8 (16-bit samples keep their
+// high byte; no gamma / colour management, like the reference); encodes RGBA8.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace srpng {
+struct Image { int w = 0, h = 0; std::vector<uint8_t> rgba; };
+bool decode_file(const std::string& path, Image& out, std::string& err);
+bool decode_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
+bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int zlevel = 3);
+}  // namespace srpng
+
+extern "C" {
+// C surface used by tests/test_host_png.py through ctypes
+int srpng_decode_rgba8(const char* path, int* w, int* h, uint8_t** rgba);  // caller frees with srpng_free
+int srpng_encode_rgba8(const char* path, const uint8_t* rgba, int w, int h);
+void srpng_free(uint8_t* p);
+}

@@ -70,6 +70,12 @@ def test_create_validates_before_touching_the_gpu(params):
     with pytest.raises(r.SrError) as e:
         r.Engine(p, factor=4)
     assert e.value.status == _lib.SR_E_FACTOR
+    with pytest.raises(r.SrError) as e:  # parameter-free graphs take exactly zero parameters
+        r.Engine(p, graph="bilinear")
+    assert e.value.status == _lib.SR_E_PARAM_COUNT
+    with pytest.raises(r.SrError) as e:
+        r.Engine((), graph="sr_net")
+    assert e.value.status == _lib.SR_E_PARAM_COUNT
     with pytest.raises(r.SrError):
         r.sr_net(4)
     with pytest.raises(NotImplementedError):

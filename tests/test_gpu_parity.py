@@ -211,3 +211,27 @@ def test_full_size_properties_1080p(engines, params):
     torch.cuda.synchronize()
     q = torch.clamp(torch.floor(255.0 * full + 0.5), 0, 255).to(torch.uint8)
     assert torch.equal(out8[..., :3], q) and bool((out8[..., 3] == 255).all())
+
+
+def test_bilinear_and_downsample_graphs(params):
+    """The two parameter-free graphs of upscale() (`-p bilinear`, `-d`; network.rs:111-138)."""
+    import rusty_sr_amd as r
+    from rusty_sr_amd import _lib
+    assert _lib.lib().sr_num_params(_lib.SR_GRAPH_BILINEAR) == 0 and _lib.lib().sr_num_params(_lib.SR_GRAPH_SR_NET) == oracle.NPARAMS
+    bl, ds = r.bilinear_net(r.FACTOR), r.downsample_net(r.FACTOR)
+    for h, w in ((1, 1), (5, 7), (43, 43), (130, 257)):
+        px = synth_u8(30 + h, 2, h, w)
+        x = oracle.img_to_data(px)
+        want = oracle.bilinear(x)
+        got = bl.upscale_f32(x)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-5
+        _check_u8(bl.upscale_rgba8(px), want)
+        if h >= 3 and w >= 3:
+            wd = oracle.downsample(x)
+            gd = ds.upscale_f32(x)
+            assert gd.shape == wd.shape == (2, h // 3, w // 3, 3) and np.abs(gd - wd).max() < 1e-5
+            _check_u8(ds.upscale_rgba8(px), wd)
+    with pytest.raises(r.SrError):
+        r.Engine(params["imagenet"], graph="bilinear")  # main.rs:162: 130459 != 0
+    with pytest.raises(r.SrError):
+        ds.upscale_f32(np.zeros((2, 2, 3), np.float32))

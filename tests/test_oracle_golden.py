@@ -107,3 +107,35 @@ def test_degenerate_sizes_and_properties(params):
     np.testing.assert_array_equal(yb[1], oracle.forward(p, xb[1])[0])
     with pytest.raises(ValueError):
         oracle.forward(p[:-1], x)
+
+
+def test_bilinear_net_pin_logo_lin():
+    """`-p bilinear` (network.rs:111-123): docs/logo_lin.png was made from the 43x43 logo by an
+    older alumina whose data_to_img truncated instead of rounding: with a
+    truncating quantiser the f64 evaluation reproduces it to >= 99 %, every f32 mismatch is a
+    flat-region knife-edge (255 v within 1e-3 of an integer), max |d| = 1.  Pins LinearInterp's
+    half-pixel alignment and the sRGB transfer curve."""
+    src = load_png("logo_nn.png")[1::3, 1::3]
+    gold = load_png("logo_lin.png")[..., :3].astype(int)
+    x = oracle.img_to_data(src)
+    for f64, floor_exact in ((True, 0.99), (False, 0.95)):
+        v = oracle.bilinear(x, f64=f64)[0].astype(np.float64)
+        d = np.clip(np.floor(255 * v), 0, 255).astype(int) - gold
+        assert np.abs(d).max() <= 1 and (d == 0).mean() >= floor_exact
+        frac = 255 * v
+        assert np.abs(frac - np.round(frac))[d != 0].max() < 1e-3
+    assert np.abs(oracle.bilinear(x)[0] - oracle.bilinear(x, f64=True)[0]).max() < 1e-6
+
+
+def test_downsample_net_properties():
+    """`-d` (network.rs:125-138) has no reference image: UNPINNED.  Size-independent properties:
+    a 3x nearest-neighbour upsample pools back to the original; flat images stay flat; the
+    remainder rows / columns are dropped."""
+    nn = load_png("logo_nn.png")
+    src = oracle.img_to_data(nn[1::3, 1::3])
+    np.testing.assert_allclose(oracle.downsample(oracle.img_to_data(nn))[0], src, atol=2e-7)
+    flat = np.full((1, 9, 12, 3), 0.3, np.float32)
+    np.testing.assert_allclose(oracle.downsample(flat), 0.3, atol=1e-6)
+    rng = np.random.default_rng(3)
+    x = rng.random((1, 11, 13, 3), dtype=np.float32)
+    np.testing.assert_array_equal(oracle.downsample(x), oracle.downsample(x[:, :9, :12]))
