@@ -63,6 +63,9 @@ __device__ long long* g_tl;
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef SR_SPLIT_WAVES
+#define SR_SPLIT_WAVES 4
+#endif
 constexpr int kTW = 32;            // tile width = one MFMA M-tile of pixels
 constexpr int kChunkFloats = 1024; // one tap: 32 cin x 32 cout
 constexpr int kRingSlots = 5;      // 4 KB weight chunks: one being read, up to four in flight
@@ -299,14 +302,14 @@ struct TileGeom {
 // table: ((P / TWH) * pitch + P % TWH) * 128) is the only per-lane operand; the
 // origin is wave-uniform.  The maps carry a zero border in HBM, so the
 // reference's zero padding (Padding::Same) needs no bounds test here.
-template <int TH, int KS>
+template <int TH, int KS, int NW = 4>
 __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, const uint32_t* __restrict__ voff,
                                            long img_stride, int pitch, int n, int y0, int x0, int wave, int lane) {
     using G = TileGeom<TH, KS>;
     const char* origin = (const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32);
 #pragma unroll
-    for (int gi = 0; gi < (G::NG + 3) / 4; ++gi) {
-        const int g = wave + 4 * gi;  // wave-uniform
+    for (int gi = 0; gi < (G::NG + NW - 1) / NW; ++gi) {
+        const int g = wave + NW * gi;  // wave-uniform
         if (g < G::NG) {
             const uint32_t vo = voff[g * 64 + lane];
 #pragma unroll
@@ -324,6 +327,7 @@ __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__
 // exactly the packed chunk order.
 __device__ __forceinline__ void weight_chunk_async(char* ring_slot, const float* __restrict__ chunk,
                                                    int wave, int lane) {
+    if (wave >= 4) return;  // 8-wave workgroups: waves 4-7 have nothing to move (their vmcnt waits pass at once)
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(chunk + (wave * 64 + lane) * 4),
         (__attribute__((address_space(3))) void*)(ring_slot + wave * 1024), 16, 0, 0);
@@ -449,7 +453,7 @@ __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T]
 // edge-REPLICATED coordinates (the interp clamps indices, it does not zero-pad),
 // the fixed weights (phase products {1/3, 2/3, 1}^2, built on the host) sit in the
 // weight pack behind the conv chunks: 9 x [cin/2][cout 32][2] floats.
-template <int TH, int T, bool IMG_U8>
+template <int TH, int T, bool IMG_U8, int NTHREADS>
 __device__ __forceinline__ void lin_taps(f32x16 (&acc)[T], char* tile, char* ring, const StageArgs& a,
                                          const float* __restrict__ wlin, int n, int y0, int x0, int wave,
                                          int lane, int tid) {
@@ -457,8 +461,8 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[T], char* tile, char* rin
     float* s_x = (float*)tile;   // [pixel][4]
     float* s_w = (float*)ring;   // 9 x 128 floats
     const size_t img_px0 = (size_t)n * a.H * a.W;
-    for (int k = tid; k < 9 * 128; k += kThreads) s_w[k] = wlin[k];
-    for (int p = tid; p < NPIX; p += kThreads) {
+    for (int k = tid; k < 9 * 128; k += NTHREADS) s_w[k] = wlin[k];
+    for (int p = tid; p < NPIX; p += NTHREADS) {
         const int py = p / TWH, px = p - py * TWH;
         const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
         const size_t gp = img_px0 + (size_t)gy * a.W + gx;
@@ -517,9 +521,9 @@ __device__ __forceinline__ int queue_resolve(int* queue, int xcd, int ntiles, in
 // next tile's DMA is requested before the current tile's epilogue.  Best for the
 // split-half mode, whose tiles last ~14 us: with one tile per workgroup 30 % of the
 // workgroup slots sat empty between a retire and the next dispatch.
-template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, bool PERSIST>
-__global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(StageArgs a) {
-    constexpr int T = TH / 4;
+template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, bool PERSIST, int NW>
+__global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv_stage_kernel(StageArgs a) {
+    constexpr int T = TH / NW;  // tile rows per wave
     using G0 = TileGeom<TH, KS0>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tile = smem;
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
         x0 = tx * kTW; y0 = a.y_begin + ty * TH;
 #pragma unroll
         for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
-        stage_tile<TH, KS0>(tile, a.src[0], KS0 == 5 ? a.voff5 : a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+        stage_tile<TH, KS0, NW>(tile, a.src[0], KS0 == 5 ? a.voff5 : a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
     };
 
     // Two workgroups share each SIMD.  A wave streaming MFMAs is the older one and
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
         TL(3);
         if constexpr (NSRC >= 2) {
             __builtin_amdgcn_s_setprio(3);
-            stage_tile<TH, 3>(tile, a.src[1], a.voff3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
+            stage_tile<TH, 3, NW>(tile, a.src[1], a.voff3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
             ring_barrier<0>();
             __builtin_amdgcn_s_setprio(0);
             TL(4);
@@ -599,14 +603,14 @@ __global__ __launch_bounds__(kThreads, TH == 8 ? 2 : 3) void conv_stage_kernel(S
         }
         if constexpr (NSRC >= 3) {
             __builtin_amdgcn_s_setprio(3);
-            stage_tile<TH, 3>(tile, a.src[2], a.voff3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
+            stage_tile<TH, 3, NW>(tile, a.src[2], a.voff3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
             ring_barrier<0>();
             __builtin_amdgcn_s_setprio(0);
             taps(std::integral_constant<int, 3>{});
         }
         __builtin_amdgcn_s_setprio(3);
         if constexpr (FINAL) {
-            lin_taps<TH, T, IMG_U8>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, tn, ty0, tx0, wave, lane, tid);
+            lin_taps<TH, T, IMG_U8, NW * 64>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, tn, ty0, tx0, wave, lane, tid);
             if constexpr (PERSIST) __syncthreads();  // everybody is done reading the image tile / lin weights
         }
         TL(6);
@@ -795,27 +799,30 @@ hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool 
 }
 
 template <typename K>
-static hipError_t launch_with_lds(K kern, const StageArgs& a, int nblk, size_t lds, hipStream_t s) {
+static hipError_t launch_with_lds(K kern, const StageArgs& a, int nblk, size_t lds, hipStream_t s, int nthreads = kThreads) {
     static bool configured = false;  // one instance per kernel template instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(kThreads), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthreads), lds, s, a);
     return hipGetLastError();
 }
 
 template <int TH, int PREC>
 static hipError_t launch_stage_t(int stage, const StageArgs& a, int nblk, bool img_u8, bool out_u8,
                                  hipStream_t s) {
+    // waves per workgroup.  8 (one tile row per wave, 4 waves per SIMD) was measured for the
+    // split-half mode: 5 % slower than 4 (B-operand reuse halves), so SR_SPLIT_WAVES stays 4.
+    constexpr int NWAVES = (PREC == 1 && TH == 8) ? SR_SPLIT_WAVES : 4;
     switch (stage) {
-        case 1: return launch_with_lds(conv_stage_kernel<TH, 1, 5, false, false, false, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 5>(), s);
-        case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 5>(), s);
-        case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 1: return launch_with_lds(conv_stage_kernel<TH, 1, 5, false, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 5>(), s, NWAVES * 64);
+        case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 5>(), s, NWAVES * 64);
+        case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 5>(), s, NWAVES * 64);
         case 4:
-            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 3>(), s);
-            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC, PREC == 1>, a, nblk, stage_lds_bytes<TH, 3>(), s);
+            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 3>(), s, NWAVES * 64);
+            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 3>(), s, NWAVES * 64);
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
