@@ -118,65 +118,62 @@ __device__ __forceinline__ float load_img(const void* img, int img_ch, bool u8, 
 }
 
 // ---- split-half ("f16x3") representation -----------------------------------
-// A value v is carried as two halves: hi = half(v) (flushed to 0 below the half
-// normal range, so nothing depends on the MFMA's denormal mode) and
-// lo = half((v - hi) * 2048).  v = hi + lo/2048 to ~2^-23 relative.  A product
-// v*w is then hi_v*hi_w + (hi_v*lo_w + lo_v*hi_w)/2048 (the lo*lo term is 2^-24):
-// three v_mfma_f32_32x32x16_f16 on the real matrix cores (16x the f32-MFMA rate
-// each) with f32 accumulation, instead of 8 f32 MFMAs on the vector ALU.
+// A value v is carried as two halves: hi = half(v) (round-toward-zero is as good as
+// any rounding here: lo absorbs the residual exactly) and lo = half((v - hi) * 2048).
+// v = hi + lo/2048 to ~2^-22 relative.  A product v*w is then
+// hi_v*hi_w + (hi_v*lo_w + lo_v*hi_w)/2048 (the lo*lo term is 2^-24): three
+// v_mfma_f32_32x32x16_f16 on the real matrix cores with f32 accumulation, instead
+// of 8 f32 MFMAs on the vector ALU.  Subnormal halves need no special care: the f16
+// MFMA does not flush them on gfx950 in the default kernel mode
+// (scripts/probe_f16_denorm.hip), and lo is pre-scaled out of that range anyway.
 constexpr float kLoScale = 2048.0f;
-__device__ __forceinline__ void split_half(float v, _Float16& hi, _Float16& lo) {
-    hi = __builtin_fabsf(v) < 6.103515625e-05f ? (_Float16)0.0f : (_Float16)v;
-    lo = (_Float16)((v - (float)hi) * kLoScale);
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));  // what v_cvt_pkrtz_f16_f32 returns
+
+// Split two f32 values: packed hi halves / packed lo halves (2 x v_cvt_pkrtz, 2 x v_cvt_f32_f16,
+// one packed subtract, one packed multiply).
+__device__ __forceinline__ void split_half2(f32x2 v, uint32_t& hi2, uint32_t& lo2) {
+    const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+    const f32x2 hf = {(float)h.x, (float)h.y};
+    const f32x2 r = (v - hf) * f32x2{kLoScale, kLoScale};
+    hi2 = __builtin_bit_cast(uint32_t, h);
+    lo2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r.x, r.y));
 }
 
 // BeLU(acc) of one 32x32 tile -> split-half NHWC rows.  A feature pixel is 128 B:
 // 32 hi halves then 32 lo halves.  Lane = channel j, register pair (r, r+1) = two
 // adjacent pixels: even lanes collect channels (j, j+1) of pixel `row` from their
-// odd neighbour, odd lanes channels (j-1, j) of pixel `row+1`, so every store is a
-// full dword and 16 even (odd) lanes write one contiguous 64-byte half line.
-// `base` already points at this lane's pixel (x0 + 4h + (j&1)) and channel pair.
-__device__ __forceinline__ void store_belu_tile_split(char* base, const f32x16& accm, const f32x16& accx,
-                                                      float bias, float beta, bool odd) {
+// odd neighbour, odd lanes channels (j-1, j) of pixel `row+1` (one DPP swap + one
+// v_perm_b32 each), so every store is a full dword and 16 even (odd) lanes write
+// one contiguous 64-byte half line.  `base` already points at this lane's pixel
+// (x0 + 4h + (j&1)) and channel pair; `limit` = image columns left of it.
+template <bool MASKED>
+__device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16& accm, const f32x16& accx,
+                                                        float bias, float beta, bool odd, int limit) {
+    // v_perm_b32(src0 = partner, src1 = mine): bytes 0-3 = mine, 4-7 = partner
+    const uint32_t sel = odd ? 0x03020706u   // (partner.hi16, mine.hi16)  = channels (j-1, j) of pixel row+1
+                             : 0x05040100u;  // (mine.lo16, partner.lo16)  = channels (j, j+1) of pixel row
+    const f32x2 bb = {bias, bias}, ks = {1.0f / kLoScale, 1.0f / kLoScale};
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        const float v0 = belu(accm[r] + accx[r] * (1.0f / kLoScale) + bias, beta);
-        const float v1 = belu(accm[r + 1] + accx[r + 1] * (1.0f / kLoScale) + bias, beta);
-        _Float16 h0, l0, h1, l1;
-        split_half(v0, h0, l0);
-        split_half(v1, h1, l1);
-        const uint32_t mh = __builtin_bit_cast(uint32_t, f16x2{h0, h1});
-        const uint32_t ml = __builtin_bit_cast(uint32_t, f16x2{l0, l1});
+        const f32x2 v = belu2(f32x2{accm[r], accm[r + 1]} + f32x2{accx[r], accx[r + 1]} * ks + bb, beta);
+        uint32_t mh, ml;
+        split_half2(v, mh, ml);
         const uint32_t ph = __shfl_xor(mh, 1), pl = __shfl_xor(ml, 1);
-        // even: (my r | partner r << 16)   odd: (partner r+1 | my r+1 << 16)
-        const uint32_t oh = odd ? ((ph >> 16) | (mh & 0xffff0000u)) : ((mh & 0xffffu) | (ph << 16));
-        const uint32_t ol = odd ? ((pl >> 16) | (ml & 0xffff0000u)) : ((ml & 0xffffu) | (pl << 16));
+        const uint32_t oh = __builtin_amdgcn_perm(ph, mh, sel), ol = __builtin_amdgcn_perm(pl, ml, sel);
         const int row = (r & 3) + 8 * (r >> 2);
-        *(uint32_t*)(base + row * 128) = oh;
-        *(uint32_t*)(base + row * 128 + 64) = ol;
-    }
-}
-
-__device__ __forceinline__ void store_belu_tile_split_masked(char* base, const f32x16& accm, const f32x16& accx,
-                                                             float bias, float beta, bool odd, int limit) {
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const float v0 = belu(accm[r] + accx[r] * (1.0f / kLoScale) + bias, beta);
-        const float v1 = belu(accm[r + 1] + accx[r + 1] * (1.0f / kLoScale) + bias, beta);
-        _Float16 h0, l0, h1, l1;
-        split_half(v0, h0, l0);
-        split_half(v1, h1, l1);
-        const uint32_t mh = __builtin_bit_cast(uint32_t, f16x2{h0, h1});
-        const uint32_t ml = __builtin_bit_cast(uint32_t, f16x2{l0, l1});
-        const uint32_t ph = __shfl_xor(mh, 1), pl = __shfl_xor(ml, 1);
-        const uint32_t oh = odd ? ((ph >> 16) | (mh & 0xffff0000u)) : ((mh & 0xffffu) | (ph << 16));
-        const uint32_t ol = odd ? ((pl >> 16) | (ml & 0xffff0000u)) : ((ml & 0xffffu) | (pl << 16));
-        const int row = (r & 3) + 8 * (r >> 2);
-        if (row < limit) {  // `limit` = image columns left of this lane's first pixel
+        if (!MASKED || row < limit) {
             *(uint32_t*)(base + row * 128) = oh;
             *(uint32_t*)(base + row * 128 + 64) = ol;
         }
     }
+}
+__device__ __forceinline__ void store_belu_tile_split(char* base, const f32x16& accm, const f32x16& accx,
+                                                      float bias, float beta, bool odd) {
+    store_belu_tile_split_t<false>(base, accm, accx, bias, beta, odd, 0);
+}
+__device__ __forceinline__ void store_belu_tile_split_masked(char* base, const f32x16& accm, const f32x16& accx,
+                                                             float bias, float beta, bool odd, int limit) {
+    store_belu_tile_split_t<true>(base, accm, accx, bias, beta, odd, limit);
 }
 
 // Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`

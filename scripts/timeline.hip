@@ -25,10 +25,11 @@ int main(int argc, char** argv) {
     a.voff5 = dvoff; a.voff3 = dvoff + kVoffEntries; a.pitch = pitch; a.img_stride = img_stride;
     a.img = f[0]; a.out = out; a.H = H; a.W = W; a.img_ch = 3; a.y_begin = 0; a.y_end = H;
     a.tiles_x = W / 32; a.tiles_y = (H + th - 1) / th;
-    const int nblk = a.tiles_x * a.tiles_y; a.n_img = 1; int* dq; hipMalloc(&dq, 64); hipMemset(dq, 0, 64); a.queue = dq;
+    int nblk = a.tiles_x * a.tiles_y; a.n_img = 1; int* dq; hipMalloc(&dq, 64); hipMemset(dq, 0, 64); a.queue = dq;
     long long* tl; hipMalloc(&tl, (size_t)nblk * 128);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
-    for (int rep = 0; rep < 3; ++rep) sr_launch_stage(stage, a, th, prec, nblk, false, false, 0);
+    if (prec == 1) nblk = 512;  // persistent form: co-resident workgroups pull tiles from the queue
+    for (int rep = 0; rep < 3; ++rep) { hipMemset(dq, 0, 64); sr_launch_stage(stage, a, th, prec, nblk, false, false, 0); }
     hipDeviceSynchronize();
     std::vector<long long> h((size_t)nblk * 16);
     hipMemcpy(h.data(), tl, (size_t)nblk * 128, hipMemcpyDeviceToHost);
@@ -44,6 +45,9 @@ int main(int argc, char** argv) {
     stat("stage tile src0", 1, 2); stat("taps src0", 2, 3);
     if (stage >= 2) { stat("stage tile src1", 3, 4); stat("taps src1", 4, 5); stat("src2 (stage+taps)", 5, 6); }
     stat("  last stage_tile: DMA issue", stage >= 2 ? 5 : 1, 8); if (stage == 1) stat("  last stage_tile: wait+barrier", 8, 2);
+    if (prec == 1) { auto st1 = [&](const char* nm, int k) { std::vector<long long> d; for (int b = 0; b < nblk; ++b) d.push_back(h[b * 16 + k]); std::sort(d.begin(), d.end());
+        double sm = 0; for (auto v : d) sm += v; printf("  tap7 %-22s mean %7.0f p10 %6lld p50 %6lld p90 %6lld\n", nm, sm / nblk, d[nblk / 10], d[nblk / 2], d[nblk * 9 / 10]); };
+      st1("DMA req + 12 ds_read issue", 11); st1("12 MFMA issue", 12); st1("wait + barrier", 13); }
     stat("epilogue", 6, 7); stat("whole workgroup", 1, 7);
     long long t0 = h[0]; for (int b = 0; b < nblk; ++b) t0 = std::min(t0, h[b * 16]);
     std::vector<long long> starts; for (int b = 0; b < nblk; ++b) starts.push_back(h[b * 16] - t0);
