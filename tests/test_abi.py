@@ -123,3 +123,17 @@ def test_product_never_touches_the_oracle():
                 text = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle", text, flags=re.M), f
                 assert "sr_oracle" not in text, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/srhip.h must bind from C (and therefore from Rust bindgen / cgo / ctypes):
+    compile a C99 translation unit that takes the address of every declared function."""
+    import subprocess
+    names = _header_functions()
+    src = "#include \"srhip.h\"\ntypedef void (*fn)(void);\nfn table[] = {" + ", ".join(f"(fn){n}" for n in names) + "};\nint main(void) { return sizeof(table) ? 0 : 1; }\n"
+    c = tmp_path / "abi.c"
+    c.write_text(src)
+    lib_dir = os.path.join(ROOT, "rusty_sr_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(c),
+                           "-L", lib_dir, "-lsrhip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib",
+                           "-o", str(tmp_path / "abi")])
