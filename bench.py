@@ -62,7 +62,7 @@ STAGE_KERNEL = {1: "conv_stage_kernel<8, 1, 5", 2: "conv_stage_kernel<8, 2, 5", 
                 4: "conv_stage_kernel<8, 3, 3", 0: "conv0_kernel<8"}
 
 
-def pmc_traffic(stage, H, W):
+def pmc_traffic(stage, H, W, precision="f32"):
     """HBM bytes per launch of the stage kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_latest.json = scripts/profile.sh of this same command; FETCH_SIZE x2
     gfx950 correction + WRITE_SIZE, collected in separate passes).  Only valid for the
@@ -72,7 +72,8 @@ def pmc_traffic(stage, H, W):
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         for name, v in d.items():
-            if STAGE_KERNEL[stage] in name and "hbm_read_bytes" in v:
+            tag = ", 0, false, 4>" if precision == "f32" else ", 1, true, 4>"
+            if STAGE_KERNEL[stage] in name and tag in name and "hbm_read_bytes" in v:
                 return {"hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v.get("hbm_write_bytes", 0)),
                         "algorithmic_bytes_per_launch": int(H * W * 128 * (min(stage, 3) + 1)),
                         "source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
@@ -220,7 +221,7 @@ def main():
                     f"against the f16 dense peak (issued rate {issued:.1f} TFLOP/s); the ceiling of this scheme is peak/3")
         result["roofline"] = {"bound": "mfma", "kernel": f"conv_stage_kernel stage {k}", "achieved": round(ach, 2),
                               "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                              "traffic": pmc_traffic(k, H, W) if args.precision == "f32" else None,
+                              "traffic": pmc_traffic(k, H, W, args.precision),
                               "avg_launch_ms": round(float(stage_ms[k]), 4), "note": note}
         result["stages"] = [{"stage": s, "ms": round(float(stage_ms[s]), 4),
                              "tflops": round(2 * MAC_PER_PX[s] * rows[s] * W / (stage_ms[s] / 1e3) / 1e12, 2)}
