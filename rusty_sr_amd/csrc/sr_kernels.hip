@@ -129,6 +129,13 @@ __device__ __forceinline__ float load_img(const void* img, int img_ch, bool u8, 
 constexpr float kLoScale = 2048.0f;
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));  // what v_cvt_pkrtz_f16_f32 returns
 
+// Exchange a dword with the neighbouring lane (lane ^ 1): one v_mov_b32_dpp quad_perm:[1,0,3,2]
+// -- pure VALU.  (__shfl_xor lowers to ds_bpermute_b32: an LDS-crossbar op whose lgkmcnt wait
+// also stalls on every operand ds_read in flight.)
+__device__ __forceinline__ uint32_t swap_lane_pair(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
 // Split two f32 values: packed hi halves / packed lo halves (2 x v_cvt_pkrtz, 2 x v_cvt_f32_f16,
 // one packed subtract, one packed multiply).
 __device__ __forceinline__ void split_half2(f32x2 v, uint32_t& hi2, uint32_t& lo2) {
@@ -158,7 +165,7 @@ __device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16
         const f32x2 v = belu2(f32x2{accm[r], accm[r + 1]} + f32x2{accx[r], accx[r + 1]} * ks + bb, beta);
         uint32_t mh, ml;
         split_half2(v, mh, ml);
-        const uint32_t ph = __shfl_xor(mh, 1), pl = __shfl_xor(ml, 1);
+        const uint32_t ph = swap_lane_pair(mh), pl = swap_lane_pair(ml);
         const uint32_t oh = __builtin_amdgcn_perm(ph, mh, sel), ol = __builtin_amdgcn_perm(pl, ml, sel);
         const int row = (r & 3) + 8 * (r >> 2);
         if (!MASKED || row < limit) {
@@ -405,10 +412,12 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, ch
 // cin groups 0-7 / 8-15 / 16-23 / 24-31, planes 4-7 the lo halves; a weight chunk
 // is [hi: 4 x 32 cout x 8 halves][lo: same].  Per tap and tile row: 2 K-steps of
 // 16 cin x 3 products = 6 v_mfma_f32_32x32x16_f16 (192 cycles vs 1024 for f32).
-// (A hand software-pipelined form -- all operand reads of tap t+1 in flight under
-// tap t's MFMAs, two register sets -- measured no faster and spilled; hipcc
-// re-orders the stream anyway.  Getting past ~45 % MFMA utilisation here needs an
-// assembly-level schedule: next round.)
+// Measured and rejected on MI355X (all within +-2 % of this form): operand reads of tap
+// t+1 issued by hand (inline asm) under tap t's MFMAs; no per-tap barrier; 8-wave
+// workgroups; the finished tile's epilogue deferred into the next tile's first taps.
+// The f16 matrix core is POWER-limited on real data (scripts/ubench_f16.hip: 2305 TF
+// issued with constant operands, 1596 TF with random ones; this kernel runs the
+// chip at ~2.07 GHz and ~930 TF issued), so cycles saved come back as lower clock.
 template <int TH, int KS, int T>
 __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T], const char* tile, char* ring,
                                             const float* __restrict__ wpack, int& gtap, int& slot,
