@@ -148,6 +148,8 @@ class Engine:
         assert x_ext.is_cuda and x_ext.dtype == torch.float32 and x_ext.is_contiguous() and x_ext.dim() == 3
         h_ext, w, _ = x_ext.shape
         hb = h_ext - halo_top - halo_bot
+        if hb <= 0 or halo_top < 0 or halo_bot < 0:
+            raise _lib.SrError(_lib.SR_E_INVALID)
         if out is None:
             out = torch.empty((3 * hb, 3 * w, 3), dtype=torch.float32, device=x_ext.device)
         _lib.check(self._L.sr_upscale_band_f32_dev(self._ctx, C.c_void_p(x_ext.data_ptr()), h_ext, w, halo_top,
@@ -160,6 +162,8 @@ class Engine:
         assert px_ext.is_cuda and px_ext.dtype == torch.uint8 and px_ext.is_contiguous() and px_ext.dim() == 3
         h_ext, w, c = px_ext.shape
         hb = h_ext - halo_top - halo_bot
+        if hb <= 0 or halo_top < 0 or halo_bot < 0:
+            raise _lib.SrError(_lib.SR_E_INVALID)
         if out is None:
             out = torch.empty((3 * hb, 3 * w, 4), dtype=torch.uint8, device=px_ext.device)
         _lib.check(self._L.sr_upscale_band_rgba8_dev(self._ctx, C.c_void_p(px_ext.data_ptr()), c, h_ext, w,

@@ -235,3 +235,44 @@ def test_bilinear_and_downsample_graphs(params):
         r.Engine(params["imagenet"], graph="bilinear")  # main.rs:162: 130459 != 0
     with pytest.raises(r.SrError):
         ds.upscale_f32(np.zeros((2, 2, 3), np.float32))
+
+
+def test_geometry_changes_keep_borders_clean(engines, params):
+    """The feature maps carry their zero padding as a border in HBM that is only re-zeroed
+    when (n, H, W) changes: interleave big / small / ragged / batched calls on ONE engine and
+    require every result to equal a fresh engine's (stale data in a border would show up at
+    the image edges)."""
+    import rusty_sr_amd as r
+    eng = engines["imagenet"]
+    fresh = r.Engine(params["imagenet"], device=0, precision=eng.precision)
+    shapes = [(1, 70, 130), (1, 9, 40), (2, 33, 65), (1, 70, 130), (1, 8, 32), (3, 5, 7), (1, 64, 96), (1, 9, 40)]
+    for k, (n, h, w) in enumerate(shapes):
+        x = oracle.img_to_data(synth_u8(50 + k, n, h, w))
+        got = eng.upscale_f32(x)
+        fresh.close()
+        fresh = r.Engine(params["imagenet"], device=0, precision=eng.precision)
+        np.testing.assert_array_equal(got, fresh.upscale_f32(x), err_msg=str((n, h, w)))
+    fresh.close()
+
+
+def test_random_shapes_sweep(engines, params):
+    """Ragged sizes around every tile boundary (8x32 / 4x32 tiles, 36- and 34-wide halo tiles)."""
+    rng = np.random.default_rng(99)
+    for _ in range(12):
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 140))
+        x = oracle.img_to_data(synth_u8(int(rng.integers(1 << 30)), 1, h, w))
+        want = oracle.forward(params["anime"], x)
+        got = engines["anime"].upscale_f32(x)
+        assert np.abs(got - want).max() < TIGHT, (h, w)
+
+
+def test_band_argument_validation(engines):
+    import torch
+    import rusty_sr_amd as r
+    eng = engines["imagenet"]
+    x = torch.zeros((30, 40, 3), dtype=torch.float32, device="cuda")
+    for top, bot in ((3, 0), (0, 6), (16, 16), (-1, 0)):
+        with pytest.raises(r.SrError):
+            eng.upscale_band_f32_dev(x, top, bot)
+    out = eng.upscale_band_f32_dev(x, 7, 7)
+    assert out.shape == (48, 120, 3)
