@@ -19,8 +19,8 @@
  *
  * Tensor layout everywhere: NHWC, channel fastest -- alumina's
  * DataShape::new(channels, &[W, H], n) order (reference main.rs:168).
- * The up-scaling factor is 3 (reference main.rs:31 `const FACTOR: usize = 3`;
- * the bundled weights only fit factor 3, network.rs:37).
+ * The up-scaling factor of the reference binary is 3 (main.rs:31 `const FACTOR: usize = 3`;
+ * the bundled weights only fit factor 3, network.rs:37); the engine also takes 2 and 4.
  */
 #ifndef SRHIP_H
 #define SRHIP_H
@@ -34,6 +34,7 @@ extern "C" {
 
 #define SR_FACTOR 3
 #define SR_NUM_PARAMS 130459 /* graph.num_params() of sr_net(3, None); main.rs:162 */
+/* sr_net(f, None) has 2400 + 64 + 3f^2 + 192 + 3*25600 + 3*9216 + 3*(3f^2*288) parameters */
 #define SR_HALO 7            /* receptive-field radius of the conv stack in input px */
 
 typedef struct sr_ctx sr_ctx;
@@ -42,7 +43,7 @@ enum sr_status {
     SR_OK = 0,
     SR_E_INVALID = -1,     /* NULL pointer / non-positive dimension / bad channel count */
     SR_E_PARAM_COUNT = -2, /* main.rs:162 assert_eq!(params.len(), graph.num_params()) */
-    SR_E_FACTOR = -3,      /* only factor 3 exists in the reference (main.rs:31) */
+    SR_E_FACTOR = -3,      /* sr_net: factor must be 2, 3 or 4 (the reference ships 3, main.rs:31) */
     SR_E_NO_DEVICE = -4,   /* no gfx950 device visible: the engine has NO CPU fallback */
     SR_E_HIP = -5,         /* a HIP runtime call failed; sr_last_hip_error() has the code */
     SR_E_NOMEM = -6,
@@ -80,7 +81,15 @@ void sr_destroy(sr_ctx* ctx);
  * entry points exist for SR_GRAPH_SR_NET only. */
 enum sr_graph { SR_GRAPH_SR_NET = 0, SR_GRAPH_BILINEAR = 1, SR_GRAPH_DOWNSAMPLE = 2 };
 int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_params, int factor, int device);
-int sr_num_params(int graph); /* graph.num_params(); -1 for an unknown graph */
+int sr_num_params(int graph); /* graph.num_params() at factor 3; -1 for an unknown graph */
+
+/* `sr_net(factor, ..)` takes the factor as an argument (network.rs:16) although main.rs:31
+ * hard-wires 3 ("TODO: expose upscaling factor as argument"): sr_create / sr_create_graph accept
+ * factor 2, 3 or 4 for SR_GRAPH_SR_NET given a parameter vector of sr_num_params_factor(factor)
+ * entries in the same op order (the expand node has 3 f^2 channels, network.rs:37), and every
+ * entry point then produces f*h x f*w outputs.  No 2x / 4x weights ship with the reference, so
+ * those factors are checked against the CPU restatement only (UNPINNED). */
+int sr_num_params_factor(int factor); /* -1 unless 2 <= factor <= 4 */
 
 /* Replaces: graph.forward(n, vec![input], &params) (reference main.rs:171).
  * in : n*h*w*3 f32 in [0,1] (what img_to_data produced), host memory.

@@ -6,5 +6,5 @@ enforces it).  See sr_oracle.c for what is restated and how it is pinned.
 """
 from .oracle import (  # noqa: F401
     NPARAMS, SEGMENTS, build, lib, rsr_decode, forward, forward_taps, img_to_data,
-    data_to_rgba8, upscale_rgba8, bilinear, downsample,
+    data_to_rgba8, upscale_rgba8, bilinear, downsample, forward_factor, num_params,
 )

@@ -82,6 +82,11 @@ def _bind(L):
         f = getattr(L, "sr_oracle_forward" + suf)
         f.restype = c.c_int
         f.argtypes = [fp, c.c_size_t, rp, c.c_int, c.c_int, c.c_int, rp, rp]
+        ff = getattr(L, "sr_oracle_forward_factor" + suf)
+        ff.restype = c.c_int
+        ff.argtypes = [fp, c.c_size_t, c.c_int, rp, c.c_int, c.c_int, c.c_int, rp]
+        getattr(L, "sr_oracle_num_params_factor" + suf).restype = c.c_int
+        getattr(L, "sr_oracle_num_params_factor" + suf).argtypes = [c.c_int]
         for nm in ("sr_oracle_bilinear", "sr_oracle_downsample"):
             q = getattr(L, nm + suf)
             q.restype = c.c_int
@@ -142,6 +147,27 @@ def forward(params, x, f64=False, native=False):
     """graph.forward (reference main.rs:171): x (n,H,W,3) or (H,W,3) in [0,1] ->
     (n,3H,3W,3) pre-quantisation."""
     return _forward(params, x, f64, False, native)
+
+
+def num_params(factor=3):
+    return lib().sr_oracle_num_params_factor(factor)
+
+
+def forward_factor(params, x, factor, f64=False):
+    """sr_net(factor, None) for factor 1..4 (UNPINNED for factor != 3; see sr_oracle.c)."""
+    L = lib()
+    dt, ct, suf = (np.float64, ctypes.c_double, "_f64") if f64 else (np.float32, ctypes.c_float, "")
+    params = np.ascontiguousarray(params, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=dt)
+    if x.ndim == 3:
+        x = x[None]
+    n, H, W, _ = x.shape
+    out = np.empty((n, factor * H, factor * W, 3), dtype=dt)
+    rc = getattr(L, "sr_oracle_forward_factor" + suf)(_ptr(params, ctypes.c_float), params.size, factor, _ptr(x, ct),
+                                                      n, H, W, _ptr(out, ct))
+    if rc != 0:
+        raise ValueError(f"forward_factor failed ({rc})")
+    return out
 
 
 def forward_taps(params, x, f64=False):

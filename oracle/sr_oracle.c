@@ -46,6 +46,7 @@ typedef float real;
 #define SR_FACTOR 3      /* reference src/main.rs:31  const FACTOR: usize = 3 */
 #define SR_CH 3          /* reference src/network.rs:13 const CHANNELS: usize = 3 */
 #define SR_FEAT 32       /* reference src/network.rs:29,41 Node::new_shaped(32, ..) */
+#define SR_MAXC 64       /* widest conv output handled: 3*f*f = 48 expand channels at factor 4 */
 #define SR_EXP (SR_CH * SR_FACTOR * SR_FACTOR) /* network.rs:37 expand node = 27 ch */
 #define SR_NPARAMS 130459
 
@@ -107,16 +108,17 @@ static void conv_same_acc(const real* src, int H, int W, int Cin, const float* w
     const int r = k / 2;
     /* transpose weights to [ky][kx][i][o], o padded to 32 with zeros, so the
      * inner loop is a fixed-width vector op over o (padding lanes are discarded) */
-    real* wT = (real*)calloc((size_t)k * k * Cin * SR_FEAT, sizeof(real));
+    const int CW = Cout <= SR_FEAT ? SR_FEAT : SR_MAXC;  /* padded output width of the inner vector loop */
+    real* wT = (real*)calloc((size_t)k * k * Cin * CW, sizeof(real));
     for (int o = 0; o < Cout; ++o)
         for (int t = 0; t < k * k; ++t)
             for (int i = 0; i < Cin; ++i)
-                wT[((size_t)t * Cin + i) * SR_FEAT + o] = (real)wt[((size_t)o * k * k + t) * Cin + i];
+                wT[((size_t)t * Cin + i) * CW + o] = (real)wt[((size_t)o * k * k + t) * Cin + i];
 #pragma omp parallel for schedule(dynamic, 1)
     for (int y = 0; y < H; ++y) {
         for (int x = 0; x < W; ++x) {
-            real acc[SR_FEAT];
-            for (int o = 0; o < SR_FEAT; ++o) acc[o] = 0;
+            real acc[SR_MAXC];
+            for (int o = 0; o < CW; ++o) acc[o] = 0;
             for (int ky = 0; ky < k; ++ky) {
                 const int sy = y + ky - r;
                 if (sy < 0 || sy >= H) continue; /* zero padding */
@@ -124,11 +126,19 @@ static void conv_same_acc(const real* src, int H, int W, int Cin, const float* w
                     const int sx = x + kx - r;
                     if (sx < 0 || sx >= W) continue;
                     const real* s = src + ((size_t)sy * W + sx) * Cin;
-                    const real* w = wT + (size_t)(ky * k + kx) * Cin * SR_FEAT;
-                    for (int i = 0; i < Cin; ++i) {
-                        const real sv = s[i];
+                    const real* w = wT + (size_t)(ky * k + kx) * Cin * CW;
+                    if (CW == SR_FEAT) {
+                        for (int i = 0; i < Cin; ++i) {
+                            const real sv = s[i];
 #pragma omp simd
-                        for (int o = 0; o < SR_FEAT; ++o) acc[o] += w[(size_t)i * SR_FEAT + o] * sv;
+                            for (int o = 0; o < SR_FEAT; ++o) acc[o] += w[(size_t)i * SR_FEAT + o] * sv;
+                        }
+                    } else {
+                        for (int i = 0; i < Cin; ++i) {
+                            const real sv = s[i];
+#pragma omp simd
+                            for (int o = 0; o < SR_MAXC; ++o) acc[o] += w[(size_t)i * SR_MAXC + o] * sv;
+                        }
                     }
                 }
             }
@@ -279,6 +289,100 @@ int SYM(sr_oracle_forward)(const float* params, size_t n_params, const real* in,
             memcpy(taps + 3 * npx * SR_FEAT, l3, sizeof(real) * npx * SR_FEAT);
             memcpy(taps + 4 * npx * SR_FEAT, e, sizeof(real) * npx * SR_EXP);
         }
+    }
+    return 0;
+}
+
+/* ---- sr_net(factor, None) for factor != 3 (reference network.rs:16: `factor` is a parameter of
+ * the graph builder; main.rs:31 hard-wires 3 "TODO: expose upscaling factor as argument", and no
+ * weights for another factor ship).  UNPINNED for factor != 3: same op semantics with
+ *   expand node = 3 f^2 channels (network.rs:37), channel = (dy*f+dx)*3+c (network.rs:39),
+ *   LinearInterp x f with half-pixel centres: s = (o+0.5)/f - 0.5,
+ * parameter order as in network.rs:33-72 with the f-dependent segment sizes.  At factor 3 it is
+ * bit-identical to sr_oracle_forward (tested). */
+static size_t nparams_for_factor(int f) {
+    const size_t E = (size_t)SR_CH * f * f;
+    return 2400 + 32 + 32 + E + 3 * 32 + 3 * 32 + 3 * 25600 + 2 * 9216 + E * 288 + 9216 + 2 * E * 288;
+}
+int SYM(sr_oracle_num_params_factor)(int f) { return f >= 1 && f <= 4 ? (int)nparams_for_factor(f) : -1; }
+
+static void linterp_f_acc(const real* in, int H, int W, int f, real* out) {
+    const int OW = W * f;
+#pragma omp parallel for schedule(static)
+    for (int oy = 0; oy < H * f; ++oy) {
+        const int y = oy / f, py = oy % f, ny = 2 * py + 1 - f; /* (s - y) = ny / (2f) */
+        const int ya = clampi(y + (ny < 0 ? -1 : 0), 0, H - 1), yb = clampi(y + (ny < 0 ? 0 : 1), 0, H - 1);
+        const real ty = (real)(ny < 0 ? ny + 2 * f : ny) / (real)(2 * f);
+        for (int ox = 0; ox < OW; ++ox) {
+            const int x = ox / f, px = ox % f, nx = 2 * px + 1 - f;
+            const int xa = clampi(x + (nx < 0 ? -1 : 0), 0, W - 1), xb = clampi(x + (nx < 0 ? 0 : 1), 0, W - 1);
+            const real tx = (real)(nx < 0 ? nx + 2 * f : nx) / (real)(2 * f);
+            for (int c = 0; c < SR_CH; ++c) {
+                const real a = ((real)1 - tx) * in[((size_t)ya * W + xa) * SR_CH + c] + tx * in[((size_t)ya * W + xb) * SR_CH + c];
+                const real b = ((real)1 - tx) * in[((size_t)yb * W + xa) * SR_CH + c] + tx * in[((size_t)yb * W + xb) * SR_CH + c];
+                out[((size_t)oy * OW + ox) * SR_CH + c] += ((real)1 - ty) * a + ty * b;
+            }
+        }
+    }
+}
+
+int SYM(sr_oracle_forward_factor)(const float* params, size_t n_params, int f, const real* in, int n, int H, int W,
+                                  real* out) {
+    if (f < 1 || f > 4) return -4;
+    if (n_params != nparams_for_factor(f)) return -1;
+    if (n < 0 || H <= 0 || W <= 0) return -2;
+    const int E = SR_CH * f * f;
+    const size_t npx = (size_t)H * W;
+    size_t o = 0;
+    const float* conv0 = params + o; o += 2400;
+    const float* f_bias = params + o; o += 32;
+    const float* f_act = params + o; o += 32;
+    const float* e_bias = params + o; o += E;
+    const float* lb[3]; for (int k = 0; k < 3; ++k) { lb[k] = params + o; o += 32; }
+    const float* la[3]; for (int k = 0; k < 3; ++k) { la[k] = params + o; o += 32; }
+    const float* c1 = params + o; o += 25600;
+    const float* c2 = params + o; o += 25600;
+    const float* c3 = params + o; o += 25600;
+    const float* c5 = params + o; o += 9216;
+    const float* c6 = params + o; o += 9216;
+    const float* c7 = params + o; o += (size_t)E * 288;
+    const float* c8 = params + o; o += 9216;
+    const float* c9 = params + o; o += (size_t)E * 288;
+    const float* c10 = params + o; o += (size_t)E * 288;
+    real* fc = zalloc_slot(0, npx * SR_FEAT); real* ff = zalloc_slot(1, npx * SR_FEAT);
+    real* l1c = zalloc_slot(2, npx * SR_FEAT); real* l1 = zalloc_slot(3, npx * SR_FEAT);
+    real* l2c = zalloc_slot(4, npx * SR_FEAT); real* l2 = zalloc_slot(5, npx * SR_FEAT);
+    real* l3c = zalloc_slot(6, npx * SR_FEAT); real* l3 = zalloc_slot(7, npx * SR_FEAT);
+    real* e = zalloc_slot(8, npx * (size_t)E);
+    if (!fc || !ff || !l1c || !l1 || !l2c || !l2 || !l3c || !l3 || !e) return -3;
+    for (int b = 0; b < n; ++b) {
+        const real* x = in + (size_t)b * npx * SR_CH;
+        real* op = out + (size_t)b * npx * SR_CH * f * f;
+        memset(op, 0, sizeof(real) * npx * SR_CH * f * f);
+        if (b) {
+            memset(fc, 0, sizeof(real) * npx * SR_FEAT); memset(l1c, 0, sizeof(real) * npx * SR_FEAT);
+            memset(l2c, 0, sizeof(real) * npx * SR_FEAT); memset(l3c, 0, sizeof(real) * npx * SR_FEAT);
+            memset(e, 0, sizeof(real) * npx * (size_t)E);
+        }
+        linterp_f_acc(x, H, W, f, op);
+        conv_same_acc(x, H, W, SR_CH, conv0, 5, SR_FEAT, fc); bias_add(fc, npx, SR_FEAT, f_bias); belu(fc, ff, npx, SR_FEAT, f_act);
+        conv_same_acc(ff, H, W, SR_FEAT, c1, 5, SR_FEAT, l1c); bias_add(l1c, npx, SR_FEAT, lb[0]); belu(l1c, l1, npx, SR_FEAT, la[0]);
+        conv_same_acc(ff, H, W, SR_FEAT, c2, 5, SR_FEAT, l2c); conv_same_acc(l1, H, W, SR_FEAT, c5, 3, SR_FEAT, l2c);
+        bias_add(l2c, npx, SR_FEAT, lb[1]); belu(l2c, l2, npx, SR_FEAT, la[1]);
+        conv_same_acc(ff, H, W, SR_FEAT, c3, 5, SR_FEAT, l3c); conv_same_acc(l1, H, W, SR_FEAT, c6, 3, SR_FEAT, l3c);
+        conv_same_acc(l2, H, W, SR_FEAT, c8, 3, SR_FEAT, l3c);
+        bias_add(l3c, npx, SR_FEAT, lb[2]); belu(l3c, l3, npx, SR_FEAT, la[2]);
+        conv_same_acc(l1, H, W, SR_FEAT, c7, 3, E, e); conv_same_acc(l2, H, W, SR_FEAT, c9, 3, E, e);
+        conv_same_acc(l3, H, W, SR_FEAT, c10, 3, E, e);
+        bias_add(e, npx, E, e_bias);
+        const int OW = W * f;
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; ++y)
+            for (int xx = 0; xx < W; ++xx)
+                for (int dy = 0; dy < f; ++dy)
+                    for (int dx = 0; dx < f; ++dx)
+                        for (int c = 0; c < SR_CH; ++c)
+                            op[((size_t)(f * y + dy) * OW + f * xx + dx) * SR_CH + c] += e[((size_t)y * W + xx) * E + (dy * f + dx) * 3 + c];
     }
     return 0;
 }

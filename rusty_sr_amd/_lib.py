@@ -24,6 +24,7 @@ SYMBOLS = {
     "sr_create": (_i, [C.POINTER(_vp), _fp, _sz, _i, _i]),
     "sr_create_graph": (_i, [C.POINTER(_vp), _i, _fp, _sz, _i, _i]),
     "sr_num_params": (_i, [_i]),
+    "sr_num_params_factor": (_i, [_i]),
     "sr_destroy": (None, [_vp]),
     "sr_upscale_f32": (_i, [_vp, _fp, _i, _i, _i, _fp]),
     "sr_upscale_rgba8": (_i, [_vp, _u8p, _i, _i, _i, _i, _u8p]),

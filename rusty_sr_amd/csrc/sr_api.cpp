@@ -16,16 +16,33 @@
 namespace {
 
 // Parameter segment offsets: op insertion order of reference src/network.rs:33-72
-// (SURVEY.md 8(a) row W).
-enum : size_t {
-    OFF_CONV0 = 0, OFF_F_BIAS = 2400, OFF_F_ACTIV = 2432, OFF_EXP_BIAS = 2464,
-    OFF_L1_BIAS = 2491, OFF_L2_BIAS = 2523, OFF_L3_BIAS = 2555,
-    OFF_L1_ACTIV = 2587, OFF_L2_ACTIV = 2619, OFF_L3_ACTIV = 2651,
-    OFF_CONV1 = 2683, OFF_CONV2 = 28283, OFF_CONV3 = 53883,
-    OFF_CONV5 = 79483, OFF_CONV6 = 88699, OFF_CONV7 = 97915,
-    OFF_CONV8 = 105691, OFF_CONV9 = 114907, OFF_CONV10 = 122683, OFF_END = 130459
+// (SURVEY.md 8(a) row W).  Only the expand node depends on the factor f: 3 f^2 channels
+// (network.rs:37), so expand_bias and conv7 / conv9 / conv10 scale with it.
+struct ParamLayout {
+    size_t conv0, f_bias, f_activ, exp_bias, l_bias[3], l_activ[3], conv1, conv2, conv3, conv5, conv6, conv7, conv8,
+        conv9, conv10, end;
+    int E;  // expand channels
+    explicit ParamLayout(int f) {
+        E = 3 * f * f;
+        size_t o = 0;
+        conv0 = o; o += 2400;
+        f_bias = o; o += 32;
+        f_activ = o; o += 32;
+        exp_bias = o; o += E;
+        for (auto& b : l_bias) { b = o; o += 32; }
+        for (auto& a : l_activ) { a = o; o += 32; }
+        conv1 = o; o += 25600;
+        conv2 = o; o += 25600;
+        conv3 = o; o += 25600;
+        conv5 = o; o += 9216;
+        conv6 = o; o += 9216;
+        conv7 = o; o += (size_t)E * 288;
+        conv8 = o; o += 9216;
+        conv9 = o; o += (size_t)E * 288;
+        conv10 = o; o += (size_t)E * 288;
+        end = o;
+    }
 };
-static_assert(OFF_END == SR_NUM_PARAMS, "parameter count");
 
 constexpr int kChunk = 1024;  // floats per tap chunk (32 cin x 32 cout)
 
@@ -66,6 +83,40 @@ void pack_conv32_h(std::vector<float>& dst, const float* w, int O, int ks) {
         }
 }
 
+// The expand node's 3 f^2 channels ((dy*f+dx)*3+c, network.rs:39) are laid out in whole RGB
+// triples, 10 per 32-lane N-tile: lane j < 30 of tile nt carries channel 3*(10 nt + j/3) + j%3.
+// Returns that channel, or -1 for an unused lane.
+int expand_channel(int f, int nt, int j) {
+    const int tr = nt * 10 + j / 3;
+    return (j < 30 && tr < f * f) ? tr * 3 + j % 3 : -1;
+}
+int expand_tiles(int f) { return (f * f + 9) / 10; }
+
+// conv7 / conv9 / conv10 ([3f^2][3][3][32]) as ring chunks: tap-major, then N-tile.
+void pack_expand(std::vector<float>& dst, const float* w, int f, bool split) {
+    for (int t = 0; t < 9; ++t)
+        for (int nt = 0; nt < expand_tiles(f); ++nt) {
+            const size_t base = dst.size();
+            dst.resize(base + kChunk, 0.0f);
+            _Float16* hp = (_Float16*)(dst.data() + base);
+            for (int j = 0; j < 32; ++j) {
+                const int ch = expand_channel(f, nt, j);
+                if (ch < 0) continue;
+                const float* src = w + ((size_t)ch * 9 + t) * 32;
+                for (int ci = 0; ci < 32; ++ci) {
+                    if (!split) {
+                        dst[base + ((ci / 4) * 32 + j) * 4 + ci % 4] = src[ci];
+                    } else {
+                        _Float16 hi, lo;
+                        split_half_host(src[ci], hi, lo);
+                        hp[((ci / 8) * 32 + j) * 8 + ci % 8] = hi;
+                        hp[1024 + ((ci / 8) * 32 + j) * 8 + ci % 8] = lo;
+                    }
+                }
+            }
+        }
+}
+
 // conv0 [32][5][5][3] -> 25 taps x [h 2][o 32][q 2], cin = 2h+q, cin 3 = zero pad.
 void pack_conv0(std::vector<float>& dst, const float* w) {
     dst.assign(25 * 128, 0.0f);
@@ -78,22 +129,32 @@ void pack_conv0(std::vector<float>& dst, const float* w) {
                 }
 }
 
-// LinearInterp x3 (network.rs:27) as a 3x3 convolution of the edge-replicated
-// 3-channel input onto the 27 expand channels: 9 taps x [h 2][o 32][q 2], cin = 2h+q.
-// Along one axis, output phase p reads inputs (i-1, i, i+1) with weights
-//   p=0: (1-t, t, 0), t = 2/3    p=1: (0, 1, 0)    p=2: (0, 1-t, t), t = 1/3
-// (half-pixel centres); the 2-D weight is the f32 product.
-void pack_lin(std::vector<float>& dst) {
-    const float t0 = 2.0f / 3.0f, t2 = 1.0f / 3.0f;
-    const float w1[3][3] = {{1.0f - t0, t0, 0.0f}, {0.0f, 1.0f, 0.0f}, {0.0f, 1.0f - t2, t2}};
+// LinearInterp x f (network.rs:27) as a 3x3 convolution of the edge-replicated 3-channel
+// input onto the expand channels: 9 taps x N-tiles x [h 2][lane 32][q 2], cin = 2h+q.
+// Along one axis output phase p of pixel i sits at s - i = (2p+1-f)/(2f) (half-pixel centres,
+// SURVEY.md 8(a) G1): negative -> inputs (i-1, i) with weights (1-t, t), t = (2p+1+f)/(2f);
+// otherwise -> inputs (i, i+1) with weights (1-t, t), t = (2p+1-f)/(2f).  Same f32 constants
+// as the oracle; the 2-D weight is their f32 product.
+void pack_lin(std::vector<float>& dst, int f) {
+    float w1[4][3] = {};
+    for (int p = 0; p < f; ++p) {
+        const int nn = 2 * p + 1 - f;
+        const float t = (float)(nn < 0 ? nn + 2 * f : nn) / (float)(2 * f);
+        if (nn < 0) { w1[p][0] = 1.0f - t; w1[p][1] = t; }
+        else { w1[p][1] = 1.0f - t; w1[p][2] = t; }
+    }
+    const int ntn = expand_tiles(f);
     const size_t base = dst.size();
-    dst.resize(base + 9 * 128, 0.0f);
+    dst.resize(base + (size_t)9 * ntn * 128, 0.0f);
     for (int u = 0; u < 3; ++u)
         for (int v = 0; v < 3; ++v)
-            for (int o = 0; o < 27; ++o) {
-                const int dy = o / 9, dx = (o % 9) / 3, c = o % 3;
-                dst[base + (u * 3 + v) * 128 + ((c >> 1) * 32 + o) * 2 + (c & 1)] = w1[dy][u] * w1[dx][v];
-            }
+            for (int nt = 0; nt < ntn; ++nt)
+                for (int j = 0; j < 32; ++j) {
+                    const int ch = expand_channel(f, nt, j);
+                    if (ch < 0) continue;
+                    const int c = ch % 3, tr = ch / 3, dy = tr / f, dx = tr % f;
+                    dst[base + ((u * 3 + v) * ntn + nt) * 128 + ((c >> 1) * 32 + j) * 2 + (c & 1)] = w1[dy][u] * w1[dx][v];
+                }
 }
 
 }  // namespace
@@ -107,6 +168,7 @@ struct sr_ctx {
     size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
+    int factor = SR_FACTOR;
     float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3 (zero-bordered, see sr_kernels.h)
     size_t feat_cap_px = 0;       // allocated padded pixels per map
     int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
@@ -141,7 +203,7 @@ const char* sr_strerror(int s) {
         case SR_E_PARAM_COUNT:
             return "Parameters selected do not have the size required by the neural net. Ensure that the "
                    "same sample factor is used for upscaling and training";  // reference main.rs:162
-        case SR_E_FACTOR: return "only upscaling factor 3 is supported (reference main.rs:31)";
+        case SR_E_FACTOR: return "unsupported upscaling factor (sr_net: 2, 3 or 4; the reference ships 3, main.rs:31)";
         case SR_E_NO_DEVICE: return "no HIP (gfx950) device available; libsrhip has no CPU fallback";
         case SR_E_HIP: return "HIP runtime error";
         case SR_E_NOMEM: return "out of device memory";
@@ -190,9 +252,11 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     if (!out) return SR_E_INVALID;
     *out = nullptr;
     if (graph != SR_GRAPH_SR_NET && graph != SR_GRAPH_BILINEAR && graph != SR_GRAPH_DOWNSAMPLE) return SR_E_INVALID;
-    if (factor != SR_FACTOR) return SR_E_FACTOR;
-    // main.rs:162 assert_eq!(params.len(), graph.num_params()): 130459 for sr_net, 0 for the other two
-    if (n_params != (graph == SR_GRAPH_SR_NET ? (size_t)SR_NUM_PARAMS : 0)) return SR_E_PARAM_COUNT;
+    // the reference is hard-wired to 3 (main.rs:31); sr_net itself takes the factor as an argument
+    // (network.rs:16), so user-trained 2x / 4x parameter files are accepted too
+    if (graph == SR_GRAPH_SR_NET ? (factor < 2 || factor > 4) : factor != SR_FACTOR) return SR_E_FACTOR;
+    // main.rs:162 assert_eq!(params.len(), graph.num_params()): 130459 for sr_net(3), 0 for the other two
+    if (n_params != (graph == SR_GRAPH_SR_NET ? ParamLayout(factor).end : 0)) return SR_E_PARAM_COUNT;
     if (graph == SR_GRAPH_SR_NET && !params) return SR_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SR_E_NO_DEVICE;
@@ -201,6 +265,7 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     if (!c) return SR_E_NOMEM;
     c->device = device;
     c->graph = graph;
+    c->factor = factor;
     int rc = [&]() -> int {
         HIPCHK(c, hipSetDevice(device));
         hipDeviceProp_t prop;
@@ -225,35 +290,37 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
             for (int i = 0; i < n; ++i) v[i] = params[off + i];
             return v;
         };
-        pack_conv0(w, params + OFF_CONV0);
+        const ParamLayout L(factor);
+        pack_conv0(w, params + L.conv0);
         c->off_w0 = push(w);
-        w.clear(); pack_conv32(w, params + OFF_CONV1, 32, 5);
-        c->off_w[1] = push(w);
-        w.clear(); pack_conv32(w, params + OFF_CONV2, 32, 5); pack_conv32(w, params + OFF_CONV5, 32, 3);
-        c->off_w[2] = push(w);
-        w.clear(); pack_conv32(w, params + OFF_CONV3, 32, 5); pack_conv32(w, params + OFF_CONV6, 32, 3);
-        pack_conv32(w, params + OFF_CONV8, 32, 3);
-        c->off_w[3] = push(w);
-        w.clear(); pack_conv32(w, params + OFF_CONV7, 27, 3); pack_conv32(w, params + OFF_CONV9, 27, 3);
-        pack_conv32(w, params + OFF_CONV10, 27, 3);
-        pack_lin(w);
-        c->off_w[4] = push(w);
-        // the same four stages again in split-half form (sr_set_precision(SR_PRECISION_SPLIT_F16))
-        w.clear(); pack_conv32_h(w, params + OFF_CONV1, 32, 5);
-        c->off_wh[1] = push(w);
-        w.clear(); pack_conv32_h(w, params + OFF_CONV2, 32, 5); pack_conv32_h(w, params + OFF_CONV5, 32, 3);
-        c->off_wh[2] = push(w);
-        w.clear(); pack_conv32_h(w, params + OFF_CONV3, 32, 5); pack_conv32_h(w, params + OFF_CONV6, 32, 3);
-        pack_conv32_h(w, params + OFF_CONV8, 32, 3);
-        c->off_wh[3] = push(w);
-        w.clear(); pack_conv32_h(w, params + OFF_CONV7, 27, 3); pack_conv32_h(w, params + OFF_CONV9, 27, 3);
-        pack_conv32_h(w, params + OFF_CONV10, 27, 3);
-        pack_lin(w);
-        c->off_wh[4] = push(w);
-        const size_t boff[5] = {OFF_F_BIAS, OFF_L1_BIAS, OFF_L2_BIAS, OFF_L3_BIAS, OFF_EXP_BIAS};
-        const size_t aoff[4] = {OFF_F_ACTIV, OFF_L1_ACTIV, OFF_L2_ACTIV, OFF_L3_ACTIV};
-        for (int s = 0; s < 5; ++s) c->off_bias[s] = push(vec32(boff[s], s == 4 ? 27 : 32));
+        for (int split = 0; split < 2; ++split) {  // exact-f32 chunks, then the same stages in split-half form
+            auto conv = [&](const float* wp, int ks) { split ? pack_conv32_h(w, wp, 32, ks) : pack_conv32(w, wp, 32, ks); };
+            size_t* off = split ? c->off_wh : c->off_w;
+            w.clear(); conv(params + L.conv1, 5);
+            off[1] = push(w);
+            w.clear(); conv(params + L.conv2, 5); conv(params + L.conv5, 3);
+            off[2] = push(w);
+            w.clear(); conv(params + L.conv3, 5); conv(params + L.conv6, 3); conv(params + L.conv8, 3);
+            off[3] = push(w);
+            w.clear();
+            pack_expand(w, params + L.conv7, factor, split); pack_expand(w, params + L.conv9, factor, split);
+            pack_expand(w, params + L.conv10, factor, split);
+            pack_lin(w, factor);  // f32 in both modes: the residual is the signal, it stays on the exact path
+            off[4] = push(w);
+        }
+        const size_t boff[4] = {L.f_bias, L.l_bias[0], L.l_bias[1], L.l_bias[2]};
+        const size_t aoff[4] = {L.f_activ, L.l_activ[0], L.l_activ[1], L.l_activ[2]};
+        for (int s = 0; s < 4; ++s) c->off_bias[s] = push(vec32(boff[s], 32));
         for (int s = 0; s < 4; ++s) c->off_beta[s] = push(vec32(aoff[s], 32));
+        {   // expand_bias in the triple layout, 32 floats per N-tile
+            std::vector<float> eb((size_t)expand_tiles(factor) * 32, 0.0f);
+            for (int nt = 0; nt < expand_tiles(factor); ++nt)
+                for (int j = 0; j < 32; ++j) {
+                    const int ch = expand_channel(factor, nt, j);
+                    if (ch >= 0) eb[nt * 32 + j] = params[L.exp_bias + ch];
+                }
+            c->off_bias[4] = push(eb);
+        }
         HIPCHK(c, hipMalloc((void**)&c->d_queue, 5 * 8 * sizeof(int)));
         HIPCHK(c, hipMalloc((void**)&c->d_params, host.size() * sizeof(float)));
         HIPCHK(c, hipMemcpy(c->d_params, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -283,6 +350,8 @@ void sr_destroy(sr_ctx* c) {
 }
 
 int sr_last_hip_error(sr_ctx* c) { return c ? c->last_hip : 0; }
+
+int sr_num_params_factor(int factor) { return factor >= 2 && factor <= 4 ? (int)ParamLayout(factor).end : -1; }
 
 int sr_num_params(int graph) { return graph == SR_GRAPH_SR_NET ? SR_NUM_PARAMS : (graph == SR_GRAPH_BILINEAR || graph == SR_GRAPH_DOWNSAMPLE ? 0 : -1); }
 
@@ -441,7 +510,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
                 const int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);
                 if (grid > resident) grid = resident;
             }
-            HIPCHK(c, sr_launch_stage(st, a, th, c->precision, grid, img_u8, out_u8, s));
+            HIPCHK(c, sr_launch_stage(st, c->factor, a, th, c->precision, grid, img_u8, out_u8, s));
         }
         if (prof) HIPCHK(c, hipEventRecord(c->ev[st + 1], s));
     }
@@ -465,7 +534,7 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, i
     HIPCHK(c, hipSetDevice(c->device));
     const size_t npx = (size_t)n * h * w;
     const size_t in_bytes = npx * (img_u8 ? (size_t)img_ch : 3 * sizeof(float));
-    const size_t out_px = c->graph == SR_GRAPH_DOWNSAMPLE ? (size_t)n * (h / 3) * (w / 3) : npx * 9;
+    const size_t out_px = c->graph == SR_GRAPH_DOWNSAMPLE ? (size_t)n * (h / 3) * (w / 3) : npx * c->factor * c->factor;
     const size_t out_bytes = out_px * (out_u8 ? 4 : 3 * sizeof(float));
     int rc = ensure_buf(c, &c->d_in, &c->in_cap, in_bytes);
     if (rc == SR_OK) rc = ensure_buf(c, &c->d_out, &c->out_cap, out_bytes);

@@ -21,7 +21,7 @@ struct StageArgs {
     const uint32_t* voff5; // LDS-DMA gather tables: byte offset of tile pixel P from the tile origin,
     const uint32_t* voff3; //   36-wide (5x5 source) and 34-wide (3x3 source) tiles, 448 entries each
     const float* wpack;   // one 4 KB chunk per tap, sources concatenated: [cin/4][cout 32][4]
-    const float* bias;    // 32 (expand_bias zero-padded from 27)
+    const float* bias;    // 32 per N-tile (final stage: expand_bias in the triple layout, see sr_api.cpp)
     const float* beta;    // 32 (unused by the final stage)
     float* dst;           // non-final: padded feature map
     const void* img;      // final: the input image again (bilinear residual)
@@ -51,5 +51,6 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
 
 // prec: 0 = exact f32 (v_mfma_f32_32x32x2_f32), 1 = split-half (3 x v_mfma_f32_32x32x16_f16)
 hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool img_u8, hipStream_t s);
-hipError_t sr_launch_stage(int stage, const StageArgs& a, int th, int prec, int nblk, bool img_u8, bool out_u8,
+// factor (2, 3 or 4) only matters for stage 4 (3 f^2 expand channels, depth-to-space x f)
+hipError_t sr_launch_stage(int stage, int factor, const StageArgs& a, int th, int prec, int nblk, bool img_u8, bool out_u8,
                            hipStream_t s);

@@ -377,8 +377,10 @@ __device__ __forceinline__ void ring_advance(int& gtap, int& slot, int ntaps_tot
 
 // One source's KS x KS taps.  The weight chunk of tap t+2 is requested (LDS-DMA)
 // while tap t computes, so a chunk has two full taps (~4000 cycles) to land.
-template <int TH, int KS, int T>
-__device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, char* ring,
+// NTN > 1: the node has more than 32 output channels (expand at factor 4: 48 = 2 N-tiles); every
+// (tap, N-tile) pair is one 4 KB chunk of the ring and accumulates into acc[nt * T + row].
+template <int TH, int KS, int T, int NTN = 1>
+__device__ __forceinline__ void conv_taps(f32x16 (&acc)[NTN * T], const char* tile, char* ring,
                                           const float* __restrict__ wpack, int& gtap, int& slot,
                                           int ntaps_total, int wave, int lane) {
     using G = TileGeom<TH, KS>;
@@ -388,6 +390,8 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, ch
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+          for (int nt = 0; nt < NTN; ++nt) {
             ring_request(ring, wpack, gtap, slot, ntaps_total, wave, lane);
             const char* wb = ring + slot * 4096 + wlane;
             const char* ab = abase + (ky * G::TWH + kx) * 16;
@@ -401,9 +405,10 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, ch
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int m = 0; m < T; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], b[q], acc[m], 0, 0, 0);
+                        acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], b[q], acc[nt * T + m], 0, 0, 0);
             }
             ring_advance(gtap, slot, ntaps_total);  // chunk gtap has landed everywhere
+          }
         }
     }
 }
@@ -418,8 +423,8 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[T], const char* tile, ch
 // The f16 matrix core is POWER-limited on real data (scripts/ubench_f16.hip: 2305 TF
 // issued with constant operands, 1596 TF with random ones; this kernel runs the
 // chip at ~2.07 GHz and ~930 TF issued), so cycles saved come back as lower clock.
-template <int TH, int KS, int T>
-__device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T], const char* tile, char* ring,
+template <int TH, int KS, int T, int NTN = 1>
+__device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[NTN * T], f32x16 (&accx)[NTN * T], const char* tile, char* ring,
                                             const float* __restrict__ wpack, int& gtap, int& slot,
                                             int ntaps_total, int wave, int lane) {
     using G = TileGeom<TH, KS>;
@@ -429,6 +434,8 @@ __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T]
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+          for (int nt = 0; nt < NTN; ++nt) {
             ring_request(ring, wpack, gtap, slot, ntaps_total, wave, lane);
             const char* wb = ring + slot * 4096 + wlane;
             const char* ab = abase + (ky * G::TWH + kx) * 16;
@@ -443,13 +450,14 @@ __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T]
                     al[m] = *(const f16x8*)(ab + (4 + kk * 2) * G::PLANE + m * G::TWH * 16);
                 }
 #pragma unroll
-                for (int m = 0; m < T; ++m) accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, accm[m], 0, 0, 0);
+                for (int m = 0; m < T; ++m) accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, accm[nt * T + m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, accx[m], 0, 0, 0);
+                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, accx[nt * T + m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, accx[m], 0, 0, 0);
+                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, accx[nt * T + m], 0, 0, 0);
             }
             ring_advance(gtap, slot, ntaps_total);
+          }
         }
     }
 }
@@ -459,15 +467,15 @@ __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[T], f32x16 (&accx)[T]
 // edge-REPLICATED coordinates (the interp clamps indices, it does not zero-pad),
 // the fixed weights (phase products {1/3, 2/3, 1}^2, built on the host) sit in the
 // weight pack behind the conv chunks: 9 x [cin/2][cout 32][2] floats.
-template <int TH, int T, bool IMG_U8, int NTHREADS>
-__device__ __forceinline__ void lin_taps(f32x16 (&acc)[T], char* tile, char* ring, const StageArgs& a,
+template <int TH, int T, bool IMG_U8, int NTHREADS, int NTN>
+__device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], char* tile, char* ring, const StageArgs& a,
                                          const float* __restrict__ wlin, int n, int y0, int x0, int wave,
                                          int lane, int tid) {
     constexpr int TWH = kTW + 2, THH = TH + 2, NPIX = THH * TWH;
     float* s_x = (float*)tile;   // [pixel][4]
-    float* s_w = (float*)ring;   // 9 x 128 floats
+    float* s_w = (float*)ring;   // 9 x NTN x 128 floats
     const size_t img_px0 = (size_t)n * a.H * a.W;
-    for (int k = tid; k < 9 * 128; k += NTHREADS) s_w[k] = wlin[k];
+    for (int k = tid; k < 9 * NTN * 128; k += NTHREADS) s_w[k] = wlin[k];
     for (int p = tid; p < NPIX; p += NTHREADS) {
         const int py = p / TWH, px = p - py * TWH;
         const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
@@ -487,12 +495,15 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[T], char* tile, char* rin
     for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const f32x2 b = *(const f32x2*)(wb + (ky * 3 + kx) * 128);
 #pragma unroll
-            for (int m = 0; m < T; ++m) {
-                const f32x2 av = *(const f32x2*)(xa + ((m + ky) * TWH + kx) * 4);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[m], 0, 0, 0);
+            for (int nt = 0; nt < NTN; ++nt) {
+                const f32x2 b = *(const f32x2*)(wb + ((ky * 3 + kx) * NTN + nt) * 128);
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    const f32x2 av = *(const f32x2*)(xa + ((m + ky) * TWH + kx) * 4);
+                    acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[nt * T + m], 0, 0, 0);
+                    acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[nt * T + m], 0, 0, 0);
+                }
             }
         }
     }
@@ -527,9 +538,13 @@ __device__ __forceinline__ int queue_resolve(int* queue, int xcd, int ntiles, in
 // next tile's DMA is requested before the current tile's epilogue.  Best for the
 // split-half mode, whose tiles last ~14 us: with one tile per workgroup 30 % of the
 // workgroup slots sat empty between a retire and the next dispatch.
-template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, bool PERSIST, int NW>
+template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, bool PERSIST, int NW, int FACTOR = 3>
 __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv_stage_kernel(StageArgs a) {
     constexpr int T = TH / NW;  // tile rows per wave
+    // The final stage has 3 f^2 expand channels (network.rs:37).  They are laid out in whole RGB
+    // triples, 10 per 32-lane N-tile (so the u8 packing never straddles tiles): f = 2, 3 -> 1 tile,
+    // f = 4 -> 16 triples -> 2 tiles.
+    constexpr int NTN = FINAL ? (FACTOR * FACTOR + 9) / 10 : 1;
     using G0 = TileGeom<TH, KS0>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tile = smem;
@@ -539,11 +554,13 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    constexpr int NTAPS = KS0 * KS0 + (NSRC - 1) * 9;
+    constexpr int NTAPS = (KS0 * KS0 + (NSRC - 1) * 9) * NTN;  // ring chunks: one per (tap, N-tile)
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = tiles_per_img * a.n_img;
     const int xcd = blockIdx.x & 7;
-    const float bias = a.bias[i];
+    float bias[NTN];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) bias[nt] = a.bias[nt * 32 + i];
     const float beta = FINAL ? 0.f : a.beta[i];
 
     // request everything the first phase of tile `t` needs: weight chunks 0..3 and the first source tile
@@ -575,9 +592,9 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
 
     while (true) {
         const int tn = n, tx0 = x0, ty0 = y0;  // this tile (request_tile below overwrites n, x0, y0)
-        f32x16 acc[T], accx[PREC == 1 ? T : 1];  // accx: the cross products of the split-half mode, x2048
+        f32x16 acc[NTN * T], accx[PREC == 1 ? NTN * T : 1];  // accx: the cross products of the split-half mode, x2048
 #pragma unroll
-        for (int m = 0; m < T; ++m)
+        for (int m = 0; m < NTN * T; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[m][r] = 0.f;
@@ -586,8 +603,8 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
         int gtap = 0, slot = 0;
         auto taps = [&](auto ks_tag) {
             constexpr int KS = decltype(ks_tag)::value;
-            if constexpr (PREC == 0) conv_taps<TH, KS, T>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
-            else conv_taps_h<TH, KS, T>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+            if constexpr (PREC == 0) conv_taps<TH, KS, T, NTN>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+            else conv_taps_h<TH, KS, T, NTN>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
         };
         TL(0); TL(1);
         ring_barrier<0>();  // every wave's tile + weight DMAs (and earlier stores) have landed
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
         }
         __builtin_amdgcn_s_setprio(3);
         if constexpr (FINAL) {
-            lin_taps<TH, T, IMG_U8, NW * 64>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, tn, ty0, tx0, wave, lane, tid);
+            lin_taps<TH, T, IMG_U8, NW * 64, NTN>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, tn, ty0, tx0, wave, lane, tid);
             if constexpr (PERSIST) __syncthreads();  // everybody is done reading the image tile / lin weights
         }
         TL(6);
@@ -640,58 +657,67 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
                 if constexpr (PREC == 0) {
                     float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
                     if (full_x) {
-                        store_belu_tile(base, acc[m], bias, beta);
+                        store_belu_tile(base, acc[m], bias[0], beta);
                     } else {
                         for_each_acc_row([&](int r, int row) {
-                            if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
+                            if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias[0]), beta);
                         });
                     }
                 } else {
                     char* base = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h + (i & 1)) * 32) + (i & ~1) * 2;
-                    if (full_x) store_belu_tile_split(base, acc[m], accx[m], bias, beta, i & 1);
-                    else store_belu_tile_split_masked(base, acc[m], accx[m], bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)));
+                    if (full_x) store_belu_tile_split(base, acc[m], accx[m], bias[0], beta, i & 1);
+                    else store_belu_tile_split_masked(base, acc[m], accx[m], bias[0], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)));
                 }
             }
         } else {
             if constexpr (PREC == 1) {
 #pragma unroll
-                for (int m = 0; m < T; ++m)
+                for (int m = 0; m < NTN * T; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[m][r] = acc[m][r] + accx[m][r] * (1.0f / kLoScale);
             }
-            // Expand (network.rs:39): lane i < 27 owns expand channel i = (dy*3+dx)*3+c;
-            // out[3y+dy][3x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
-            const int ch = i < 27 ? i : 26;
-            const int dy = ch / 9, sub = ch - dy * 9;  // sub = dx*3 + c
-            const int OW = a.W * 3;
+            // Expand (network.rs:39): out[f y+dy][f x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
+            // Lane i < 30 of N-tile nt owns colour c = i % 3 of sub-pixel triple tr = 10 nt + i / 3
+            // (dy = tr / f, dx = tr % f); the host packs the weights in that order.
+            const int OW = a.W * FACTOR;
             const int h_band = a.y_end - a.y_begin;
+            const int tl = i / 3, c = i - 3 * tl;
 #pragma unroll
-            for (int m = 0; m < T; ++m) {
-                const int y = y0 + wave * T + m;
-                if (y >= a.y_end) continue;
-                const size_t opx = ((size_t)n * h_band * 3 + (size_t)(y - a.y_begin) * 3 + dy) * OW + 3 * (x0 + 4 * h);
-                if constexpr (!OUT_U8) {
-                    float* base = (float*)a.out + opx * 3 + sub;
-                    if (full_x) {
-                        for_each_acc_row([&](int r, int row) { if (i < 27) base[row * 9] = __fadd_rn(acc[m][r], bias); });
+            for (int nt = 0; nt < NTN; ++nt) {
+                const int tr = nt * 10 + tl;
+                const bool valid = i < 30 && tr < FACTOR * FACTOR;
+                const int trc = valid ? tr : 0;
+                const int dy = trc / FACTOR, dx = trc - dy * FACTOR;
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    const int y = y0 + wave * T + m;
+                    if (y >= a.y_end) continue;
+                    const f32x16& av = acc[nt * T + m];
+                    const size_t opx = ((size_t)n * h_band * FACTOR + (size_t)(y - a.y_begin) * FACTOR + dy) * OW +
+                                       FACTOR * (x0 + 4 * h) + dx;
+                    if constexpr (!OUT_U8) {
+                        float* base = (float*)a.out + opx * 3 + c;
+                        if (full_x) {
+                            for_each_acc_row([&](int r, int row) { if (valid) base[row * FACTOR * 3] = __fadd_rn(av[r], bias[nt]); });
+                        } else {
+                            for_each_acc_row([&](int r, int row) {
+                                if (valid && x0 + 4 * h + row < a.W) base[row * FACTOR * 3] = __fadd_rn(av[r], bias[nt]);
+                            });
+                        }
                     } else {
+                        // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255;
+                        // the lane holding c == 0 gathers G and B from its two neighbours
+                        uint32_t* base = (uint32_t*)a.out + opx;
+                        const bool writer = valid && c == 0;
                         for_each_acc_row([&](int r, int row) {
-                            if (i < 27 && x0 + 4 * h + row < a.W) base[row * 9] = __fadd_rn(acc[m][r], bias);
+                            float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(av[r], bias[nt])), 0.5f));
+                            q = fminf(fmaxf(q, 0.0f), 255.0f);
+                            const uint32_t qi = (uint32_t)q;
+                            const uint32_t g = __shfl_down(qi, 1), b = __shfl_down(qi, 2);
+                            if (writer && (full_x || x0 + 4 * h + row < a.W))
+                                base[row * FACTOR] = qi | (g << 8) | (b << 16) | 0xff000000u;
                         });
                     }
-                } else {
-                    // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255;
-                    // the lane holding c == 0 gathers G and B from its two neighbours
-                    uint32_t* base = (uint32_t*)a.out + opx + sub / 3;
-                    const bool writer = i < 27 && (sub % 3) == 0;
-                    for_each_acc_row([&](int r, int row) {
-                        float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(acc[m][r], bias)), 0.5f));
-                        q = fminf(fmaxf(q, 0.0f), 255.0f);
-                        const uint32_t qi = (uint32_t)q;
-                        const uint32_t g = __shfl_down(qi, 1), b = __shfl_down(qi, 2);
-                        if (writer && (full_x || x0 + 4 * h + row < a.W))
-                            base[row * 3] = qi | (g << 8) | (b << 16) | 0xff000000u;
-                    });
                 }
             }
         }
@@ -817,7 +843,7 @@ static hipError_t launch_with_lds(K kern, const StageArgs& a, int nblk, size_t l
 }
 
 template <int TH, int PREC>
-static hipError_t launch_stage_t(int stage, const StageArgs& a, int nblk, bool img_u8, bool out_u8,
+static hipError_t launch_stage_t(int stage, int factor, const StageArgs& a, int nblk, bool img_u8, bool out_u8,
                                  hipStream_t s) {
     // waves per workgroup.  8 (one tile row per wave, 4 waves per SIMD) was measured for the
     // split-half mode: 5 % slower than 4 (B-operand reuse halves), so SR_SPLIT_WAVES stays 4.
@@ -827,18 +853,24 @@ static hipError_t launch_stage_t(int stage, const StageArgs& a, int nblk, bool i
         case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 5>(), s, NWAVES * 64);
         case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 5>(), s, NWAVES * 64);
         case 4:
-            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 3>(), s, NWAVES * 64);
-            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 3>(), s, NWAVES * 64);
+#define SR_FINAL(F)                                                                                                          \
+            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC, PREC == 1, NWAVES, F>, a, nblk, stage_lds_bytes<TH, 3>(), s, NWAVES * 64); \
+            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC, PREC == 1, NWAVES, F>, a, nblk, stage_lds_bytes<TH, 3>(), s, NWAVES * 64); \
+            return hipErrorInvalidValue;
+            if (factor == 3) { SR_FINAL(3) }
+            if (factor == 2) { SR_FINAL(2) }
+            if (factor == 4) { SR_FINAL(4) }
+#undef SR_FINAL
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t sr_launch_stage(int stage, const StageArgs& a, int th, int prec, int nblk, bool img_u8, bool out_u8,
-                           hipStream_t s) {
+hipError_t sr_launch_stage(int stage, int factor, const StageArgs& a, int th, int prec, int nblk, bool img_u8,
+                           bool out_u8, hipStream_t s) {
     if (prec == 0)
-        return th == 8 ? launch_stage_t<8, 0>(stage, a, nblk, img_u8, out_u8, s)
-                       : launch_stage_t<4, 0>(stage, a, nblk, img_u8, out_u8, s);
-    return th == 8 ? launch_stage_t<8, 1>(stage, a, nblk, img_u8, out_u8, s)
-                   : launch_stage_t<4, 1>(stage, a, nblk, img_u8, out_u8, s);
+        return th == 8 ? launch_stage_t<8, 0>(stage, factor, a, nblk, img_u8, out_u8, s)
+                       : launch_stage_t<4, 0>(stage, factor, a, nblk, img_u8, out_u8, s);
+    return th == 8 ? launch_stage_t<8, 1>(stage, factor, a, nblk, img_u8, out_u8, s)
+                   : launch_stage_t<4, 1>(stage, factor, a, nblk, img_u8, out_u8, s);
 }

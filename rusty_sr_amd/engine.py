@@ -65,6 +65,7 @@ class Engine:
         p = np.ascontiguousarray(params, dtype=np.float32)
         self._ctx = C.c_void_p()
         self.graph = graph
+        self.factor = factor
         _lib.check(L.sr_create_graph(C.byref(self._ctx), self.GRAPHS[graph],
                                      p.ctypes.data_as(C.POINTER(C.c_float)) if p.size else None, p.size, factor, device))
         self.device = device
@@ -77,7 +78,7 @@ class Engine:
         self.precision = precision
 
     def _out_hw(self, h, w):
-        return (h // 3, w // 3) if self.graph == "downsample" else (3 * h, 3 * w)
+        return (h // 3, w // 3) if self.graph == "downsample" else (self.factor * h, self.factor * w)
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -151,7 +152,7 @@ class Engine:
         if hb <= 0 or halo_top < 0 or halo_bot < 0:
             raise _lib.SrError(_lib.SR_E_INVALID)
         if out is None:
-            out = torch.empty((3 * hb, 3 * w, 3), dtype=torch.float32, device=x_ext.device)
+            out = torch.empty((self.factor * hb, self.factor * w, 3), dtype=torch.float32, device=x_ext.device)
         _lib.check(self._L.sr_upscale_band_f32_dev(self._ctx, C.c_void_p(x_ext.data_ptr()), h_ext, w, halo_top,
                                                    halo_bot, C.c_void_p(out.data_ptr()), self._stream_ptr(stream)),
                    self._ctx)
@@ -165,7 +166,7 @@ class Engine:
         if hb <= 0 or halo_top < 0 or halo_bot < 0:
             raise _lib.SrError(_lib.SR_E_INVALID)
         if out is None:
-            out = torch.empty((3 * hb, 3 * w, 4), dtype=torch.uint8, device=px_ext.device)
+            out = torch.empty((self.factor * hb, self.factor * w, 4), dtype=torch.uint8, device=px_ext.device)
         _lib.check(self._L.sr_upscale_band_rgba8_dev(self._ctx, C.c_void_p(px_ext.data_ptr()), c, h_ext, w,
                                                      halo_top, halo_bot, C.c_void_p(out.data_ptr()),
                                                      self._stream_ptr(stream)), self._ctx)
@@ -200,7 +201,7 @@ class Graph:
     forward() (main.rs:171)."""
 
     def __init__(self, factor: int, device: int = 0):
-        if factor != FACTOR:
+        if factor not in (2, 3, 4):
             raise _lib.SrError(_lib.SR_E_FACTOR)
         self.factor = factor
         self.device = device
@@ -208,7 +209,7 @@ class Graph:
         self._params_key = None
 
     def num_params(self) -> int:
-        return _lib.SR_NUM_PARAMS
+        return _lib.lib().sr_num_params_factor(self.factor)
 
     def forward(self, n: int, inputs: List[NodeData], params) -> List[NodeData]:
         if len(inputs) != 1:

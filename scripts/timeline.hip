@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     long long* tl; hipMalloc(&tl, (size_t)nblk * 128);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
     if (prec == 1) nblk = 512;  // persistent form: co-resident workgroups pull tiles from the queue
-    for (int rep = 0; rep < 3; ++rep) { hipMemset(dq, 0, 64); sr_launch_stage(stage, a, th, prec, nblk, false, false, 0); }
+    for (int rep = 0; rep < 3; ++rep) { hipMemset(dq, 0, 64); sr_launch_stage(stage, 3, a, th, prec, nblk, false, false, 0); }
     hipDeviceSynchronize();
     std::vector<long long> h((size_t)nblk * 16);
     hipMemcpy(h.data(), tl, (size_t)nblk * 128, hipMemcpyDeviceToHost);

@@ -68,8 +68,13 @@ def test_create_validates_before_touching_the_gpu(params):
     assert e.value.status == _lib.SR_E_PARAM_COUNT
     assert "Parameters selected do not have the size required by the neural net" in str(e.value)  # main.rs:162
     with pytest.raises(r.SrError) as e:
-        r.Engine(p, factor=4)
+        r.Engine(p, factor=5)
     assert e.value.status == _lib.SR_E_FACTOR
+    with pytest.raises(r.SrError) as e:  # factor 4 needs sr_net(4)'s 148624 parameters, not the bundled 130459
+        r.Engine(p, factor=4)
+    assert e.value.status == _lib.SR_E_PARAM_COUNT
+    L = _lib.lib()
+    assert [L.sr_num_params_factor(f) for f in (1, 2, 3, 4, 5)] == [-1, oracle.num_params(2), oracle.NPARAMS, oracle.num_params(4), -1]
     with pytest.raises(r.SrError) as e:  # parameter-free graphs take exactly zero parameters
         r.Engine(p, graph="bilinear")
     assert e.value.status == _lib.SR_E_PARAM_COUNT
@@ -77,7 +82,8 @@ def test_create_validates_before_touching_the_gpu(params):
         r.Engine((), graph="sr_net")
     assert e.value.status == _lib.SR_E_PARAM_COUNT
     with pytest.raises(r.SrError):
-        r.sr_net(4)
+        r.sr_net(5)
+    assert r.sr_net(4).num_params() == 148624 and r.sr_net(2).num_params() == 117484
     with pytest.raises(NotImplementedError):
         r.sr_net(3, training=(1e-6, False))
 

@@ -276,3 +276,50 @@ def test_band_argument_validation(engines):
             eng.upscale_band_f32_dev(x, top, bot)
     out = eng.upscale_band_f32_dev(x, 7, 7)
     assert out.shape == (48, 120, 3)
+
+
+def _synthetic_params(factor, seed):
+    """No 2x / 4x weights ship with the reference: seeded synthetic parameters with the bundled
+    weights' scales (conv std from imagenet.rsr, small biases, BeLU betas in [-0.5, 1.5])."""
+    rng = np.random.default_rng(seed)
+    n = oracle.num_params(factor)
+    p = (rng.standard_normal(n) * 0.03).astype(np.float32)
+    e = 3 * factor * factor
+    p[2400:2464 + e + 96] = (rng.standard_normal(64 + e + 96) * 0.05).astype(np.float32)       # biases
+    p[2432:2464] = rng.uniform(-0.5, 1.5, 32).astype(np.float32)                                 # f_activ
+    a0 = 2464 + e + 96
+    p[a0:a0 + 96] = rng.uniform(-0.5, 1.5, 96).astype(np.float32)                                # l1..l3 activ
+    return p
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("precision", ["f32", "split_f16"])
+def test_other_factors_against_the_restatement(factor, precision):
+    """sr_net(factor) for factor 2 and 4 (network.rs:16 takes it as an argument; main.rs:31 fixes 3).
+    UNPINNED against the reference (no such weights exist): parity is against the oracle's
+    generalised restatement, which is bit-identical to the pinned path at factor 3."""
+    import torch
+    import rusty_sr_amd as r
+    p = _synthetic_params(factor, 100 + factor)
+    eng = r.Engine(p, device=0, factor=factor, precision=precision)
+    for n, h, w in ((1, 9, 33), (2, 40, 70), (1, 64, 96)):
+        px = synth_u8(60 + h, n, h, w)
+        x = oracle.img_to_data(px)
+        want = oracle.forward_factor(p, x, factor)
+        got = eng.upscale_f32(x)
+        assert got.shape == (n, factor * h, factor * w, 3)
+        assert np.abs(got - want).max() < TIGHT
+        _check_u8(eng.upscale_rgba8(px), want)
+    # row bands stay bit-identical at any factor
+    x = oracle.img_to_data(synth_u8(77, 1, 50, 40))
+    full = eng.upscale_f32(x)[0]
+    xt = torch.from_numpy(x[0]).cuda()
+    out = eng.upscale_band_f32_dev(xt[20 - 7:33 + 7].contiguous(), 7, 7)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), full[factor * 20:factor * 33])
+    eng.close()
+
+
+def test_factor3_general_path_is_the_pinned_path(params):
+    x = oracle.img_to_data(synth_u8(5, 1, 21, 34))
+    np.testing.assert_array_equal(oracle.forward_factor(params["anime"], x, 3), oracle.forward(params["anime"], x))
