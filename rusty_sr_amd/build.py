@@ -40,7 +40,7 @@ PNGLIB = os.path.join(HERE, "libsrpng.so")
 def build_host(force=False, verbose=False):
     """g++ -> rusty_sr_amd/bin/rusty_sr (the CLI with the reference's argv surface; links
     libsrhip.so via $ORIGIN/..) and rusty_sr_amd/libsrpng.so (the PNG codec alone, for tests)."""
-    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "png.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "png.cpp", "jpeg.cpp")]
     deps = srcs + [os.path.join(HOST, "png.hpp"), os.path.join(HERE, "..", "include", "srhip.h"), LIB]
     if not force and os.path.exists(CLI) and os.path.exists(PNGLIB) and \
             all(os.path.getmtime(d) <= min(os.path.getmtime(CLI), os.path.getmtime(PNGLIB)) for d in deps):
@@ -48,7 +48,7 @@ def build_host(force=False, verbose=False):
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     res = os.path.join(HERE, "res")
     cmds = [
-        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[1], "-lz", "-o", PNGLIB],
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[1], srcs[2], "-lz", "-o", PNGLIB],
         ["g++", "-O2", "-std=c++17", "-pthread", f'-DSR_RES_DIR="{res}"', *srcs, "-L", HERE, "-lsrhip", "-lz",
          "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", CLI],
     ]

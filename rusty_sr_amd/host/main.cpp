@@ -3,8 +3,8 @@
 //
 //   rusty_sr <INPUT_FILE> <OUTPUT_FILE> [-p imagenet|imagenetlinear|anime|bilinear] [-c FILE] [-d]
 //
-// Differences from the reference, all outside the hot path: PNG only (own codec over
-// zlib; the reference's `image` crate also reads JPEG etc.), the `train` sub-command
+// Differences from the reference, all outside the hot path: own codecs (PNG over zlib,
+// baseline JPEG, PPM/PGM, BMP in; PNG out -- the reference's `image` crate knows more formats), the `train` sub-command
 // is not part of this build, and three extra options that cannot collide with the
 // reference's (-p -c -d): --device N, --precision f32|split_f16, --timing.
 #include <cstdio>
@@ -139,7 +139,7 @@ int main(int argc, char** argv) {
 
     srpng::Image in;
     std::string err;
-    if (!srpng::decode_file(pos[0], in, err)) die("Error opening input image file. (" + err + ")");  // main.rs:164
+    if (!srpng::decode_image_file(pos[0], in, err)) die("Error opening input image file. (" + err + ")");  // main.rs:164
     if (!ends_with_png(pos[1])) die("Could not write output file (only .png output is supported by this build)");
     if (graph == SR_GRAPH_DOWNSAMPLE && (in.w < 3 || in.h < 3)) die("input image is smaller than one 3x3 pooling block");
 

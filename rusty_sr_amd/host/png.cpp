@@ -2,6 +2,7 @@
 
 #include <zlib.h>
 
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -146,6 +147,120 @@ bool decode_memory(const uint8_t* p, size_t len, Image& out, std::string& err) {
     }
     // grey / RGB + tRNS colour key -> alpha 0 for the key (8-bit compare on the stored sample)
     return true;
+}
+
+static bool read_all(const std::string& path, std::vector<uint8_t>& buf, std::string& err) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open file"; return false; }
+    uint8_t tmp[65536];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    return true;
+}
+
+// PPM / PGM / PBM: binary (P6 / P5 / P4) and plain (P3 / P2 / P1), maxval <= 65535
+static bool decode_pnm(const uint8_t* d, size_t len, Image& out, std::string& err) {
+    const int kind = d[1] - '0';
+    const bool plain = kind <= 3, bitmap = kind == 1 || kind == 4;
+    const int ch = (kind == 3 || kind == 6) ? 3 : 1;
+    size_t pos = 2;
+    auto next_int = [&](long& v) {
+        for (;;) {
+            if (pos >= len) return false;
+            if (d[pos] == '#') { while (pos < len && d[pos] != '\n') ++pos; continue; }
+            if (isspace(d[pos])) { ++pos; continue; }
+            break;
+        }
+        if (!isdigit(d[pos])) return false;
+        v = 0;
+        while (pos < len && isdigit(d[pos]) && v < (1L << 40)) { v = v * 10 + (d[pos] - '0'); ++pos; }
+        return true;
+    };
+    long w = 0, h = 0, maxv = 1;
+    if (!next_int(w) || !next_int(h) || (!bitmap && !next_int(maxv))) { err = "bad PNM header"; return false; }
+    if (w <= 0 || h <= 0 || w > (1 << 20) || h > (1 << 20) || maxv <= 0 || maxv > 65535) { err = "bad PNM header"; return false; }
+    out.w = (int)w; out.h = (int)h;
+    out.rgba.assign((size_t)w * h * 4, 255);
+    auto put = [&](size_t p, int c, long v) {
+        const uint8_t q = (uint8_t)((std::min(v, maxv) * 255 + maxv / 2) / maxv);
+        if (ch == 3) out.rgba[p * 4 + c] = q; else out.rgba[p * 4] = out.rgba[p * 4 + 1] = out.rgba[p * 4 + 2] = q;
+    };
+    if (plain) {
+        for (size_t p = 0; p < (size_t)w * h; ++p)
+            for (int c = 0; c < ch; ++c) {
+                long v;
+                if (bitmap) {  // P1: digits need no separators, 1 = black
+                    while (pos < len && (isspace(d[pos]) || d[pos] == '#')) { if (d[pos] == '#') while (pos < len && d[pos] != '\n') ++pos; else ++pos; }
+                    if (pos >= len || (d[pos] != '0' && d[pos] != '1')) { err = "truncated PNM"; return false; }
+                    v = d[pos++] == '0';
+                } else if (!next_int(v)) { err = "truncated PNM"; return false; }
+                put(p, c, v);
+            }
+        return true;
+    }
+    ++pos;  // the single whitespace after the header
+    if (bitmap) {
+        const size_t stride = ((size_t)w + 7) / 8;
+        if (pos + stride * h > len) { err = "truncated PNM"; return false; }
+        for (long y = 0; y < h; ++y)
+            for (long x = 0; x < w; ++x) put((size_t)y * w + x, 0, !((d[pos + y * stride + x / 8] >> (7 - x % 8)) & 1));
+        return true;
+    }
+    const int bps = maxv > 255 ? 2 : 1;
+    if (pos + (size_t)w * h * ch * bps > len) { err = "truncated PNM"; return false; }
+    for (size_t p = 0; p < (size_t)w * h; ++p)
+        for (int c = 0; c < ch; ++c) {
+            const uint8_t* s = d + pos + (p * ch + c) * bps;
+            put(p, c, bps == 2 ? (long)(s[0] << 8 | s[1]) : (long)s[0]);
+        }
+    return true;
+}
+
+// uncompressed BMP: 1 / 4 / 8-bit palettised, 24 and 32 bits per pixel (BI_RGB / BI_BITFIELDS with
+// the usual BGRA masks); alpha is ignored as the image crate of the reference's era does
+static bool decode_bmp(const uint8_t* d, size_t len, Image& out, std::string& err) {
+    auto le32 = [&](size_t o) { return (uint32_t)d[o] | d[o + 1] << 8 | d[o + 2] << 16 | (uint32_t)d[o + 3] << 24; };
+    if (len < 54) { err = "truncated BMP"; return false; }
+    const uint32_t off = le32(10), hdr = le32(14), comp = le32(30);
+    const int32_t w = (int32_t)le32(18), hs = (int32_t)le32(22);
+    const int bpp = d[28] | d[29] << 8;
+    const int h = hs < 0 ? -hs : hs;
+    const bool pal = bpp == 1 || bpp == 4 || bpp == 8;
+    if (hdr < 40 || w <= 0 || h <= 0 || w > (1 << 20) || h > (1 << 20) || !(pal || bpp == 24 || bpp == 32) ||
+        (comp != 0 && !(comp == 3 && bpp == 32))) { err = "unsupported BMP (only uncompressed 1/4/8/24/32-bit)"; return false; }
+    const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
+    uint32_t ncol = pal ? le32(46) : 0;
+    if (pal && (ncol == 0 || ncol > (1u << bpp))) ncol = 1u << bpp;
+    const size_t pal_off = 14 + (size_t)hdr;
+    if ((size_t)off + stride * h > len || pal_off + (size_t)ncol * 4 > len) { err = "truncated BMP"; return false; }
+    out.w = w; out.h = h;
+    out.rgba.resize((size_t)w * h * 4);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* row = d + off + stride * (hs < 0 ? y : h - 1 - y);
+        for (int x = 0; x < w; ++x) {
+            const uint8_t* px;
+            if (pal) {
+                const uint32_t idx = bpp == 8 ? row[x] : bpp == 4 ? (row[x / 2] >> ((x & 1) ? 0 : 4)) & 15 : (row[x / 8] >> (7 - x % 8)) & 1;
+                if (idx >= ncol) { err = "BMP palette index out of range"; return false; }
+                px = d + pal_off + (size_t)idx * 4;
+            } else px = row + (size_t)x * bpp / 8;
+            uint8_t* o = out.rgba.data() + ((size_t)y * w + x) * 4;
+            o[0] = px[2]; o[1] = px[1]; o[2] = px[0]; o[3] = 255;
+        }
+    }
+    return true;
+}
+
+bool decode_image_file(const std::string& path, Image& out, std::string& err) {
+    std::vector<uint8_t> buf;
+    if (!read_all(path, buf, err)) return false;
+    if (buf.size() >= 8 && buf[0] == 0x89 && buf[1] == 'P') return decode_memory(buf.data(), buf.size(), out, err);
+    if (buf.size() >= 4 && buf[0] == 0xff && buf[1] == 0xd8) return decode_jpeg_memory(buf.data(), buf.size(), out, err);
+    if (buf.size() >= 7 && buf[0] == 'P' && buf[1] >= '1' && buf[1] <= '6' && isspace(buf[2])) return decode_pnm(buf.data(), buf.size(), out, err);
+    if (buf.size() >= 54 && buf[0] == 'B' && buf[1] == 'M') return decode_bmp(buf.data(), buf.size(), out, err);
+    err = "unrecognised image format (this build reads PNG, baseline JPEG, PPM/PGM/PBM, BMP)";
+    return false;
 }
 
 bool decode_file(const std::string& path, Image& out, std::string& err) {

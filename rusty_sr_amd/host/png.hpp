@@ -13,11 +13,16 @@ struct Image { int w = 0, h = 0; std::vector<uint8_t> rgba; };
 bool decode_file(const std::string& path, Image& out, std::string& err);
 bool decode_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
 bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int zlevel = 3);
+// baseline JPEG (jpeg.cpp); binary PPM / PGM and uncompressed 24 / 32-bit BMP (png.cpp)
+bool decode_jpeg_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
+// image::open stand-in: picks the decoder from the file's magic bytes (PNG, JPEG, PPM/PGM, BMP)
+bool decode_image_file(const std::string& path, Image& out, std::string& err);
 }  // namespace srpng
 
 extern "C" {
 // C surface used by tests/test_host_png.py through ctypes
 int srpng_decode_rgba8(const char* path, int* w, int* h, uint8_t** rgba);  // caller frees with srpng_free
+int srpng_decode_any_rgba8(const char* path, int* w, int* h, uint8_t** rgba);  // PNG / JPEG / PPM / BMP by magic
 int srpng_encode_rgba8(const char* path, const uint8_t* rgba, int w, int h);
 void srpng_free(uint8_t* p);
 }

@@ -24,8 +24,19 @@ def png():
     L = C.CDLL(PNGLIB)
     L.srpng_decode_rgba8.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8))]
     L.srpng_encode_rgba8.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    L.srpng_decode_any_rgba8.argtypes = L.srpng_decode_rgba8.argtypes
 
     class Codec:
+        @staticmethod
+        def decode_any(path):
+            """image::open stand-in (main.rs:164): PNG / baseline JPEG / PPM / PGM / BMP by magic bytes"""
+            w, h, p = C.c_int(), C.c_int(), C.POINTER(C.c_uint8)()
+            if L.srpng_decode_any_rgba8(str(path).encode(), C.byref(w), C.byref(h), C.byref(p)) != 0:
+                raise ValueError("decode failed")
+            a = np.ctypeslib.as_array(p, (h.value, w.value, 4)).copy()
+            L.srpng_free(p)
+            return a
+
         @staticmethod
         def decode(path):
             w, h, p = C.c_int(), C.c_int(), C.POINTER(C.c_uint8)()
@@ -96,6 +107,78 @@ def test_png_adam7_interlaced(png, tmp_path):
     assert (got[..., 3] == 255).all()
 
 
+def test_jpeg_baseline_matches_libjpeg(png, tmp_path):
+    """image::open (main.rs:164) also takes JPEG.  Baseline / extended-sequential Huffman files
+    decode to within 3 levels of libjpeg (IDCT rounding; same triangle chroma upsampling);
+    progressive files are refused, never mis-decoded."""
+    from PIL import Image
+    src = Image.open(os.path.join(GOLDEN, "butterfly_lr.png")).convert("RGB")
+    cases = {
+        "444": dict(quality=95, subsampling=0), "422": dict(quality=85, subsampling=1),
+        "420": dict(quality=90, subsampling=2), "420_opt": dict(quality=75, subsampling=2, optimize=True),
+        "q30": dict(quality=30, subsampling=2),
+    }
+    for name, kw in cases.items():
+        p = tmp_path / f"{name}.jpg"
+        src.save(p, **kw)
+        got, want = png.decode_any(p), np.array(Image.open(p).convert("RGBA"))
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert got.shape == want.shape and d.max() <= 3 and d.mean() < 0.15, (name, d.max(), d.mean())
+    # odd sizes (partial MCUs, odd chroma planes), greyscale, restart intervals
+    for (w, h) in ((1, 1), (7, 5), (83, 119), (17, 16)):
+        p = tmp_path / "odd.jpg"
+        src.crop((0, 0, w, h)).save(p, quality=92, subsampling=2)
+        got, want = png.decode_any(p), np.array(Image.open(p).convert("RGBA"))
+        assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).max() <= 3, (w, h)
+    p = tmp_path / "grey.jpg"
+    src.convert("L").save(p, quality=90)
+    got, want = png.decode_any(p), np.array(Image.open(p).convert("RGBA"))
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 2 and (got[..., 0] == got[..., 2]).all()
+    p = tmp_path / "rst.jpg"
+    try:
+        src.save(p, quality=90, subsampling=2, restart_marker_blocks=3)
+    except TypeError:  # older Pillow: no restart option
+        p = None
+    if p is not None and b"\xff\xdd" in p.read_bytes():
+        got, want = png.decode_any(p), np.array(Image.open(p).convert("RGBA"))
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 3
+    p = tmp_path / "prog.jpg"
+    src.save(p, quality=90, progressive=True)
+    with pytest.raises(ValueError):
+        png.decode_any(p)
+    p = tmp_path / "trunc.jpg"
+    src.save(p, quality=90)
+    p.write_bytes(p.read_bytes()[:400])
+    with pytest.raises(ValueError):
+        png.decode_any(p)
+
+
+def test_pnm_bmp_and_magic_dispatch(png, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (13, 21, 3), dtype=np.uint8)
+    for name, im in (("c.ppm", Image.fromarray(a)), ("g.pgm", Image.fromarray(a[..., 0])), ("c.bmp", Image.fromarray(a)),
+                     ("g.bmp", Image.fromarray(a[..., 0])), ("c.png", Image.fromarray(a)),
+                     ("p.bmp", Image.fromarray(a).convert("P")), ("b.bmp", Image.fromarray(a[..., 0]).convert("1")),
+                     ("b.pbm", Image.fromarray(a[..., 0]).convert("1"))):
+        p = tmp_path / name
+        im.save(p)
+        np.testing.assert_array_equal(png.decode_any(p), np.array(Image.open(p).convert("RGBA")), err_msg=name)
+    # plain (ASCII) PPM with a comment, maxval 15; dispatch is by content, not by extension
+    (tmp_path / "plain.dat").write_bytes(b"P3\n# comment\n2 1\n15\n15 0 0  0 15 3\n")
+    got = png.decode_any(tmp_path / "plain.dat")
+    np.testing.assert_array_equal(got, np.array([[[255, 0, 0, 255], [0, 255, 51, 255]]], np.uint8))
+    (tmp_path / "p1.dat").write_bytes(b"P1 3 2\n101\n0 1 0\n")
+    np.testing.assert_array_equal(png.decode_any(tmp_path / "p1.dat")[..., 0], np.array([[0, 255, 0], [255, 0, 255]], np.uint8))
+    g16 = rng.integers(0, 65536, (5, 7)).astype(">u2")
+    (tmp_path / "g16.pgm").write_bytes(b"P5\n7 5\n65535\n" + g16.tobytes())
+    np.testing.assert_array_equal(png.decode_any(tmp_path / "g16.pgm")[..., 1], ((g16.astype(np.int64) * 255 + 32767) // 65535).astype(np.uint8))
+    for junk in (b"", b"GIF89a" + b"\0" * 32, b"P6\n2 2\n255\nxx"):
+        (tmp_path / "junk").write_bytes(junk)
+        with pytest.raises(ValueError):
+            png.decode_any(tmp_path / "junk")
+
+
 def _run(*args):
     return subprocess.run([CLI, *args], capture_output=True, text=True, timeout=120)
 
@@ -151,6 +234,15 @@ def test_cli_end_to_end(png, tmp_path, params):
     bad.write_bytes(b"\x03\x00\x00\x00" + b"\x04\x00\x00\x00" * 3 + b"\x00" * 12)  # 3 params: count mismatch
     r = _run(os.path.join(GOLDEN, "cartoon_lr.png"), str(out2), "-c", str(bad))
     assert r.returncode == 1 and "Parameters selected do not have the size required" in r.stderr  # main.rs:162
+    # a JPEG input (image::open sniffs the format, main.rs:164): same pixels in, same pixels out
+    from PIL import Image
+    jpg = tmp_path / "in.jpg"
+    Image.open(os.path.join(GOLDEN, "butterfly_lr.png")).convert("RGB").save(jpg, quality=95, subsampling=0)
+    r = _run(str(jpg), str(out))
+    assert r.returncode == 0, r.stderr
+    want = oracle.upscale_rgba8(params["imagenet"], png.decode_any(jpg)[None, ..., :3])[0]
+    d = png.decode(out)[..., :3].astype(int) - want[..., :3].astype(int)
+    assert np.abs(d).max() <= 1 and (d != 0).mean() < 1e-3
     # -p bilinear and -d
     src = tmp_path / "src.png"
     px = synth_u8(40, 1, 33, 47)[0]
