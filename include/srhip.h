@@ -104,6 +104,17 @@ int sr_upscale_f32(sr_ctx* ctx, const float* in, int n, int h, int w, float* out
 int sr_upscale_rgba8(sr_ctx* ctx, const uint8_t* in, int in_channels, int n, int h, int w,
                      uint8_t* out_rgba);
 
+/* The two host-pointer entry points above run upload / conv stack / download as a software
+ * pipeline on three HIP streams: a batch goes in chunks of whole images, one large sr_net image
+ * goes as row bands with SR_HALO halo rows (bit-identical to the undivided pass, see
+ * sr_upscale_band_*).  Results do not depend on the setting; 0 = one upload, one pass, one
+ * download.  The reference has no counterpart (its tensors never leave host memory,
+ * main.rs:168-175); buffers from sr_host_alloc are page-locked, which lets the copies run at
+ * PCIe rate and truly overlap -- any host memory is accepted. */
+int sr_set_pipeline(sr_ctx* ctx, int enabled);         /* default: enabled */
+int sr_host_alloc(void** out, size_t bytes);           /* SR_E_NO_DEVICE without a GPU */
+void sr_host_free(void* p);
+
 /* Same two operations on buffers already resident in this context's device
  * memory (HBM); asynchronous on `stream` (opaque hipStream_t; NULL = HIP's
  * default stream, which is also torch's default stream).  The caller orders
@@ -142,7 +153,9 @@ int sr_read_feature(sr_ctx* ctx, int which, float* out_host, size_t cap_floats);
 
 /* Device time of the most recent call, measured with HIP events on the stream
  * the kernels ran on.  stage_ms[5] = conv0, l1, l2, l3, expand stage kernels
- * (enable with sr_set_profiling; off by default -- it inserts events).
+ * (enable with sr_set_profiling; off by default -- it inserts events, and the host-pointer
+ * entry points then run undivided).  After a pipelined host call total / h2d / d2h are sums
+ * over the chunks and sr_read_feature refuses (the maps hold the last chunk only).
  * h2d / d2h are zero for the *_dev entry points. */
 int sr_set_profiling(sr_ctx* ctx, int enabled);
 int sr_last_timing(sr_ctx* ctx, double* total_ms, double stage_ms[5], double* h2d_ms,

@@ -42,6 +42,9 @@ extern "C" {
     pub fn sr_upscale_band_rgba8_dev(ctx: *mut SrCtx, d_in: *const u8, in_channels: c_int, h_ext: c_int, w: c_int,
                                      halo_top: c_int, halo_bot: c_int, d_out: *mut u8, stream: *mut c_void) -> c_int;
     pub fn sr_read_feature(ctx: *mut SrCtx, which: c_int, out_host: *mut f32, cap_floats: usize) -> c_int;
+    pub fn sr_set_pipeline(ctx: *mut SrCtx, enabled: c_int) -> c_int;
+    pub fn sr_host_alloc(out: *mut *mut c_void, bytes: usize) -> c_int;  // page-locked host memory
+    pub fn sr_host_free(p: *mut c_void);
     pub fn sr_set_profiling(ctx: *mut SrCtx, enabled: c_int) -> c_int;
     pub fn sr_last_timing(ctx: *mut SrCtx, total_ms: *mut f64, stage_ms: *mut f64, h2d_ms: *mut f64, d2h_ms: *mut f64) -> c_int;
     pub fn sr_device_info(ctx: *mut SrCtx, name: *mut c_char, cap: usize, cus: *mut c_int, mhz: *mut c_int) -> c_int;

@@ -34,6 +34,9 @@ SYMBOLS = {
     "sr_upscale_band_rgba8_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_read_feature": (_i, [_vp, _i, _fp, _sz]),
     "sr_set_precision": (_i, [_vp, _i]),
+    "sr_set_pipeline": (_i, [_vp, _i]),
+    "sr_host_alloc": (_i, [C.POINTER(_vp), _sz]),
+    "sr_host_free": (None, [_vp]),
     "sr_set_profiling": (_i, [_vp, _i]),
     "sr_last_timing": (_i, [_vp, _dp, _dp, _dp, _dp]),
     "sr_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_i)]),

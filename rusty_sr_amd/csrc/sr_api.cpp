@@ -176,8 +176,14 @@ struct sr_ctx {
     int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
     uint32_t* d_voff = nullptr;   // 2 x kVoffEntries LDS-DMA gather offsets (5x5 tile, 3x3 tile)
     int voff_pitch = 0, voff_th = 0;
-    void* d_in = nullptr;  size_t in_cap = 0;    // staging for the host-pointer entry points
-    void* d_out = nullptr; size_t out_cap = 0;
+    // host-pointer entry points: two in / out slots so that chunk i+1 uploads and chunk i-1
+    // downloads while chunk i computes (run_host)
+    void* d_in[2] = {nullptr, nullptr};  size_t in_cap[2] = {0, 0};
+    void* d_out[2] = {nullptr, nullptr}; size_t out_cap[2] = {0, 0};
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    std::vector<hipEvent_t> pool;  // per-chunk timing / ordering events of run_host, grown on demand
+    int pipeline = 1;              // 0: one upload, one pass, one download
+    int last_chunks = 0;
     hipEvent_t ev[8] = {nullptr};
     bool profiling = false;
     double total_ms = 0, stage_ms[5] = {0}, h2d_ms = 0, d2h_ms = 0;
@@ -274,6 +280,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         c->cus = prop.multiProcessorCount;
         c->clock_mhz = prop.clockRate / 1000;
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
         for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
 
         if (graph != SR_GRAPH_SR_NET) return SR_OK;  // parameter-free graphs need nothing else
@@ -342,9 +350,12 @@ void sr_destroy(sr_ctx* c) {
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_voff) (void)hipFree(c->d_voff);
     if (c->d_queue) (void)hipFree(c->d_queue);
-    if (c->d_in) (void)hipFree(c->d_in);
-    if (c->d_out) (void)hipFree(c->d_out);
+    for (auto& p : c->d_in) if (p) (void)hipFree(p);
+    for (auto& p : c->d_out) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->pool) if (e) (void)hipEventDestroy(e);
+    if (c->copy_in) { (void)hipStreamSynchronize(c->copy_in); (void)hipStreamDestroy(c->copy_in); }
+    if (c->copy_out) { (void)hipStreamSynchronize(c->copy_out); (void)hipStreamDestroy(c->copy_out); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -359,6 +370,26 @@ int sr_set_precision(sr_ctx* c, int mode) {
     if (!c || (mode != SR_PRECISION_F32 && mode != SR_PRECISION_SPLIT_F16)) return SR_E_INVALID;
     c->precision = mode;
     return SR_OK;
+}
+
+int sr_set_pipeline(sr_ctx* c, int enabled) {
+    if (!c) return SR_E_INVALID;
+    c->pipeline = enabled != 0;
+    return SR_OK;
+}
+
+int sr_host_alloc(void** out, size_t bytes) {
+    if (!out || bytes == 0) return SR_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SR_E_NO_DEVICE;
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) { *out = nullptr; return e == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP; }
+    return SR_OK;
+}
+
+void sr_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int sr_set_profiling(sr_ctx* c, int enabled) {
@@ -528,32 +559,125 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     return SR_OK;
 }
 
+// One unit of the host pipeline: a whole image of a batch, or a row band of a single image
+// with the halo rows it needs (band == untiled bit for bit, see sr_upscale_band_*).
+struct Chunk {
+    size_t in_off, in_bytes, out_off, out_bytes;
+    int n, h_ext, halo_top, halo_bot;
+};
+
+// Split the job.  Batches go image by image.  A single large sr_net image goes as row bands that
+// all have the SAME extended height E (so the zero borders of the feature maps stay valid and
+// nothing is re-cleared between chunks): band k owns rows [y0,y1) and carries the E rows
+// [start, start+E) with start = clamp(y0 - SR_HALO, 0, h - E).
+std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_px_bytes, size_t out_px_bytes) {
+    std::vector<Chunk> plan;
+    const int f = c->factor;
+    const size_t in_img = (size_t)h * w * in_px_bytes;
+    const size_t out_img = c->graph == SR_GRAPH_DOWNSAMPLE ? (size_t)(h / 3) * (w / 3) * out_px_bytes
+                                                           : (size_t)h * f * w * f * out_px_bytes;
+    const bool pipe = c->pipeline && !c->profiling;  // per-stage profiling times one undivided pass
+    const int per = (int)std::max<size_t>(1, ((size_t)1 << 20) / ((size_t)h * w));  // images per chunk: ~1M px of work
+    if (pipe && n > per) {
+        for (int i = 0; i < n; i += per) {
+            const int m = std::min(per, n - i);
+            plan.push_back({i * in_img, m * in_img, i * out_img, m * out_img, m, h, 0, 0});
+        }
+        return plan;
+    }
+    int bands = 1;
+    if (pipe && n == 1 && c->graph == SR_GRAPH_SR_NET && (size_t)h * w >= ((size_t)1 << 19)) {
+        bands = h / 192;  // >= 192 own rows per band keeps the 14 recomputed rows under 7.5 %
+        if (bands > 8) bands = 8;
+    }
+    if (bands >= 2) {
+        const int rows = (h + bands - 1) / bands, E = rows + 2 * SR_HALO;
+        bool ok = E <= h;
+        for (int k = 0; k < bands && ok; ++k) {
+            const int y0 = k * rows, y1 = std::min(h, y0 + rows);
+            int start = std::max(0, y0 - SR_HALO);
+            if (start > h - E) start = h - E;
+            const int ht = y0 - start, hb = start + E - y1;
+            ok = y1 > y0 && (ht == 0 || ht >= SR_HALO) && (hb == 0 || hb >= SR_HALO) && (ht == 0) == (y0 == 0) &&
+                 (hb == 0) == (y1 == h);
+            plan.push_back({(size_t)start * w * in_px_bytes, (size_t)E * w * in_px_bytes,
+                            (size_t)y0 * f * w * f * out_px_bytes, (size_t)(y1 - y0) * f * w * f * out_px_bytes, 1, E, ht, hb});
+        }
+        if (ok) return plan;
+        plan.clear();
+    }
+    plan.push_back({0, (size_t)n * in_img, 0, (size_t)n * out_img, n, h, 0, 0});
+    return plan;
+}
+
+// Host-pointer entry points: upload, conv stack, download -- software-pipelined over chunks on
+// three streams.  Issue order is H2D(i+1), kernels(i+1), D2H(i): with pageable caller memory the
+// runtime blocks the calling thread inside each copy, and this order keeps kernels queued behind
+// it; with pinned memory (sr_host_alloc) all three engines run concurrently.
 int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, int w, void* out, bool out_u8) {
     if (!c || !in || !out || n <= 0 || h <= 0 || w <= 0) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    if (c->graph == SR_GRAPH_DOWNSAMPLE && (h < 3 || w < 3)) return SR_E_INVALID;
+    if (c->graph != SR_GRAPH_SR_NET && img_u8 != out_u8) return SR_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t npx = (size_t)n * h * w;
-    const size_t in_bytes = npx * (img_u8 ? (size_t)img_ch : 3 * sizeof(float));
-    const size_t out_px = c->graph == SR_GRAPH_DOWNSAMPLE ? (size_t)n * (h / 3) * (w / 3) : npx * c->factor * c->factor;
-    const size_t out_bytes = out_px * (out_u8 ? 4 : 3 * sizeof(float));
-    int rc = ensure_buf(c, &c->d_in, &c->in_cap, in_bytes);
-    if (rc == SR_OK) rc = ensure_buf(c, &c->d_out, &c->out_cap, out_bytes);
+    const size_t in_px = img_u8 ? (size_t)img_ch : 3 * sizeof(float), out_px = out_u8 ? 4 : 3 * sizeof(float);
+    const std::vector<Chunk> plan = plan_chunks(c, n, h, w, in_px, out_px);
+    const int nch = (int)plan.size();
+    const int slots = nch > 1 ? 2 : 1;
+    size_t in_max = 0, out_max = 0;
+    for (const Chunk& k : plan) { in_max = std::max(in_max, k.in_bytes); out_max = std::max(out_max, k.out_bytes); }
+    for (int sl = 0; sl < slots; ++sl) {
+        int rc = ensure_buf(c, &c->d_in[sl], &c->in_cap[sl], in_max);
+        if (rc == SR_OK) rc = ensure_buf(c, &c->d_out[sl], &c->out_cap[sl], out_max);
+        if (rc != SR_OK) return rc;
+    }
+    // events per chunk: 0 upload begins, 1 upload done, 2 kernels begin, 3 kernels done, 4 download done
+    while (c->pool.size() < (size_t)nch * 5) {
+        hipEvent_t e = nullptr;
+        HIPCHK(c, hipEventCreate(&e));
+        c->pool.push_back(e);
+    }
+    auto ev = [&](int i, int k) { return c->pool[(size_t)i * 5 + k]; };
+    const char* src = (const char*)in;
+    char* dst = (char*)out;
+    auto issue_front = [&](int i) -> int {  // upload + kernels of chunk i
+        const Chunk& k = plan[i];
+        const int sl = i % slots;
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->copy_in, ev(i - 2, 3), 0));  // slot's previous reader
+        HIPCHK(c, hipEventRecord(ev(i, 0), c->copy_in));
+        HIPCHK(c, hipMemcpyAsync(c->d_in[sl], src + k.in_off, k.in_bytes, hipMemcpyHostToDevice, c->copy_in));
+        HIPCHK(c, hipEventRecord(ev(i, 1), c->copy_in));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, ev(i, 1), 0));
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, ev(i - 2, 4), 0));   // slot's previous download
+        HIPCHK(c, hipEventRecord(ev(i, 2), c->stream));
+        const int rc = run_stack(c, c->d_in[sl], img_u8, img_ch, k.n, k.h_ext, w, k.halo_top, k.halo_bot, c->d_out[sl],
+                                 out_u8, c->stream);
+        if (rc != SR_OK) return rc;
+        HIPCHK(c, hipEventRecord(ev(i, 3), c->stream));
+        return SR_OK;
+    };
+    int rc = issue_front(0);
+    for (int i = 0; i < nch && rc == SR_OK; ++i) {
+        if (i + 1 < nch) rc = issue_front(i + 1);
+        if (rc != SR_OK) break;
+        HIPCHK(c, hipStreamWaitEvent(c->copy_out, ev(i, 3), 0));
+        HIPCHK(c, hipMemcpyAsync(dst + plan[i].out_off, c->d_out[i % slots], plan[i].out_bytes, hipMemcpyDeviceToHost, c->copy_out));
+        HIPCHK(c, hipEventRecord(ev(i, 4), c->copy_out));
+    }
+    // drain everything before returning, also on failure: the caller's buffers must not be in flight
+    const hipError_t e1 = hipStreamSynchronize(c->copy_in), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->copy_out);
     if (rc != SR_OK) return rc;
-    hipStream_t s = c->stream;
-    HIPCHK(c, hipEventRecord(c->ev[6], s));
-    HIPCHK(c, hipMemcpyAsync(c->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipEventRecord(c->ev[7], s));
-    rc = run_stack(c, c->d_in, img_u8, img_ch, n, h, w, 0, 0, c->d_out, out_u8, s);
-    if (rc != SR_OK) return rc;
-    hipEvent_t k_end = c->ev[5];
-    HIPCHK(c, hipEventRecord(k_end, s));
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out, out_bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipEventRecord(c->ev[0], s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    float ms = 0;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[7])); c->h2d_ms = ms;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[7], k_end));    c->total_ms = ms;
-    HIPCHK(c, hipEventElapsedTime(&ms, k_end, c->ev[0]));    c->d2h_ms = ms;
+    HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
+    double h2d = 0, ker = 0, d2h = 0;
+    for (int i = 0; i < nch; ++i) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, ev(i, 0), ev(i, 1))); h2d += ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, ev(i, 2), ev(i, 3))); ker += ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, ev(i, 3), ev(i, 4))); d2h += ms;  // includes waiting for the copy engine
+    }
+    c->h2d_ms = h2d; c->total_ms = ker; c->d2h_ms = d2h;
+    c->last_chunks = nch;
+    if (nch > 1) c->last_h = c->last_w = 0;  // the feature maps hold one chunk only: sr_read_feature refuses
     return SR_OK;
 }
 

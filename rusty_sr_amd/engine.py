@@ -103,15 +103,21 @@ class Engine:
         _lib.check(self._L.sr_upscale_f32(self._ctx, x.ctypes.data_as(fp), n, h, w, out.ctypes.data_as(fp)), self._ctx)
         return out[0] if squeeze else out
 
-    def upscale_rgba8(self, px: np.ndarray) -> np.ndarray:
-        """(n,H,W,3|4) or (H,W,3|4) u8 -> (n,3H,3W,4) u8 RGBA (alpha 255)."""
+    def upscale_rgba8(self, px: np.ndarray, out: np.ndarray = None) -> np.ndarray:
+        """(n,H,W,3|4) or (H,W,3|4) u8 -> (n,3H,3W,4) u8 RGBA (alpha 255).  `out` may be a
+        page-locked array from host_alloc (copies then overlap the kernels at PCIe rate)."""
         px = np.ascontiguousarray(px, dtype=np.uint8)
         squeeze = px.ndim == 3
         if squeeze:
             px = px[None]
         n, h, w, c = px.shape
         oh, ow = self._out_hw(h, w)
-        out = np.empty((n, oh, ow, 4), dtype=np.uint8)
+        if out is None:
+            out = np.empty((n, oh, ow, 4), dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.size != n * oh * ow * 4 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous u8 array of n*oh*ow*4 elements")
+        else:
+            out = out.reshape(n, oh, ow, 4)
         u8p = C.POINTER(C.c_uint8)
         _lib.check(self._L.sr_upscale_rgba8(self._ctx, px.ctypes.data_as(u8p), c, n, h, w, out.ctypes.data_as(u8p)), self._ctx)
         return out[0] if squeeze else out
@@ -179,6 +185,11 @@ class Engine:
         _lib.check(self._L.sr_read_feature(self._ctx, which, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), self._ctx)
         return out
 
+    def set_pipeline(self, on: bool):
+        """Host-pointer entry points: chunked upload / compute / download overlap (default on);
+        results do not depend on it."""
+        _lib.check(self._L.sr_set_pipeline(self._ctx, 1 if on else 0))
+
     def set_profiling(self, on: bool):
         _lib.check(self._L.sr_set_profiling(self._ctx, int(on)))
 
@@ -193,6 +204,33 @@ class Engine:
         cus, mhz = C.c_int(), C.c_int()
         _lib.check(self._L.sr_device_info(self._ctx, name, 128, C.byref(cus), C.byref(mhz)))
         return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value}
+
+
+class PinnedBuffer:
+    """Page-locked host memory from sr_host_alloc, exposed as a numpy array (`.array`)."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self._L = _lib.lib()
+        self._p = C.c_void_p()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        _lib.check(self._L.sr_host_alloc(C.byref(self._p), nbytes))
+        self.array = np.frombuffer((C.c_char * nbytes).from_address(self._p.value), dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._L.sr_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_alloc(shape, dtype=np.uint8) -> PinnedBuffer:
+    return PinnedBuffer(shape, dtype)
 
 
 class Graph:

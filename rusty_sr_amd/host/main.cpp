@@ -144,9 +144,14 @@ int main(int argc, char** argv) {
     if (graph == SR_GRAPH_DOWNSAMPLE && (in.w < 3 || in.h < 3)) die("input image is smaller than one 3x3 pooling block");
 
     const int ow = graph == SR_GRAPH_DOWNSAMPLE ? in.w / 3 : in.w * 3, oh = graph == SR_GRAPH_DOWNSAMPLE ? in.h / 3 : in.h * 3;
-    std::vector<uint8_t> out((size_t)ow * oh * 4);
+    // page-locked output pixels: the download then runs at PCIe rate under the kernels of the next band
+    const size_t out_bytes = (size_t)ow * oh * 4;
+    void* pinned = nullptr;
+    std::vector<uint8_t> pageable;
+    if (sr_host_alloc(&pinned, out_bytes) != SR_OK) { pinned = nullptr; pageable.resize(out_bytes); }
+    uint8_t* out = pinned ? (uint8_t*)pinned : pageable.data();
     // img_to_data + graph.forward + data_to_img(..).to_rgba(), fused on the device (main.rs:168-175)
-    rc = sr_upscale_rgba8(ctx, in.rgba.data(), 4, 1, in.h, in.w, out.data());
+    rc = sr_upscale_rgba8(ctx, in.rgba.data(), 4, 1, in.h, in.w, out);
     if (rc != SR_OK) die(std::string(sr_strerror(rc)) + (rc == SR_E_HIP ? " (hipError " + std::to_string(sr_last_hip_error(ctx)) + ")" : ""));
     if (timing) {
         double tot = 0, h2d = 0, d2h = 0;
@@ -155,8 +160,9 @@ int main(int argc, char** argv) {
     }
     printf(" Writing file...");
     fflush(stdout);
-    if (!srpng::encode_file(pos[1], out.data(), ow, oh, err)) die("Could not write output file (" + err + ")");  // main.rs:175
+    if (!srpng::encode_file(pos[1], out, ow, oh, err)) die("Could not write output file (" + err + ")");  // main.rs:175
     puts(" Done");
+    sr_host_free(pinned);
     sr_destroy(ctx);
     return 0;
 }

@@ -213,6 +213,56 @@ def test_full_size_properties_1080p(engines, params):
     assert torch.equal(out8[..., :3], q) and bool((out8[..., 3] == 255).all())
 
 
+@pytest.mark.parametrize("h,w", [(1080, 1920), (577, 911), (399, 1400), (2000, 270)])
+def test_host_pipeline_bands_are_bit_identical(engines, h, w):
+    """sr_upscale_* on host pointers splits a large image into row bands (upload / kernels /
+    download overlap); the result must equal the undivided pass bit for bit, f32 and u8,
+    pageable and page-locked (sr_host_alloc) destinations alike."""
+    import rusty_sr_amd as r
+    from rusty_sr_amd.engine import host_alloc
+    eng = engines["imagenet"]
+    px = synth_u8(h + w, 1, h, w)[0]
+    x = oracle.img_to_data(px)
+    try:
+        eng.set_pipeline(False)
+        want32, want8 = eng.upscale_f32(x), eng.upscale_rgba8(px)
+        assert eng.read_feature(0, h, w).shape == (h, w, 32)   # allowed after an undivided pass
+        eng.set_pipeline(True)
+        got32, got8 = eng.upscale_f32(x), eng.upscale_rgba8(px)
+        t = eng.last_timing()
+        assert t["total_ms"] > 0 and t["h2d_ms"] > 0 and t["d2h_ms"] > 0
+        with pytest.raises(r.SrError):      # feature maps hold the last band only
+            eng.read_feature(0, h, w)
+        pin = host_alloc((3 * h, 3 * w, 4))
+        got8p = eng.upscale_rgba8(px, out=pin.array).copy()
+        pin.close()
+    finally:
+        eng.set_pipeline(True)
+    np.testing.assert_array_equal(got32, want32)
+    np.testing.assert_array_equal(got8, want8)
+    np.testing.assert_array_equal(got8p, want8)
+
+
+def test_host_pipeline_batch_chunks(engines, params):
+    """A batch goes through the host pipeline in chunks of whole images (ragged last chunk);
+    every image equals its own single-image call, and config D's shape (n x 512 x 512) works."""
+    eng = engines["imagenet"]
+    for (n, h, w) in ((25, 300, 300), (7, 64, 64), (9, 512, 512)):
+        px = synth_u8(n * h, n, h, w)
+        got = eng.upscale_rgba8(px)
+        eng.set_pipeline(False)
+        try:
+            want = eng.upscale_rgba8(px)
+            one = eng.upscale_rgba8(px[n - 1])
+        finally:
+            eng.set_pipeline(True)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got[n - 1], one)
+    x = oracle.img_to_data(synth_u8(3, 21, 200, 280))   # 56K px per image -> chunks of 18 + 3
+    got = eng.upscale_f32(x)
+    assert np.abs(got[20] - oracle.forward(params["imagenet"], x[20:21])[0]).max() < TOL
+
+
 def test_bilinear_and_downsample_graphs(params):
     """The two parameter-free graphs of upscale() (`-p bilinear`, `-d`; network.rs:111-138)."""
     import rusty_sr_amd as r
