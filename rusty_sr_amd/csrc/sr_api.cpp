@@ -174,8 +174,8 @@ struct sr_ctx {
     int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
     int pitch = 0; long img_stride = 0;
     int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
-    uint32_t* d_voff = nullptr;   // 2 x kVoffEntries LDS-DMA gather offsets (5x5 tile, 3x3 tile)
-    int voff_pitch = 0, voff_th = 0;
+    uint32_t* d_voff = nullptr;   // 4 x kVoffEntries LDS-DMA gather offsets (tile height 8 / 4: 5x5 tile, 3x3 tile)
+    int voff_pitch = 0;
     // host-pointer entry points: two in / out slots so that chunk i+1 uploads and chunk i-1
     // downloads while chunk i computes (run_host)
     void* d_in[2] = {nullptr, nullptr};  size_t in_cap[2] = {0, 0};
@@ -438,20 +438,21 @@ int ensure_features(sr_ctx* c, int n, int H, int W, int tiles_x, hipStream_t s) 
 // LDS-DMA gather tables for this row pitch: entry P = byte offset of tile pixel P
 // (row-major in the TWH-wide halo tile) from the tile origin; padding entries read
 // the origin (harmless) and land in the unused tail of the LDS plane.
-int ensure_voff(sr_ctx* c, int th, hipStream_t s) {
-    if (c->d_voff && c->voff_pitch == c->pitch && c->voff_th == th) return SR_OK;
-    if (!c->d_voff) HIPCHK(c, hipMalloc((void**)&c->d_voff, 2 * kVoffEntries * sizeof(uint32_t)));
-    std::vector<uint32_t> t(2 * kVoffEntries, 0u);
-    const int ks[2] = {5, 3};
-    for (int k = 0; k < 2; ++k) {
-        const int r = ks[k] / 2, twh = 32 + 2 * r, thh = th + 2 * r;
-        for (int P = 0; P < twh * thh && P < kVoffEntries; ++P)
-            t[k * kVoffEntries + P] = (uint32_t)(((size_t)(P / twh) * c->pitch + (P % twh)) * 128);
-    }
+int ensure_voff(sr_ctx* c, hipStream_t s) {
+    if (c->d_voff && c->voff_pitch == c->pitch) return SR_OK;
+    if (!c->d_voff) HIPCHK(c, hipMalloc((void**)&c->d_voff, 4 * kVoffEntries * sizeof(uint32_t)));
+    std::vector<uint32_t> t(4 * kVoffEntries, 0u);  // [th = 8: 5x5, 3x3][th = 4: 5x5, 3x3]
+    const int ks[2] = {5, 3}, ths[2] = {8, 4};
+    for (int v = 0; v < 2; ++v)
+        for (int k = 0; k < 2; ++k) {
+            const int r = ks[k] / 2, twh = 32 + 2 * r, thh = ths[v] + 2 * r;
+            for (int P = 0; P < twh * thh && P < kVoffEntries; ++P)
+                t[(v * 2 + k) * kVoffEntries + P] = (uint32_t)(((size_t)(P / twh) * c->pitch + (P % twh)) * 128);
+        }
     // pageable-host async copy is staged by the runtime before it returns
     HIPCHK(c, hipMemcpyAsync(c->d_voff, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    c->voff_pitch = c->pitch; c->voff_th = th;
+    c->voff_pitch = c->pitch;
     return SR_OK;
 }
 
@@ -495,9 +496,12 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     if (rc != SR_OK) return rc;
     // tile height: 8 rows when that still gives every CU two workgroups, else 4
     const long tiles8 = (long)n * tiles_x * ((bot - top + 7) / 8);
-    int th = tiles8 >= 2L * (c->cus > 0 ? c->cus : 256) ? 8 : 4;
-    if (const char* e = getenv("SRHIP_TH")) th = atoi(e) == 4 ? 4 : 8;  // experiment override
-    rc = ensure_voff(c, th, s);
+    const int th_all = tiles8 >= 2L * (c->cus > 0 ? c->cus : 256) ? 8 : 4;
+    int ths[5] = {th_all, th_all, th_all, th_all, th_all};
+    if (const char* e = getenv("SRHIP_TH")) {  // experiment override: one digit for all stages, or five
+        for (int k = 0; k < 5; ++k) { const char ch = strlen(e) == 5 ? e[k] : e[0]; ths[k] = ch == '4' ? 4 : 8; }
+    }
+    rc = ensure_voff(c, s);
     if (rc != SR_OK) return rc;
     const float* P = c->d_params;
     const bool prof = c->profiling;
@@ -511,6 +515,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
         int y0 = top - margin[st], y1 = bot + margin[st];
         if (y0 < 0) y0 = 0;
         if (y1 > H) y1 = H;
+        const int th = ths[st];
         const int tiles_y = (y1 - y0 + th - 1) / th;
         const int nblk = n * tiles_x * tiles_y;
         if (st == 0) {
@@ -523,7 +528,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
         } else {
             StageArgs a{};
             float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
-            a.voff5 = c->d_voff; a.voff3 = c->d_voff + kVoffEntries;
+            a.voff5 = c->d_voff + (th == 8 ? 0 : 2) * kVoffEntries; a.voff3 = a.voff5 + kVoffEntries;
             a.pitch = c->pitch; a.img_stride = c->img_stride;
             switch (st) {
                 case 1: a.src[0] = f; a.dst = l1; break;
