@@ -72,7 +72,7 @@ def pmc_traffic(stage, H, W, precision="f32"):
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         for name, v in d.items():
-            tag = ", 0, false, 4>" if precision == "f32" else ", 1, true, 4>"
+            tag = ", 0, false, 4" if precision == "f32" else ", 1, true, 4"
             if STAGE_KERNEL[stage] in name and tag in name and "hbm_read_bytes" in v:
                 return {"hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v.get("hbm_write_bytes", 0)),
                         "algorithmic_bytes_per_launch": int(H * W * 128 * (min(stage, 3) + 1)),
@@ -139,11 +139,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; rusty_sr_amd has no CPU fallback")
+    # Rehearsal on a box with fewer GPUs than ranks (not a measurement): SRHIP_SHARE_GPU=1 folds the ranks
+    # onto the devices present and SRHIP_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks per device.
+    backend = os.environ.get("SRHIP_DIST_BACKEND", "nccl")
+    if os.environ.get("SRHIP_SHARE_GPU") == "1":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     H, W = args.height, args.width
     params = r.rsr.builtin(args.weights)
@@ -194,6 +202,8 @@ def main():
         "value": round(value, 2), "unit": "output MP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
+        **({"rehearsal": f"backend={backend}, ranks folded onto {torch.cuda.device_count()} device(s): not a measurement"}
+           if world > 1 and (backend != "nccl" or os.environ.get("SRHIP_SHARE_GPU") == "1") else {}),
         "dtype": "f32" if args.precision == "f32" else "f16x3 split (hi/lo half pairs, f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"{W}x{H} RGB x3 upscale per GPU, {args.weights}.rsr, {args.io} in/out resident in HBM"
                                + (f"; {world} row bands of one {W}x{H * world} image, 7-row RCCL halo exchange per step"

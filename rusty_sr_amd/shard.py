@@ -52,6 +52,9 @@ class BandExchange:
         self.band_rows = band_rows
         # band lives in the middle of one buffer so the received halos land in place
         self.ext = torch.zeros((self.top + band_rows + self.bot, width, channels), dtype=dtype, device=device)
+        # gloo has no device-memory point-to-point: stage the 7-row halos through host memory then
+        # (CPU tests, and the single-GPU rehearsal of bench.py --gpus N); RCCL sends from HBM directly
+        self._staged = (world > 1 and self.ext.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo")
 
     @property
     def band(self) -> torch.Tensor:
@@ -63,14 +66,23 @@ class BandExchange:
             return self.ext
         h, ops = self.halo, []
         band = self.band
+        via = (lambda t: t.cpu()) if self._staged else (lambda t: t)
+        landing = []  # (host tensor, device destination) pairs of the staged path
+        def recv_into(dst):
+            if not self._staged:
+                return dst
+            landing.append((torch.empty(dst.shape, dtype=dst.dtype), dst))
+            return landing[-1][0]
         if self.rank > 0:
-            ops.append(dist.P2POp(dist.isend, band[:h], self._peer(self.rank - 1), self.group))
-            ops.append(dist.P2POp(dist.irecv, self.ext[:h], self._peer(self.rank - 1), self.group))
+            ops.append(dist.P2POp(dist.isend, via(band[:h]), self._peer(self.rank - 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, recv_into(self.ext[:h]), self._peer(self.rank - 1), self.group))
         if self.rank < self.world - 1:
-            ops.append(dist.P2POp(dist.isend, band[-h:], self._peer(self.rank + 1), self.group))
-            ops.append(dist.P2POp(dist.irecv, self.ext[-h:], self._peer(self.rank + 1), self.group))
+            ops.append(dist.P2POp(dist.isend, via(band[-h:]), self._peer(self.rank + 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, recv_into(self.ext[-h:]), self._peer(self.rank + 1), self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        for host, dst in landing:
+            dst.copy_(host)
         return self.ext
 
     def _peer(self, group_rank: int) -> int:

@@ -1,0 +1,49 @@
+"""bench.py's one-line JSON contract, on the GPU: N=1 with roofline + cpu_baseline objects, and a
+2-rank rehearsal of the sharded path (gloo, both ranks folded onto the one GPU of the test box --
+RCCL refuses two ranks per device; the driver's real N>1 runs use RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--height", "360", "--width", "640"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"]
+    assert abs(d["value"] - 9 * 360 * 640 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_bench_two_rank_rehearsal():
+    env = dict(os.environ, SRHIP_DIST_BACKEND="gloo", SRHIP_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--height", "360", "--width", "640"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "rowband2" and "rehearsal" in d
+    assert d["config"]["image"] == [720, 640]
+    assert abs(d["value"] - 2 * 9 * 360 * 640 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
