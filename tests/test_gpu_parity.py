@@ -2,11 +2,13 @@
 CPU oracle on identical inputs.  Bar (BASELINE.json north_star): every output channel
 within 1e-4 f32 of the CPU path before quantisation; u8 outputs may differ only at
 rounding knife-edges."""
+import os
+
 import numpy as np
 import pytest
 
 import oracle
-from conftest import load_png, synth_u8
+from conftest import GOLDEN, load_png, synth_u8
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +62,24 @@ def test_per_stage_features(engines, params, name):
         err = np.abs(feat - taps[key]).max()
         assert err < TIGHT * max(1.0, np.abs(taps[key]).max()), (key, err)
     assert np.abs(got - want).max() < TIGHT
+
+
+@pytest.mark.parametrize("case", ["crop", "border", "one", "twothree"])
+def test_against_second_restatement_vectors(engines, case):
+    """The committed torch-float64 node vectors (tests/golden/make_vectors.py), without the C oracle in
+    the loop: every node of the graph on the GPU against an independent restatement."""
+    v = np.load(os.path.join(GOLDEN, "vectors_torch_f64.npz"))
+    eng = engines[str(v[f"{case}.weights"])]
+    px = v[f"{case}.px"]
+    h, w = px.shape[:2]
+    got = eng.upscale_f32(oracle.img_to_data(px))
+    assert np.abs(got - v[f"{case}.out"]).max() < TIGHT
+    for k, key in enumerate(("f", "l1", "l2", "l3")):
+        want = v[f"{case}.{key}"]
+        feat = eng.read_feature(k, h, w)
+        feat = feat[..., ::4] if want.shape[-1] == 8 else feat
+        assert np.abs(feat - want).max() < TIGHT * max(1.0, np.abs(want).max()), (case, key)
+    _check_u8(eng.upscale_rgba8(px), v[f"{case}.out"])
 
 
 def test_white_noise_stress(engines, params):

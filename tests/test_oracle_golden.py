@@ -139,3 +139,29 @@ def test_downsample_net_properties():
     rng = np.random.default_rng(3)
     x = rng.random((1, 11, 13, 3), dtype=np.float32)
     np.testing.assert_array_equal(oracle.downsample(x), oracle.downsample(x[:, :9, :12]))
+
+
+VEC_CASES = ("crop", "border", "one", "twothree")
+
+
+def load_vectors():
+    return np.load(os.path.join(GOLDEN, "vectors_torch_f64.npz"))
+
+
+@pytest.mark.parametrize("case", VEC_CASES)
+def test_second_restatement_vectors(params, case):
+    """tests/golden/vectors_torch_f64.npz (made by tests/golden/make_vectors.py) holds every node of
+    the graph computed by an independent restatement -- torch conv2d / interpolate in float64.  The C
+    oracle must agree node by node: in float64 to rounding of the f32 fixture, in float32 to
+    accumulation noise.  Covers zero padding on all four sides of every layer and the 1x1 / 2x3 clamps."""
+    v = load_vectors()
+    p = params[str(v[f"{case}.weights"])]
+    x = oracle.img_to_data(v[f"{case}.px"])
+    for f64, tol in ((True, 4e-7), (False, 1e-5)):
+        out, taps = oracle.forward_taps(p, x, f64=f64)
+        for k in ("f", "l1", "l2", "l3", "e"):
+            want = v[f"{case}.{k}"]
+            got = taps[k][..., ::4] if want.shape[-1] == 8 else taps[k]
+            assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), (case, k, f64)
+        assert out[0].shape == v[f"{case}.out"].shape
+        assert np.abs(out[0] - v[f"{case}.out"]).max() <= tol * 2, (case, "out", f64)
