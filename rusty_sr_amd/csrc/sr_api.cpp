@@ -174,8 +174,6 @@ struct sr_ctx {
     int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
     int pitch = 0; long img_stride = 0;
     int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
-    uint32_t* d_voff = nullptr;   // 4 x kVoffEntries LDS-DMA gather offsets (tile height 8 / 4: 5x5 tile, 3x3 tile)
-    int voff_pitch = 0;
     // host-pointer entry points: two in / out slots so that chunk i+1 uploads and chunk i-1
     // downloads while chunk i computes (run_host)
     void* d_in[2] = {nullptr, nullptr};  size_t in_cap[2] = {0, 0};
@@ -348,7 +346,6 @@ void sr_destroy(sr_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->d_feat) if (p) (void)hipFree(p);
     if (c->d_params) (void)hipFree(c->d_params);
-    if (c->d_voff) (void)hipFree(c->d_voff);
     if (c->d_queue) (void)hipFree(c->d_queue);
     for (auto& p : c->d_in) if (p) (void)hipFree(p);
     for (auto& p : c->d_out) if (p) (void)hipFree(p);
@@ -435,27 +432,6 @@ int ensure_features(sr_ctx* c, int n, int H, int W, int tiles_x, hipStream_t s) 
     return SR_OK;
 }
 
-// LDS-DMA gather tables for this row pitch: entry P = byte offset of tile pixel P
-// (row-major in the TWH-wide halo tile) from the tile origin; padding entries read
-// the origin (harmless) and land in the unused tail of the LDS plane.
-int ensure_voff(sr_ctx* c, hipStream_t s) {
-    if (c->d_voff && c->voff_pitch == c->pitch) return SR_OK;
-    if (!c->d_voff) HIPCHK(c, hipMalloc((void**)&c->d_voff, 4 * kVoffEntries * sizeof(uint32_t)));
-    std::vector<uint32_t> t(4 * kVoffEntries, 0u);  // [th = 8: 5x5, 3x3][th = 4: 5x5, 3x3]
-    const int ks[2] = {5, 3}, ths[2] = {8, 4};
-    for (int v = 0; v < 2; ++v)
-        for (int k = 0; k < 2; ++k) {
-            const int r = ks[k] / 2, twh = 32 + 2 * r, thh = ths[v] + 2 * r;
-            for (int P = 0; P < twh * thh && P < kVoffEntries; ++P)
-                t[(v * 2 + k) * kVoffEntries + P] = (uint32_t)(((size_t)(P / twh) * c->pitch + (P % twh)) * 128);
-        }
-    // pageable-host async copy is staged by the runtime before it returns
-    HIPCHK(c, hipMemcpyAsync(c->d_voff, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    c->voff_pitch = c->pitch;
-    return SR_OK;
-}
-
 int ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return SR_OK;
     if (*p) HIPCHK(c, hipFree(*p));
@@ -501,8 +477,6 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     if (const char* e = getenv("SRHIP_TH")) {  // experiment override: one digit for all stages, or five
         for (int k = 0; k < 5; ++k) { const char ch = strlen(e) == 5 ? e[k] : e[0]; ths[k] = ch == '4' ? 4 : 8; }
     }
-    rc = ensure_voff(c, s);
-    if (rc != SR_OK) return rc;
     const float* P = c->d_params;
     const bool prof = c->profiling;
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
@@ -524,11 +498,11 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
             a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
             a.pitch = c->pitch; a.img_stride = c->img_stride;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+            a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
             HIPCHK(c, sr_launch_conv0(a, th, c->precision, nblk, img_u8, s));
         } else {
             StageArgs a{};
             float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
-            a.voff5 = c->d_voff + (th == 8 ? 0 : 2) * kVoffEntries; a.voff3 = a.voff5 + kVoffEntries;
             a.pitch = c->pitch; a.img_stride = c->img_stride;
             switch (st) {
                 case 1: a.src[0] = f; a.dst = l1; break;
@@ -541,6 +515,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
             a.H = H; a.W = W; a.img_ch = img_ch;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.n_img = n; a.queue = c->d_queue + st * 8;
+            a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
             int grid = nblk;
             if (persist) {  // the workgroups that are co-resident: 2 per CU with 8-row tiles, 3 with 4-row tiles
                 const int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);

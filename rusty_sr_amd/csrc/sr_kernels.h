@@ -3,6 +3,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Division of a tile index by a launch constant d as multiply-high + add + shift (Granlund-Montgomery
+// round-up form): q = (mulhi(t, m) + t) >> s, exact for t < 2^31.  Scalar-ALU only on the device -- the
+// compiler's own expansion goes through v_rcp_f32 on the vector ALU, which the matrix pipe shares.
+struct TileDiv {
+    uint32_t m, s;
+};
+inline TileDiv make_tile_div(uint32_t d) {
+    TileDiv r{1u, 0u};
+    while ((1u << r.s) < d) ++r.s;
+    r.m = (uint32_t)(((uint64_t)1 << 32) * (((uint64_t)1 << r.s) - d) / d + 1);
+    return r;
+}
+
 struct Conv0Args {
     const void* img;      // n*H*W*3 f32, or n*H*W*img_ch u8
     const float* wpack;   // 25 taps x [cin/2][cout 32][2]  (cin 3 zero-padded to 4)
@@ -14,12 +27,11 @@ struct Conv0Args {
     long img_stride;      // feature-map image stride in pixels
     int y_begin, y_end;   // rows to compute
     int tiles_x, tiles_y;
+    TileDiv div_tpi, div_tx;
 };
 
 struct StageArgs {
     const float* src[3];  // NHWC 32-channel feature maps, zero-bordered (pointer to pixel (0,0))
-    const uint32_t* voff5; // LDS-DMA gather tables: byte offset of tile pixel P from the tile origin,
-    const uint32_t* voff3; //   36-wide (5x5 source) and 34-wide (3x3 source) tiles, 448 entries each
     const float* wpack;   // one 4 KB chunk per tap, sources concatenated: [cin/4][cout 32][4]
     const float* bias;    // 32 per N-tile (final stage: expand_bias in the triple layout, see sr_api.cpp)
     const float* beta;    // 32 (unused by the final stage)
@@ -32,6 +44,7 @@ struct StageArgs {
     int y_begin, y_end;
     int tiles_x, tiles_y;
     int n_img;            // images in the batch (tiles = n_img * tiles_x * tiles_y)
+    TileDiv div_tpi, div_tx;  // tile id -> (image, tile row, tile column) without a hardware divide
     int* queue;           // persistent form: 8 per-XCD tile-queue heads, zeroed before the launch
 };
 
@@ -40,7 +53,6 @@ struct StageArgs {
 // ever store inside [0,H) x [0,W), so the border keeps the reference's zero padding.
 constexpr int kFeatPad = 2;          // 5x5 halo
 constexpr int kFeatPadBottom = 12;   // last tile row may start at H-1: + 8 rows + 2 halo (+2 spare)
-constexpr int kVoffEntries = 448;    // 7 groups of 64 tile pixels
 
 struct AuxArgs {          // bilinear_net / downsample_net (parameter-free graphs)
     const void* img;      // n*H*W*3 f32 or n*H*W*img_ch u8

@@ -56,8 +56,15 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifdef SR_TIMELINE
 __device__ long long* g_tl;
 #define TL(k) do { if (threadIdx.x == 0) g_tl[(size_t)blockIdx.x * 16 + (k)] = (k) == 0 ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter(); } while (0)
+// end of the workgroup: wall clock (100 MHz) in slot 9, where it ran (XCC_ID << 32 | HW_ID) in slot 10
+#define TL_BEGIN() do { if (threadIdx.x == 0) g_tl[(size_t)blockIdx.x * 16 + 11] = (long long)wall_clock64(); } while (0)
+#define TL_END() do { if (threadIdx.x == 0) { g_tl[(size_t)blockIdx.x * 16 + 9] = (long long)wall_clock64(); \
+    g_tl[(size_t)blockIdx.x * 16 + 10] = ((long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32) | \
+        (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); } } while (0)
 #else
 #define TL(k) do {} while (0)
+#define TL_BEGIN() do {} while (0)
+#define TL_END() do {} while (0)
 #endif
 
 namespace {
@@ -109,6 +116,10 @@ __device__ __forceinline__ void store_belu_tile(float* base, const f32x16& acc, 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ int tile_div(int t, TileDiv d) {  // see make_tile_div
+    return (int)((__umulhi((uint32_t)t, d.m) + (uint32_t)t) >> d.s);
 }
 
 __device__ __forceinline__ float load_img(const void* img, int img_ch, bool u8, size_t px, int c) {
@@ -210,8 +221,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     const int i = lane & 31, h = lane >> 5;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n = bid / tiles_per_img, t = bid - n * tiles_per_img;
-    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
+    const int ty = tile_div(t, a.div_tx), tx = t - ty * a.tiles_x;
     const int x0 = tx * kTW, y0 = a.y_begin + ty * TH;
     const size_t img_px0 = (size_t)n * a.H * a.W;
 
@@ -302,25 +313,46 @@ struct TileGeom {
 // Stage one source tile (+halo) into LDS, planar [cin/4][pixel][16 B], by LDS-DMA
 // (no VGPR round trip, no VALU).  One instruction moves 16 bytes of 64 consecutive
 // tile pixels: lane l gathers channel group c of tile pixel P = 64 g + l from
-// `origin + voff[P] + 16 c`, and lands at plane c, slot P.  voff (host-built
-// table: ((P / TWH) * pitch + P % TWH) * 128) is the only per-lane operand; the
-// origin is wave-uniform.  The maps carry a zero border in HBM, so the
-// reference's zero padding (Padding::Same) needs no bounds test here.
+// `origin + off[P] + 16 c`, and lands at plane c, slot P.  off (TileOffsets below) is the
+// only per-lane operand; the origin is wave-uniform and 16 c is an instruction immediate.
+// The maps carry a zero border in HBM, so the reference's zero padding (Padding::Same)
+// needs no bounds test here.
+// Per-lane gather offsets of a tile: entry gi = byte offset of tile pixel P = 64 (wave + NW gi) + lane
+// from the tile origin, ((P / TWH) * pitch + P % TWH) * 128.  Computed once per workgroup (a dozen
+// VALU ops) and kept in registers: every later DMA then needs no vector ALU work at all, which
+// matters because a staging wave gets about one VALU issue slot per MFMA of its SIMD neighbour.
+// Padding slots (P >= NPIX) re-read the last pixel and land in the unused tail of the plane.
 template <int TH, int KS, int NW = 4>
-__device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, const uint32_t* __restrict__ voff,
+struct TileOffsets {
+    using G = TileGeom<TH, KS>;
+    static constexpr int N = (G::NG + NW - 1) / NW;
+    uint32_t v[N];
+    __device__ __forceinline__ void init(int pitch, int wave, int lane) {
+#pragma unroll
+        for (int gi = 0; gi < N; ++gi) {
+            const int P = min((wave + NW * gi) * 64 + lane, G::NPIX - 1);
+            const int prow = P / G::TWH, pcol = P - prow * G::TWH;
+            v[gi] = (uint32_t)(prow * pitch + pcol) * 128u;
+        }
+    }
+};
+
+template <int TH, int KS, int NW = 4>
+__device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, const TileOffsets<TH, KS, NW>& off,
                                            long img_stride, int pitch, int n, int y0, int x0, int wave, int lane) {
     using G = TileGeom<TH, KS>;
     const char* origin = (const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32);
 #pragma unroll
-    for (int gi = 0; gi < (G::NG + NW - 1) / NW; ++gi) {
+    for (int gi = 0; gi < TileOffsets<TH, KS, NW>::N; ++gi) {
         const int g = wave + NW * gi;  // wave-uniform
         if (g < G::NG) {
-            const uint32_t vo = voff[g * 64 + lane];
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(origin + c * 16 + vo),
-                    (__attribute__((address_space(3))) void*)(tile + c * G::PLANE + g * 1024), 16, 0, 0);
+            const char* gp = origin + off.v[gi];  // SGPR base + 32-bit VGPR offset: the saddr form, no 64-bit VALU add
+            // channel group c: the immediate offset applies to the global AND the LDS address
+#define SR_DMA16(c)                                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,                 \
+                                     (__attribute__((address_space(3))) void*)(tile + (c) * G::PLANE + g * 1024 - (c) * 16), 16, (c) * 16, 0)
+            SR_DMA16(0); SR_DMA16(1); SR_DMA16(2); SR_DMA16(3); SR_DMA16(4); SR_DMA16(5); SR_DMA16(6); SR_DMA16(7);
+#undef SR_DMA16
         }
     }
     TL(8);
@@ -332,8 +364,10 @@ __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__
 __device__ __forceinline__ void weight_chunk_async(char* ring_slot, const float* __restrict__ chunk,
                                                    int wave, int lane) {
     if (wave >= 4) return;  // 8-wave workgroups: waves 4-7 have nothing to move (their vmcnt waits pass at once)
+    // wave-uniform base + 32-bit lane offset: the saddr form, no per-chunk 64-bit VALU add
+    const char* base = (const char*)chunk + wave * 1024;
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(chunk + (wave * 64 + lane) * 4),
+        (const __attribute__((address_space(1))) void*)(base + (uint32_t)(lane * 16)),
         (__attribute__((address_space(3))) void*)(ring_slot + wave * 1024), 16, 0, 0);
 }
 
@@ -540,6 +574,12 @@ __device__ __forceinline__ int queue_resolve(int* queue, int xcd, int ntiles, in
 // workgroup slots sat empty between a retire and the next dispatch.
 template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, bool PERSIST, int NW, int FACTOR = 3>
 __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv_stage_kernel(StageArgs a) {
+    TL_BEGIN();
+    // Two workgroups share each SIMD.  A wave streaming MFMAs is the older one and wins every
+    // arbitration, leaving the other workgroup's prologue / staging / epilogue code roughly one
+    // issue slot per MFMA.  The matrix stream only needs one slot per 64 cycles, so everything
+    // that is not the tap loop runs at raised priority -- from the first instruction on.
+    __builtin_amdgcn_s_setprio(3);
     constexpr int T = TH / NW;  // tile rows per wave
     // The final stage has 3 f^2 expand channels (network.rs:37).  They are laid out in whole RGB
     // triples, 10 per 32-lane N-tile (so the u8 packing never straddles tiles): f = 2, 3 -> 1 tile,
@@ -563,22 +603,21 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
     for (int nt = 0; nt < NTN; ++nt) bias[nt] = a.bias[nt * 32 + i];
     const float beta = FINAL ? 0.f : a.beta[i];
 
+    TileOffsets<TH, KS0, NW> off0;
+    TileOffsets<TH, 3, NW> off3;
+    off0.init(a.pitch, wave, lane);
+    if constexpr (NSRC >= 2) off3.init(a.pitch, wave, lane);
     // request everything the first phase of tile `t` needs: weight chunks 0..3 and the first source tile
     int n = 0, x0 = 0, y0 = 0;
     auto request_tile = [&](int t) {
-        n = t / tiles_per_img;
-        const int r = t - n * tiles_per_img, ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        n = tile_div(t, a.div_tpi);
+        const int r = t - n * tiles_per_img, ty = tile_div(r, a.div_tx), tx = r - ty * a.tiles_x;
         x0 = tx * kTW; y0 = a.y_begin + ty * TH;
 #pragma unroll
         for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
-        stage_tile<TH, KS0, NW>(tile, a.src[0], KS0 == 5 ? a.voff5 : a.voff3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+        stage_tile<TH, KS0, NW>(tile, a.src[0], off0, a.img_stride, a.pitch, n, y0, x0, wave, lane);
     };
 
-    // Two workgroups share each SIMD.  A wave streaming MFMAs is the older one and
-    // wins every VALU arbitration, leaving the other workgroup's staging / epilogue
-    // code roughly one issue slot per MFMA.  The matrix stream only needs one slot
-    // per 64 cycles, so the non-MFMA phases run at raised priority.
-    __builtin_amdgcn_s_setprio(3);
     int cur;
     if constexpr (PERSIST) {
         if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
@@ -617,7 +656,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
         TL(3);
         if constexpr (NSRC >= 2) {
             __builtin_amdgcn_s_setprio(3);
-            stage_tile<TH, 3, NW>(tile, a.src[1], a.voff3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
+            stage_tile<TH, 3, NW>(tile, a.src[1], off3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
             ring_barrier<0>();
             __builtin_amdgcn_s_setprio(0);
             TL(4);
@@ -626,7 +665,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
         }
         if constexpr (NSRC >= 3) {
             __builtin_amdgcn_s_setprio(3);
-            stage_tile<TH, 3, NW>(tile, a.src[2], a.voff3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
+            stage_tile<TH, 3, NW>(tile, a.src[2], off3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
             ring_barrier<0>();
             __builtin_amdgcn_s_setprio(0);
             taps(std::integral_constant<int, 3>{});
@@ -725,6 +764,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
         TL(7);
         if (!more_tiles) break;
     }
+    TL_END();
 }
 
 // ---------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 #define SR_TIMELINE 1
 #include "../rusty_sr_amd/csrc/sr_kernels.hip"
 #include <algorithm>
+#include <map>
 #include <cstdio>
 #include <vector>
 int main(int argc, char** argv) {
@@ -13,18 +14,15 @@ int main(int argc, char** argv) {
     float *f[3], *dst, *w, *bias; void* out;
     for (auto& p : f) { hipMalloc(&p, npx * 128); hipMemset(p, 0, npx * 128); }
     hipMalloc(&dst, npx * 128); hipMalloc(&out, (size_t)H * W * 9 * 12);
-    std::vector<uint32_t> vt(2 * kVoffEntries, 0u);
-    for (int k = 0; k < 2; ++k) { const int r = k == 0 ? 2 : 1, twh = 32 + 2 * r, thh = th + 2 * r;
-        for (int P = 0; P < twh * thh; ++P) vt[k * kVoffEntries + P] = (uint32_t)(((size_t)(P / twh) * pitch + P % twh) * 128); }
-    uint32_t* dvoff; hipMalloc(&dvoff, vt.size() * 4); hipMemcpy(dvoff, vt.data(), vt.size() * 4, hipMemcpyHostToDevice);
     const size_t org = ((size_t)2 * pitch + 2) * 32;
     hipMalloc(&w, 43 * 4096); hipMemset(w, 0, 43 * 4096);
     hipMalloc(&bias, 256); hipMemset(bias, 0, 256);
     StageArgs a{};
     a.src[0] = f[0] + org; a.src[1] = f[1] + org; a.src[2] = f[2] + org; a.wpack = w; a.bias = bias; a.beta = bias; a.dst = dst + org;
-    a.voff5 = dvoff; a.voff3 = dvoff + kVoffEntries; a.pitch = pitch; a.img_stride = img_stride;
+    a.pitch = pitch; a.img_stride = img_stride;
     a.img = f[0]; a.out = out; a.H = H; a.W = W; a.img_ch = 3; a.y_begin = 0; a.y_end = H;
     a.tiles_x = W / 32; a.tiles_y = (H + th - 1) / th;
+    a.div_tpi = make_tile_div(a.tiles_x * a.tiles_y); a.div_tx = make_tile_div(a.tiles_x);
     int nblk = a.tiles_x * a.tiles_y; a.n_img = 1; int* dq; hipMalloc(&dq, 64); hipMemset(dq, 0, 64); a.queue = dq;
     long long* tl; hipMalloc(&tl, (size_t)nblk * 128);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
@@ -54,5 +52,36 @@ int main(int argc, char** argv) {
     std::sort(starts.begin(), starts.end());
     printf("  WG start times (100 MHz ticks): first %lld, p25 %lld, p50 %lld, p75 %lld, last %lld  => kernel ~%.1f us to last start\n",
            starts[0], starts[nblk / 4], starts[nblk / 2], starts[nblk * 3 / 4], starts[nblk - 1], starts[nblk - 1] / 100.0);
+    if (prec == 0) {
+        // slot occupancy per CU: how much of the kernel's span each CU spends with 2 (1, 0) workgroups resident
+        struct Ev { long long t; int d; };
+        std::map<long long, std::vector<Ev>> per_cu;
+        long long k_begin = h[11], k_end = 0; double prologue = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const long long s = h[b * 16 + 11], e = h[b * 16 + 9], id = h[b * 16 + 10];
+            prologue += (double)(h[b * 16 + 0] - s);
+            const long long hw = id & 0xffffffffLL, xcc = (id >> 32) & 0xf;
+            const long long cu = (xcc << 16) | (((hw >> 13) & 0x7) << 8) | (((hw >> 12) & 0x1) << 7) | ((hw >> 8) & 0xf);  // xcc, se, sh, cu
+            per_cu[cu].push_back({s, +1}); per_cu[cu].push_back({e, -1});
+            k_begin = std::min(k_begin, s); k_end = std::max(k_end, e);
+        }
+        double occ[4] = {0, 0, 0, 0}, gap_sum = 0; long long gaps = 0;
+        for (auto& kv : per_cu) {
+            auto& v = kv.second;
+            std::sort(v.begin(), v.end(), [](const Ev& a, const Ev& b) { return a.t < b.t || (a.t == b.t && a.d < b.d); });
+            int cur = 0; long long last = k_begin, last_end = -1;
+            for (auto& ev : v) {
+                occ[std::min(cur, 3)] += (double)(ev.t - last); last = ev.t;
+                if (ev.d < 0) last_end = ev.t; else if (last_end >= 0 && cur < 2) { gap_sum += (double)(ev.t - last_end); ++gaps; last_end = -1; }
+                cur += ev.d;
+            }
+            occ[0] += (double)(k_end - last);
+        }
+        const double span = (double)(k_end - k_begin) * per_cu.size();
+        printf("  %zu CUs seen; kernel span %.1f us; time with 0 / 1 / 2 / 3+ workgroups resident: %.1f %% / %.1f %% / %.1f %% / %.1f %%\n",
+               per_cu.size(), (k_end - k_begin) / 100.0, 100 * occ[0] / span, 100 * occ[1] / span, 100 * occ[2] / span, 100 * occ[3] / span);
+        printf("  retire -> next kernel entry on the same CU: mean %.2f us over %lld hand-overs; kernel entry -> first barrier: mean %.2f us\n",
+               gaps ? gap_sum / gaps / 100.0 : 0.0, gaps, prologue / nblk / 100.0);
+    }
     return 0;
 }
