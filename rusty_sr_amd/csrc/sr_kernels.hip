@@ -54,14 +54,22 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // Optional per-workgroup phase timestamps for scripts/timeline.hip (never compiled
 // into the product library).
 #ifdef SR_TIMELINE
+// Slots per workgroup: 0 wall clock at the first tile, 1..8 phase stamps (s_memtime) SUMMED over the tiles the
+// workgroup processed, relative to each tile's stamp 1 (so slot[k1] - slot[k0] = total time between the two
+// marks); 9 wall clock at the end, 10 where it ran (XCC_ID << 32 | HW_ID), 11 wall clock at kernel entry,
+// 12 tiles processed.
 __device__ long long* g_tl;
-#define TL(k) do { if (threadIdx.x == 0) g_tl[(size_t)blockIdx.x * 16 + (k)] = (k) == 0 ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter(); } while (0)
-// end of the workgroup: wall clock (100 MHz) in slot 9, where it ran (XCC_ID << 32 | HW_ID) in slot 10
+#define TL_DECL() long long tl_s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tl_n = 0
+#define TL(k) do { if ((k) == 0) { if (tl_n == 0 && threadIdx.x == 0) g_tl[(size_t)blockIdx.x * 16] = (long long)wall_clock64(); } \
+    else { tl_s[(k)] = (long long)__builtin_readcyclecounter(); \
+           if ((k) == 7) { for (int j_ = 1; j_ < 9; ++j_) tl_c[j_] += tl_s[j_] - tl_s[1]; ++tl_n; } } } while (0)
 #define TL_BEGIN() do { if (threadIdx.x == 0) g_tl[(size_t)blockIdx.x * 16 + 11] = (long long)wall_clock64(); } while (0)
 #define TL_END() do { if (threadIdx.x == 0) { g_tl[(size_t)blockIdx.x * 16 + 9] = (long long)wall_clock64(); \
     g_tl[(size_t)blockIdx.x * 16 + 10] = ((long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32) | \
-        (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); } } while (0)
+        (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); \
+    for (int j_ = 1; j_ < 9; ++j_) g_tl[(size_t)blockIdx.x * 16 + j_] = tl_c[j_]; g_tl[(size_t)blockIdx.x * 16 + 12] = tl_n; } } while (0)
 #else
+#define TL_DECL() do {} while (0)
 #define TL(k) do {} while (0)
 #define TL_BEGIN() do {} while (0)
 #define TL_END() do {} while (0)
@@ -355,7 +363,6 @@ __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__
 #undef SR_DMA16
         }
     }
-    TL(8);
 }
 
 // Asynchronous 4 KB weight-chunk copy global -> LDS ring slot (LDS-DMA, no VGPR
@@ -575,6 +582,7 @@ __device__ __forceinline__ int queue_resolve(int* queue, int xcd, int ntiles, in
 template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, bool PERSIST, int NW, int FACTOR = 3>
 __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv_stage_kernel(StageArgs a) {
     TL_BEGIN();
+    TL_DECL();
     // Two workgroups share each SIMD.  A wave streaming MFMAs is the older one and wins every
     // arbitration, leaving the other workgroup's prologue / staging / epilogue code roughly one
     // issue slot per MFMA.  The matrix stream only needs one slot per 64 cycles, so everything
@@ -685,6 +693,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
             more_tiles = cur >= 0;
             if (more_tiles) request_tile(cur);
         }
+        TL(8);
         {
         const int n = tn, x0 = tx0, y0 = ty0;
         const bool full_x = x0 + kTW <= a.W;

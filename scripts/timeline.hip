@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     int nblk = a.tiles_x * a.tiles_y; a.n_img = 1; int* dq; hipMalloc(&dq, 64); hipMemset(dq, 0, 64); a.queue = dq;
     long long* tl; hipMalloc(&tl, (size_t)nblk * 128);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
-    if (prec == 1) nblk = 512;  // persistent form: co-resident workgroups pull tiles from the queue
+    if (prec == 1 || getenv("TL_PERSIST")) nblk = 512;  // persistent form: co-resident workgroups pull tiles from the queue
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
@@ -53,7 +53,6 @@ int main(int argc, char** argv) {
     printf("prec %d, ", prec); printf("stage %d, TH=%d, %d workgroups (timestamps of thread 0; s_memtime shader cycles)\n", stage, th, nblk);
     stat("stage tile src0", 1, 2); stat("taps src0", 2, 3);
     if (stage >= 2) { stat("stage tile src1", 3, 4); stat("taps src1", 4, 5); stat("src2 (stage+taps)", 5, 6); }
-    stat("  last stage_tile: DMA issue", stage >= 2 ? 5 : 1, 8); if (stage == 1) stat("  last stage_tile: wait+barrier", 8, 2);
 #ifdef SR_TIMELINE_TAPS
     if (prec == 1) {  // sums over the 25 taps of source 0 of the last tile of each workgroup (wave 0)
         auto st1 = [&](const char* nm, int k) { std::vector<long long> d; for (int b = 0; b < nblk; ++b) d.push_back(h[b * 16 + k] / 25); std::sort(d.begin(), d.end());
@@ -61,7 +60,9 @@ int main(int argc, char** argv) {
         st1("DMA req + 12 ds_read issue", 12); st1("wait for operands", 13); st1("12 MFMA issue", 14); st1("vmcnt wait + barrier", 15);
     }
 #endif
-    stat("epilogue", 6, 7); stat("whole workgroup", 1, 7);
+    stat("next-tile request (persistent)", 6, 8);
+    stat("epilogue", 8, 7); stat("all tiles of the workgroup", 1, 7);
+    { double tiles = 0; for (int b = 0; b < nblk; ++b) tiles += (double)h[b * 16 + 12]; printf("  tiles per workgroup: %.2f (phase rows above are sums over them)\n", tiles / nblk); }
     long long t0 = h[0]; for (int b = 0; b < nblk; ++b) t0 = std::min(t0, h[b * 16]);
     std::vector<long long> starts; for (int b = 0; b < nblk; ++b) starts.push_back(h[b * 16] - t0);
     std::sort(starts.begin(), starts.end());
