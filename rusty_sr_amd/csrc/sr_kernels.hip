@@ -325,6 +325,27 @@ struct TileGeom {
 // only per-lane operand; the origin is wave-uniform and 16 c is an instruction immediate.
 // The maps carry a zero border in HBM, so the reference's zero padding (Padding::Same)
 // needs no bounds test here.
+// One LDS-DMA instruction: 16 bytes per lane from `base + voff + IMM` (base wave-uniform, voff a 32-bit lane
+// offset) to LDS address `lds + 16 * lane + IMM` (the immediate applies to both sides).  Issued as inline
+// assembly on purpose: while the compiler sees LDS-DMA in a function it treats the LGKM counter as
+// unordered and puts s_waitcnt lgkmcnt(0) in front of every use of a ds_read result, which made
+// software-pipelined operand reads impossible.  vmcnt bookkeeping for these is done by hand (ring_barrier).
+template <int IMM>
+__device__ __forceinline__ void lds_dma16(const void* base, uint32_t voff, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                 :: "s"(lds), "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+// The DMA base must sit in SGPRs.  Every caller passes a wave-uniform pointer; this spells it out for the
+// cases where the compiler cannot prove it (folds away where it can).
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 // Per-lane gather offsets of a tile: entry gi = byte offset of tile pixel P = 64 (wave + NW gi) + lane
 // from the tile origin, ((P / TWH) * pitch + P % TWH) * 128.  Computed once per workgroup (a dozen
 // VALU ops) and kept in registers: every later DMA then needs no vector ALU work at all, which
@@ -349,16 +370,14 @@ template <int TH, int KS, int NW = 4>
 __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, const TileOffsets<TH, KS, NW>& off,
                                            long img_stride, int pitch, int n, int y0, int x0, int wave, int lane) {
     using G = TileGeom<TH, KS>;
-    const char* origin = (const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32);
+    const char* origin = uniform_ptr(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32);
 #pragma unroll
     for (int gi = 0; gi < TileOffsets<TH, KS, NW>::N; ++gi) {
         const int g = wave + NW * gi;  // wave-uniform
         if (g < G::NG) {
-            const char* gp = origin + off.v[gi];  // SGPR base + 32-bit VGPR offset: the saddr form, no 64-bit VALU add
-            // channel group c: the immediate offset applies to the global AND the LDS address
-#define SR_DMA16(c)                                                                                     \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,                 \
-                                     (__attribute__((address_space(3))) void*)(tile + (c) * G::PLANE + g * 1024 - (c) * 16), 16, (c) * 16, 0)
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr(tile) + g * 1024);
+            // channel group c lands in plane c; the immediate (16 c) applies to the LDS side too, hence the - 16 c
+#define SR_DMA16(c) lds_dma16<(c) * 16>(origin, off.v[gi], dst + (c) * (G::PLANE - 16))
             SR_DMA16(0); SR_DMA16(1); SR_DMA16(2); SR_DMA16(3); SR_DMA16(4); SR_DMA16(5); SR_DMA16(6); SR_DMA16(7);
 #undef SR_DMA16
         }
@@ -371,11 +390,8 @@ __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__
 __device__ __forceinline__ void weight_chunk_async(char* ring_slot, const float* __restrict__ chunk,
                                                    int wave, int lane) {
     if (wave >= 4) return;  // 8-wave workgroups: waves 4-7 have nothing to move (their vmcnt waits pass at once)
-    // wave-uniform base + 32-bit lane offset: the saddr form, no per-chunk 64-bit VALU add
-    const char* base = (const char*)chunk + wave * 1024;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(base + (uint32_t)(lane * 16)),
-        (__attribute__((address_space(3))) void*)(ring_slot + wave * 1024), 16, 0, 0);
+    lds_dma16<0>(uniform_ptr((const char*)chunk + wave * 1024), (uint32_t)(lane * 16),
+                 __builtin_amdgcn_readfirstlane(lds_addr(ring_slot) + wave * 1024));
 }
 
 // Workgroup barrier that lets the newest `PENDING` LDS-DMA chunk loads stay in
@@ -405,9 +421,12 @@ __device__ __forceinline__ void ring_request(char* ring, const float* __restrict
         weight_chunk_async(ring + s2 * 4096, wpack + (size_t)(gtap + kRingAhead) * kChunkFloats, wave, lane);
     }
 }
+// EXTRA = 0: when this returns, chunk gtap (the new gtap) has landed in every wave's view; EXTRA = 1: chunk
+// gtap + 1 as well (the split-half loop reads its operands one step ahead).
+template <int EXTRA = 0>
 __device__ __forceinline__ void ring_advance(int& gtap, int& slot, int ntaps_total) {
-    // chunks still allowed in flight after chunk gtap+1 is complete: those of taps gtap+2 .. min(gtap+4, last)
-    const int pending = min(kRingAhead - 1, ntaps_total - 2 - gtap);
+    // chunks still allowed in flight: those requested after the newest one that must be complete
+    const int pending = max(0, min(kRingAhead - 1 - EXTRA, ntaps_total - 2 - EXTRA - gtap));
     ++gtap;
     slot = slot == kRingSlots - 1 ? 0 : slot + 1;
     if (pending >= 3) ring_barrier<3>();
@@ -428,27 +447,54 @@ __device__ __forceinline__ void conv_taps(f32x16 (&acc)[NTN * T], const char* ti
     const int i = lane & 31, h = lane >> 5;
     const int wlane = (h * 32 + i) * 16;
     const char* abase = tile + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
+    // One tap = 4 operand groups (8 input channels each): T tile-row vectors + one weight vector, then
+    // 4 T MFMAs.  Software-pipelined by hand: the reads of group g+1 are issued before the MFMAs of group g,
+    // and the first group of the NEXT tap right after this tap's barrier, under its last MFMA group -- so a
+    // wave streams MFMAs without waiting for LDS even while its SIMD neighbour is staging or storing.
+    // (The compiler's own schedule waited lgkmcnt(0) in front of every group: ~77 % for a wave on its own.)
+    struct Ops { f32x4 a[T]; f32x4 b; };
+    auto load = [&](Ops& o, int ky, int kx, int sl, int rr) {
+        const char* wb = ring + sl * 4096 + wlane;
+        const char* ab = abase + (ky * G::TWH + kx) * 16;
+        o.b = *(const f32x4*)(wb + rr * 1024);
+#pragma unroll
+        for (int m = 0; m < T; ++m) o.a[m] = *(const f32x4*)(ab + rr * 2 * G::PLANE + m * G::TWH * 16);
+    };
+    auto mfma = [&](const Ops& o, int nt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 0; m < T; ++m)
+                acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[m][q], o.b[q], acc[nt * T + m], 0, 0, 0);
+    };
+    Ops cur, nxt;
+    load(cur, 0, 0, slot, 0);
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
           for (int nt = 0; nt < NTN; ++nt) {
             ring_request(ring, wpack, gtap, slot, ntaps_total, wave, lane);
-            const char* wb = ring + slot * 4096 + wlane;
-            const char* ab = abase + (ky * G::TWH + kx) * 16;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const f32x4 b = *(const f32x4*)(wb + rr * 1024);
-                f32x4 av[T];
-#pragma unroll
-                for (int m = 0; m < T; ++m) av[m] = *(const f32x4*)(ab + rr * 2 * G::PLANE + m * G::TWH * 16);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int m = 0; m < T; ++m)
-                        acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][q], b[q], acc[nt * T + m], 0, 0, 0);
+            for (int rr = 0; rr < 3; ++rr) {
+                load(nxt, ky, kx, slot, rr + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(cur, nt);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
             }
-            ring_advance(gtap, slot, ntaps_total);  // chunk gtap has landed everywhere
+            ring_advance(gtap, slot, ntaps_total);  // chunk gtap has landed everywhere; `slot` is now its slot
+            // first group of the next step (same tap, next N-tile; or the next tap), if this source has one
+            const bool more = !(ky == KS - 1 && kx == KS - 1 && nt == NTN - 1);
+            if (more) {
+                const int nkx = nt + 1 < NTN ? kx : (kx + 1 < KS ? kx + 1 : 0);
+                const int nky = nt + 1 < NTN ? ky : (kx + 1 < KS ? ky : ky + 1);
+                load(nxt, nky, nkx, slot, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(cur, nt);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
           }
         }
     }
@@ -472,32 +518,52 @@ __device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[NTN * T], f32x16 (&ac
     const int i = lane & 31, h = lane >> 5;
     const int wlane = (h * 32 + i) * 16;
     const char* abase = tile + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
+    // Software-pipelined one whole step ahead: the 4 + 4 T operand vectors of step s+1 are requested at the
+    // start of step s and land under its 6 T MFMAs (a step is only ~400 cycles of matrix work, about one LDS
+    // round trip).  The weight chunk of step s+1 must therefore be in the ring when step s starts, i.e. the
+    // barrier that ends step s-1 waits for chunk s+1, one more than the f32 loop needs (ring_advance<1>).
+    struct Ops { f16x8 bh[2], bl[2], ah[2][T], al[2][T]; };
+    auto load = [&](Ops& o, int ky, int kx, int sl) {
+        const char* wb = ring + sl * 4096 + wlane;
+        const char* ab = abase + (ky * G::TWH + kx) * 16;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            o.bh[kk] = *(const f16x8*)(wb + kk * 1024);
+            o.bl[kk] = *(const f16x8*)(wb + 2048 + kk * 1024);
+#pragma unroll
+            for (int m = 0; m < T; ++m) {
+                o.ah[kk][m] = *(const f16x8*)(ab + (kk * 2) * G::PLANE + m * G::TWH * 16);
+                o.al[kk][m] = *(const f16x8*)(ab + (4 + kk * 2) * G::PLANE + m * G::TWH * 16);
+            }
+        }
+    };
+    Ops cur, nxt;
+    load(cur, 0, 0, slot);
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
 #pragma unroll
           for (int nt = 0; nt < NTN; ++nt) {
             ring_request(ring, wpack, gtap, slot, ntaps_total, wave, lane);
-            const char* wb = ring + slot * 4096 + wlane;
-            const char* ab = abase + (ky * G::TWH + kx) * 16;
+            const bool more = !(ky == KS - 1 && kx == KS - 1 && nt == NTN - 1);
+            if (more) {
+                const int nkx = nt + 1 < NTN ? kx : (kx + 1 < KS ? kx + 1 : 0);
+                const int nky = nt + 1 < NTN ? ky : (kx + 1 < KS ? ky : ky + 1);
+                load(nxt, nky, nkx, slot == kRingSlots - 1 ? 0 : slot + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const f16x8 bh = *(const f16x8*)(wb + kk * 1024);
-                const f16x8 bl = *(const f16x8*)(wb + 2048 + kk * 1024);
-                f16x8 ah[T], al[T];
 #pragma unroll
-                for (int m = 0; m < T; ++m) {
-                    ah[m] = *(const f16x8*)(ab + (kk * 2) * G::PLANE + m * G::TWH * 16);
-                    al[m] = *(const f16x8*)(ab + (4 + kk * 2) * G::PLANE + m * G::TWH * 16);
-                }
+                for (int m = 0; m < T; ++m) accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[kk][m], cur.bh[kk], accm[nt * T + m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < T; ++m) accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, accm[nt * T + m], 0, 0, 0);
+                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[kk][m], cur.bl[kk], accx[nt * T + m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, accx[nt * T + m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, accx[nt * T + m], 0, 0, 0);
+                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[kk][m], cur.bh[kk], accx[nt * T + m], 0, 0, 0);
             }
-            ring_advance(gtap, slot, ntaps_total);
+            __builtin_amdgcn_sched_barrier(0);
+            ring_advance<1>(gtap, slot, ntaps_total);
+            cur = nxt;
           }
         }
     }
@@ -630,7 +696,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
     if constexpr (PERSIST) {
         if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
         __syncthreads();
-        cur = *s_next;
+        cur = __builtin_amdgcn_readfirstlane(*s_next);  // uniform by construction; tells the compiler so (SGPR tile coordinates)
         if (cur < 0) return;
     } else {
         cur = xcd_remap(blockIdx.x, gridDim.x);
@@ -689,7 +755,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
             // the LDS tile and ring are free (last tap's barrier): request the next tile's
             // weights and first source NOW so the DMA runs under this tile's epilogue
             if constexpr (NSRC == 1 && !FINAL) __syncthreads();  // publish s_next (later sources' barriers do it otherwise)
-            cur = *s_next;
+            cur = __builtin_amdgcn_readfirstlane(*s_next);
             more_tiles = cur >= 0;
             if (more_tiles) request_tile(cur);
         }
