@@ -71,12 +71,14 @@ def pmc_traffic(stage, H, W, precision="f32"):
         return None
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        for name, v in d.items():
-            tag = ", 0, false, 4" if precision == "f32" else ", 1, true, 4"
-            if STAGE_KERNEL[stage] in name and tag in name and "hbm_read_bytes" in v:
-                return {"hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v.get("hbm_write_bytes", 0)),
-                        "algorithmic_bytes_per_launch": int(H * W * 128 * (min(stage, 3) + 1)),
-                        "source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+        tag = ", 0, false, 4" if precision == "f32" else ", 1, true, 4"
+        names = [n for n in d if STAGE_KERNEL[stage] in n and tag in n and "hbm_read_bytes" in d[n]]
+        names.sort(key=lambda n: 0 if (", 4, 3>" in n or n.endswith(", 4>(StageArgs)")) else 1)  # the factor-3 instance
+        if names:
+            v = d[names[0]]
+            return {"hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v.get("hbm_write_bytes", 0)),
+                    "algorithmic_bytes_per_launch": int(H * W * 128 * (min(stage, 3) + 1)),
+                    "source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
     except Exception:
         pass
     return None
