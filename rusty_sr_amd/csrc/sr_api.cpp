@@ -117,6 +117,43 @@ void pack_expand(std::vector<float>& dst, const float* w, int f, bool split) {
         }
 }
 
+// Pipe form (conv_stage_pipe_kernel): one chunk per STEP = two taps of one 16-channel half.  Steps run half 0
+// (channels 0-15) over tap pairs (0,1), (2,3), ... then half 1; a lone last tap leaves its slot zero.
+//   f32  : [q = 2 tapslot + rr][h 2][lane 32][4]   channel = 16 half + 8 rr + 4 h + e
+//   split: [hi | lo] x [tapslot 2][h 2][lane 32][8] channel = 16 half + 8 h + e
+// `lane_channel(j)` maps the MFMA column (lane) to the output channel of w ([O][ks][ks][32]) or -1.
+template <typename F>
+void pack_pipe(std::vector<float>& dst, const float* w, int ks, bool split, F lane_channel) {
+    const int nt = ks * ks, np = (nt + 1) / 2;
+    for (int half = 0; half < 2; ++half)
+        for (int p = 0; p < np; ++p) {
+            const size_t base = dst.size();
+            dst.resize(base + kChunk, 0.0f);
+            _Float16* hp = (_Float16*)(dst.data() + base);
+            for (int ts = 0; ts < 2; ++ts) {
+                const int t = 2 * p + ts;
+                if (t >= nt) continue;
+                for (int j = 0; j < 32; ++j) {
+                    const int o = lane_channel(j);
+                    if (o < 0) continue;
+                    const float* src = w + ((size_t)o * nt + t) * 32 + 16 * half;
+                    for (int c = 0; c < 16; ++c) {
+                        if (!split) {
+                            const int rr = c / 8, h = (c / 4) % 2, e = c % 4;
+                            dst[base + (size_t)(2 * ts + rr) * 256 + (h * 32 + j) * 4 + e] = src[c];
+                        } else {
+                            _Float16 hi, lo;
+                            split_half_host(src[c], hi, lo);
+                            const int h = c / 8, e = c % 8;
+                            hp[ts * 512 + (h * 32 + j) * 8 + e] = hi;
+                            hp[1024 + ts * 512 + (h * 32 + j) * 8 + e] = lo;
+                        }
+                    }
+                }
+            }
+        }
+}
+
 // conv0 [32][5][5][3] -> 25 taps x [h 2][o 32][q 2], cin = 2h+q, cin 3 = zero pad.
 void pack_conv0(std::vector<float>& dst, const float* w) {
     dst.assign(25 * 128, 0.0f);
@@ -166,6 +203,8 @@ struct sr_ctx {
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
     size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
+    size_t off_wp[2][5] = {{0}, {0}};  // pipe-form chunk order (f32, split); valid when pipe_ok
+    bool pipe_ok = false;              // factor <= 3: the final stage fits one N-tile
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;
@@ -314,6 +353,24 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
             pack_lin(w, factor);  // f32 in both modes: the residual is the signal, it stays on the exact path
             off[4] = push(w);
         }
+        c->pipe_ok = expand_tiles(factor) == 1;
+        if (c->pipe_ok)
+            for (int split = 0; split < 2; ++split) {
+                auto ident = [](int j) { return j; };
+                auto expand = [&](int j) { return expand_channel(factor, 0, j); };
+                auto conv = [&](const float* wp, int ks) { pack_pipe(w, wp, ks, split != 0, ident); };
+                w.clear(); conv(params + L.conv1, 5);
+                c->off_wp[split][1] = push(w);
+                w.clear(); conv(params + L.conv2, 5); conv(params + L.conv5, 3);
+                c->off_wp[split][2] = push(w);
+                w.clear(); conv(params + L.conv3, 5); conv(params + L.conv6, 3); conv(params + L.conv8, 3);
+                c->off_wp[split][3] = push(w);
+                w.clear();
+                pack_pipe(w, params + L.conv7, 3, split != 0, expand); pack_pipe(w, params + L.conv9, 3, split != 0, expand);
+                pack_pipe(w, params + L.conv10, 3, split != 0, expand);
+                pack_lin(w, factor);
+                c->off_wp[split][4] = push(w);
+            }
         const size_t boff[4] = {L.f_bias, L.l_bias[0], L.l_bias[1], L.l_bias[2]};
         const size_t aoff[4] = {L.f_activ, L.l_activ[0], L.l_activ[1], L.l_activ[2]};
         for (int s = 0; s < 4; ++s) c->off_bias[s] = push(vec32(boff[s], 32));
@@ -482,7 +539,13 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
     float* feat[4];
     for (int k = 0; k < 4; ++k) feat[k] = c->d_feat[k] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
-    const bool persist = c->precision == SR_PRECISION_SPLIT_F16;  // see conv_stage_kernel
+    // SRHIP_PIPE = f32 / split / all / none selects the pipe form of the stage kernels per precision (experiment switch)
+    bool pipe = false;
+    if (const char* e = getenv("SRHIP_PIPE"))
+        pipe = !strcmp(e, "all") || (!strcmp(e, "f32") && c->precision == SR_PRECISION_F32) ||
+               (!strcmp(e, "split") && c->precision == SR_PRECISION_SPLIT_F16);
+    pipe = pipe && c->pipe_ok;
+    const bool persist = c->precision == SR_PRECISION_SPLIT_F16 || pipe;  // see conv_stage_kernel
     if (persist) HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of all stages
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
@@ -521,7 +584,12 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
                 const int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);
                 if (grid > resident) grid = resident;
             }
-            HIPCHK(c, sr_launch_stage(st, c->factor, a, th, c->precision, grid, img_u8, out_u8, s));
+            if (pipe && th == 8) {
+                a.wpack = P + c->off_wp[c->precision ? 1 : 0][st];
+                HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, grid, img_u8, out_u8, s));
+            } else {
+                HIPCHK(c, sr_launch_stage(st, c->factor, a, th, c->precision, grid, img_u8, out_u8, s));
+            }
         }
         if (prof) HIPCHK(c, hipEventRecord(c->ev[st + 1], s));
     }

@@ -66,3 +66,7 @@ hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool 
 // factor (2, 3 or 4) only matters for stage 4 (3 f^2 expand channels, depth-to-space x f)
 hipError_t sr_launch_stage(int stage, int factor, const StageArgs& a, int th, int prec, int nblk, bool img_u8, bool out_u8,
                            hipStream_t s);
+// "pipe" form of the stage kernels (half-tile double buffering, persistent; 8-row tiles, factor 2 / 3 only).
+// wpack must be in the pipe chunk order (sr_api.cpp pack_*_pipe); grid = co-resident workgroups.
+hipError_t sr_launch_stage_pipe(int stage, int factor, const StageArgs& a, int prec, int grid, bool img_u8, bool out_u8,
+                                hipStream_t s);

@@ -616,6 +616,87 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], char* tile, cha
     }
 }
 
+// What happens to a finished tile: bias + BeLU -> the node's feature map (exact f32 or split-half pairs), or,
+// for the final stage, + expand_bias, depth-to-space (Expand, network.rs:39) and optionally the u8 quantiser.
+template <int TH, int T, int NTN, bool FINAL, bool OUT_U8, int PREC, int FACTOR>
+__device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)[NTN * T], f32x16 (&accx)[PREC == 1 ? NTN * T : 1],
+                                               const float (&bias)[NTN], float beta, int n, int x0, int y0, int wave, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    const bool full_x = x0 + kTW <= a.W;
+    if constexpr (!FINAL) {
+#pragma unroll
+        for (int m = 0; m < T; ++m) {
+            const int y = y0 + wave * T + m;
+            if (y >= a.y_end) continue;
+            if constexpr (PREC == 0) {
+                float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
+                if (full_x) {
+                    store_belu_tile(base, acc[m], bias[0], beta);
+                } else {
+                    for_each_acc_row([&](int r, int row) {
+                        if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias[0]), beta);
+                    });
+                }
+            } else {
+                char* base = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h + (i & 1)) * 32) + (i & ~1) * 2;
+                if (full_x) store_belu_tile_split(base, acc[m], accx[m], bias[0], beta, i & 1);
+                else store_belu_tile_split_masked(base, acc[m], accx[m], bias[0], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)));
+            }
+        }
+    } else {
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int m = 0; m < NTN * T; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = acc[m][r] + accx[m][r] * (1.0f / kLoScale);
+        }
+        // Expand (network.rs:39): out[f y+dy][f x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
+        // Lane i < 30 of N-tile nt owns colour c = i % 3 of sub-pixel triple tr = 10 nt + i / 3
+        // (dy = tr / f, dx = tr % f); the host packs the weights in that order.
+        const int OW = a.W * FACTOR;
+        const int h_band = a.y_end - a.y_begin;
+        const int tl = i / 3, c = i - 3 * tl;
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+            const int tr = nt * 10 + tl;
+            const bool valid = i < 30 && tr < FACTOR * FACTOR;
+            const int trc = valid ? tr : 0;
+            const int dy = trc / FACTOR, dx = trc - dy * FACTOR;
+#pragma unroll
+            for (int m = 0; m < T; ++m) {
+                const int y = y0 + wave * T + m;
+                if (y >= a.y_end) continue;
+                const f32x16& av = acc[nt * T + m];
+                const size_t opx = ((size_t)n * h_band * FACTOR + (size_t)(y - a.y_begin) * FACTOR + dy) * OW +
+                                   FACTOR * (x0 + 4 * h) + dx;
+                if constexpr (!OUT_U8) {
+                    float* base = (float*)a.out + opx * 3 + c;
+                    if (full_x) {
+                        for_each_acc_row([&](int r, int row) { if (valid) base[row * FACTOR * 3] = __fadd_rn(av[r], bias[nt]); });
+                    } else {
+                        for_each_acc_row([&](int r, int row) {
+                            if (valid && x0 + 4 * h + row < a.W) base[row * FACTOR * 3] = __fadd_rn(av[r], bias[nt]);
+                        });
+                    }
+                } else {
+                    // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255;
+                    // the lane holding c == 0 gathers G and B from its two neighbours
+                    uint32_t* base = (uint32_t*)a.out + opx;
+                    const bool writer = valid && c == 0;
+                    for_each_acc_row([&](int r, int row) {
+                        float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(av[r], bias[nt])), 0.5f));
+                        q = fminf(fmaxf(q, 0.0f), 255.0f);
+                        const uint32_t qi = (uint32_t)q;
+                        const uint32_t g = __shfl_down(qi, 1), b = __shfl_down(qi, 2);
+                        if (writer && (full_x || x0 + 4 * h + row < a.W))
+                            base[row * FACTOR] = qi | (g << 8) | (b << 16) | 0xff000000u;
+                    });
+                }
+            }
+        }
+    }
+}
+
 // Dynamic tile queue for the persistent form.  The tiles are cut into 8 contiguous
 // runs, one per XCD (the dispatcher places block b on XCD b % 8: neighbouring tiles
 // share halo rows in that XCD's L2); each run has a head counter in HBM (zeroed by
@@ -760,86 +841,349 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
             if (more_tiles) request_tile(cur);
         }
         TL(8);
-        {
-        const int n = tn, x0 = tx0, y0 = ty0;
-        const bool full_x = x0 + kTW <= a.W;
-        if constexpr (!FINAL) {
-#pragma unroll
-            for (int m = 0; m < T; ++m) {
-                const int y = y0 + wave * T + m;
-                if (y >= a.y_end) continue;
-                if constexpr (PREC == 0) {
-                    float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
-                    if (full_x) {
-                        store_belu_tile(base, acc[m], bias[0], beta);
-                    } else {
-                        for_each_acc_row([&](int r, int row) {
-                            if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias[0]), beta);
-                        });
-                    }
-                } else {
-                    char* base = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h + (i & 1)) * 32) + (i & ~1) * 2;
-                    if (full_x) store_belu_tile_split(base, acc[m], accx[m], bias[0], beta, i & 1);
-                    else store_belu_tile_split_masked(base, acc[m], accx[m], bias[0], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)));
-                }
-            }
-        } else {
-            if constexpr (PREC == 1) {
-#pragma unroll
-                for (int m = 0; m < NTN * T; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][r] = acc[m][r] + accx[m][r] * (1.0f / kLoScale);
-            }
-            // Expand (network.rs:39): out[f y+dy][f x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
-            // Lane i < 30 of N-tile nt owns colour c = i % 3 of sub-pixel triple tr = 10 nt + i / 3
-            // (dy = tr / f, dx = tr % f); the host packs the weights in that order.
-            const int OW = a.W * FACTOR;
-            const int h_band = a.y_end - a.y_begin;
-            const int tl = i / 3, c = i - 3 * tl;
-#pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) {
-                const int tr = nt * 10 + tl;
-                const bool valid = i < 30 && tr < FACTOR * FACTOR;
-                const int trc = valid ? tr : 0;
-                const int dy = trc / FACTOR, dx = trc - dy * FACTOR;
-#pragma unroll
-                for (int m = 0; m < T; ++m) {
-                    const int y = y0 + wave * T + m;
-                    if (y >= a.y_end) continue;
-                    const f32x16& av = acc[nt * T + m];
-                    const size_t opx = ((size_t)n * h_band * FACTOR + (size_t)(y - a.y_begin) * FACTOR + dy) * OW +
-                                       FACTOR * (x0 + 4 * h) + dx;
-                    if constexpr (!OUT_U8) {
-                        float* base = (float*)a.out + opx * 3 + c;
-                        if (full_x) {
-                            for_each_acc_row([&](int r, int row) { if (valid) base[row * FACTOR * 3] = __fadd_rn(av[r], bias[nt]); });
-                        } else {
-                            for_each_acc_row([&](int r, int row) {
-                                if (valid && x0 + 4 * h + row < a.W) base[row * FACTOR * 3] = __fadd_rn(av[r], bias[nt]);
-                            });
-                        }
-                    } else {
-                        // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255;
-                        // the lane holding c == 0 gathers G and B from its two neighbours
-                        uint32_t* base = (uint32_t*)a.out + opx;
-                        const bool writer = valid && c == 0;
-                        for_each_acc_row([&](int r, int row) {
-                            float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(av[r], bias[nt])), 0.5f));
-                            q = fminf(fmaxf(q, 0.0f), 255.0f);
-                            const uint32_t qi = (uint32_t)q;
-                            const uint32_t g = __shfl_down(qi, 1), b = __shfl_down(qi, 2);
-                            if (writer && (full_x || x0 + 4 * h + row < a.W))
-                                base[row * FACTOR] = qi | (g << 8) | (b << 16) | 0xff000000u;
-                        });
-                    }
-                }
-            }
-        }
-        }
+        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, tn, tx0, ty0, wave, lane);
         TL(7);
         if (!more_tiles) break;
     }
     TL_END();
+}
+
+// ---------------------------------------------------------------------------
+// Stage kernel, second form ("pipe"): every source tile is staged in two HALVES of 16 input channels
+// (4 LDS planes, 28 KB for a 5x5 halo) into two buffers that alternate, so the gather DMA of half j+1
+// -- and, at the end of a tile, of the NEXT tile's first half -- runs under the taps of half j.  Nothing
+// but the epilogue is left outside the matrix stream: no staging waits between sources, no prologue per
+// tile (persistent workgroups, tiles from the per-XCD queue).  A step = two taps of one half = one 4 KB
+// weight chunk = 32 f32 / 12 f16 MFMAs per wave, same size as a whole tap of the first form.
+// Restrictions: 8-row tiles, 4 waves, one N-tile (factor 2 and 3); everything else runs the first form.
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier(int pending) {  // s_waitcnt vmcnt(pending) lgkmcnt(0); s_barrier
+    switch (pending) {
+#define SR_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); break;
+        SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
+#undef SR_CASE
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int KS>
+struct HalfTile {
+    using G = TileGeom<8, KS>;
+    static constexpr int BYTES = 4 * G::PLANE;
+    static constexpr int STEPS = (KS * KS + 1) / 2;
+    uint32_t off[G::NG];  // gather offset of tile pixel 64 g + lane (same for every wave: wave w moves plane w)
+    __device__ __forceinline__ void init(int pitch, int lane) {
+#pragma unroll
+        for (int g = 0; g < G::NG; ++g) {
+            const int P = min(g * 64 + lane, G::NPIX - 1);
+            const int prow = P / G::TWH, pcol = P - prow * G::TWH;
+            off[g] = (uint32_t)(prow * pitch + pcol) * 128u;
+        }
+    }
+    // request half `khalf` of the tile at (n, y0, x0) of `src` into the LDS buffer `buf`: G::NG DMAs per wave
+    template <int PREC, int G0 = 0, int G1 = G::NG>
+    __device__ __forceinline__ void stage(uint32_t buf, const float* __restrict__ src, int khalf, long img_stride, int pitch,
+                                          int n, int y0, int x0, int wave) const {
+        // 16-byte channel group this wave moves: f32 map = 8 groups of 4 channels; split map = 4 groups of hi
+        // halves then 4 of lo halves (8 channels each)
+        const int chunk = PREC == 0 ? 4 * khalf + wave : (wave < 2 ? 2 * khalf + wave : 4 + 2 * khalf + (wave - 2));
+        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) + chunk * 16);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + wave * G::PLANE);
+#pragma unroll
+        for (int g = G0; g < G1 && g < G::NG; ++g) lds_dma16<0>(origin, off[g], dst + g * 1024);
+    }
+};
+
+// Bookkeeping of the pipe form's DMA traffic.  Every LDS-DMA instruction a wave issues gets a sequence number;
+// loads complete in issue order, so "everything up to number q has landed" is s_waitcnt vmcnt(issued - q).
+// (Stores and plain loads issued in between only make that wait stricter, never weaker.)
+// Weight chunks: step gs of a tile uses chunk gs; it is requested kRingAhead steps earlier, wrapping into the
+// next tile.  Half tiles: requested piecemeal over the first steps of the previous half (a burst of gathers
+// stalls the issuing wave for ~250 cycles per instruction), needed at its end.
+struct StepStream {
+    int gs, slot;        // this step's number within the tile and its ring slot
+    int nsteps;          // steps per tile
+    bool have_next;      // another tile follows (its chunks are requested by the last steps of this one)
+    int issued;          // DMA instructions issued so far by this wave
+    int q[kRingAhead];   // sequence numbers of the requests of chunks gs + 1 .. gs + kRingAhead
+    int tile_seq;        // sequence number of the newest half-tile DMA
+};
+
+__device__ __forceinline__ void step_request(StepStream& st, char* ring, const float* __restrict__ wpack, int wave, int lane) {
+    int req = st.gs + kRingAhead;
+    bool go = true;
+    if (req >= st.nsteps) {
+        go = st.have_next;
+        req -= st.nsteps;
+    }
+#pragma unroll
+    for (int k = 0; k + 1 < kRingAhead; ++k) st.q[k] = st.q[k + 1];
+    if (go) {
+        int s2 = st.slot + kRingAhead;
+        if (s2 >= kRingSlots) s2 -= kRingSlots;
+        weight_chunk_async(ring + s2 * 4096, wpack + (size_t)req * kChunkFloats, wave, lane);
+        ++st.issued;
+    }
+    st.q[kRingAhead - 1] = st.issued;  // nothing requested: nothing newer to wait for either
+}
+// End of a step: chunk gs + EXTRA (numbered after the shift in step_request: q[EXTRA - 1 + 1]...) -- see below.
+// On return chunk gs + 1 + EXTRA has landed; with `tile` also every half-tile DMA issued so far.
+template <int EXTRA>
+__device__ __forceinline__ void step_advance(StepStream& st, bool tile) {
+    // after this step's step_request, q[k] is the request of chunk gs + 1 + k
+    int need = st.q[EXTRA];
+    if (tile && st.tile_seq > need) need = st.tile_seq;
+    wait_vm_barrier<0>(st.issued - need);
+    st.gs = st.gs + 1 == st.nsteps ? 0 : st.gs + 1;
+    st.slot = st.slot == kRingSlots - 1 ? 0 : st.slot + 1;
+}
+
+// What a half's steps should request on the side: half `khalf` of the tile at (n, y0, x0) of `src` into `buf`,
+// two gather instructions per step.  active = false: nothing (last half of the last tile).
+struct HalfRequest {
+    bool active;
+    uint32_t buf;
+    const float* src;
+    int khalf, n, y0, x0;
+};
+template <int PREC, int KSN, int P>
+__device__ __forceinline__ void request_piece(const HalfRequest& rq, const HalfTile<KSN>& ht, const StageArgs& a, StepStream& st, int wave) {
+    constexpr int g0 = 2 * P, g1 = 2 * P + 2, ng = HalfTile<KSN>::G::NG;
+    if constexpr (g0 < ng) {
+        if (rq.active) {
+            ht.template stage<PREC, g0, g1>(rq.buf, rq.src, rq.khalf, a.img_stride, a.pitch, rq.n, rq.y0, rq.x0, wave);
+            st.issued += (g1 < ng ? g1 : ng) - g0;
+            st.tile_seq = st.issued;
+        }
+    }
+}
+
+
+// The steps of one half-source, exact f32.  hb: LDS half tile (4 planes of 4 channels).
+template <int KS, int T, int KSN>
+__device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[T], const char* hb, char* ring, const StageArgs& a,
+                                               StepStream& st, const HalfRequest& rq, const HalfTile<KSN>& htn, int wave, int lane,
+                                               volatile int* mailbox, int xcd, int ntiles, int pulled, bool publish) {
+    const float* __restrict__ wpack = a.wpack;
+    int* queue = a.queue;
+    using G = TileGeom<8, KS>;
+    constexpr int NT = KS * KS, NP = (NT + 1) / 2;
+    const int i = lane & 31, h = lane >> 5;
+    const int wlane = (h * 32 + i) * 16;
+    const char* abase = hb + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
+    struct Ops { f32x4 a[T]; f32x4 b; };
+    // operand group q of pair p: q = 2 * tapslot + rr  (rr: which 8 of the half's 16 channels)
+    auto load = [&](Ops& o, int p, int q, int sl) {
+        const int t = 2 * p + (q >> 1), ky = t / KS, kx = t - ky * KS;
+        const char* ab = abase + (q & 1) * 2 * G::PLANE + (ky * G::TWH + kx) * 16;
+        o.b = *(const f32x4*)(ring + sl * 4096 + wlane + q * 1024);
+#pragma unroll
+        for (int m = 0; m < T; ++m) o.a[m] = *(const f32x4*)(ab + m * G::TWH * 16);
+    };
+    auto mfma = [&](const Ops& o) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < T; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[m][e], o.b[e], acc[m], 0, 0, 0);
+    };
+    Ops cur, nxt;
+    load(cur, 0, 0, st.slot);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        constexpr int dummy = 0; (void)dummy;
+        const int ngroups = (2 * p + 1 < NT) ? 4 : 2;
+        if (p == 0) request_piece<0, KSN, 0>(rq, htn, a, st, wave);
+        if (p == 1) request_piece<0, KSN, 1>(rq, htn, a, st, wave);
+        if (p == 2) request_piece<0, KSN, 2>(rq, htn, a, st, wave);
+        if (p == 3) request_piece<0, KSN, 3>(rq, htn, a, st, wave);
+        step_request(st, ring, wpack, wave, lane);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q + 1 < ngroups) {
+                load(nxt, p, q + 1, st.slot);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma(cur);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+        }
+        if (publish && p == NP - 1 && threadIdx.x == 0) *mailbox = queue_resolve(queue, xcd, ntiles, pulled);
+        step_advance<0>(st, p == NP - 1);
+        if (p + 1 < NP) load(nxt, p + 1, 0, st.slot);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+}
+
+// The steps of one half-source, split-half arithmetic.  hb planes: 0, 1 = hi halves of channels 0-7 / 8-15 of
+// this half, 2, 3 = their lo halves; chunk = [hi tap0 | hi tap1 | lo tap0 | lo tap1], 1 KB each.
+template <int KS, int T, int KSN>
+__device__ __forceinline__ void half_steps_h(f32x16 (&accm)[T], f32x16 (&accx)[T], const char* hb, char* ring,
+                                             const StageArgs& a, StepStream& st, const HalfRequest& rq, const HalfTile<KSN>& htn,
+                                             int wave, int lane, volatile int* mailbox, int xcd, int ntiles, int pulled, bool publish) {
+    const float* __restrict__ wpack = a.wpack;
+    int* queue = a.queue;
+    using G = TileGeom<8, KS>;
+    constexpr int NT = KS * KS, NP = (NT + 1) / 2;
+    const int i = lane & 31, h = lane >> 5;
+    const int wlane = (h * 32 + i) * 16;
+    const char* abase = hb + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
+    struct Ops { f16x8 bh[2], bl[2], ah[2][T], al[2][T]; };
+    auto load = [&](Ops& o, int p, int sl) {
+        const char* wb = ring + sl * 4096 + wlane;
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts) {
+            const int t = 2 * p + ts;
+            if (t < NT) {
+                const int ky = t / KS, kx = t - ky * KS;
+                const char* ab = abase + (ky * G::TWH + kx) * 16;
+                o.bh[ts] = *(const f16x8*)(wb + ts * 1024);
+                o.bl[ts] = *(const f16x8*)(wb + 2048 + ts * 1024);
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    o.ah[ts][m] = *(const f16x8*)(ab + m * G::TWH * 16);
+                    o.al[ts][m] = *(const f16x8*)(ab + 2 * G::PLANE + m * G::TWH * 16);
+                }
+            }
+        }
+    };
+    Ops cur, nxt;
+    load(cur, 0, st.slot);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (p == 0) request_piece<1, KSN, 0>(rq, htn, a, st, wave);
+        if (p == 1) request_piece<1, KSN, 1>(rq, htn, a, st, wave);
+        if (p == 2) request_piece<1, KSN, 2>(rq, htn, a, st, wave);
+        if (p == 3) request_piece<1, KSN, 3>(rq, htn, a, st, wave);
+        step_request(st, ring, wpack, wave, lane);
+        if (p + 1 < NP) load(nxt, p + 1, st.slot == kRingSlots - 1 ? 0 : st.slot + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts) {
+            if (2 * p + ts < NT) {
+#pragma unroll
+                for (int m = 0; m < T; ++m) accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bh[ts], accm[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bl[ts], accx[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[ts][m], cur.bh[ts], accx[m], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (publish && p == NP - 1 && threadIdx.x == 0) *mailbox = queue_resolve(queue, xcd, ntiles, pulled);
+        step_advance<1>(st, p == NP - 1);
+        cur = nxt;
+    }
+}
+
+template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, int FACTOR = 3>
+__global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int TH = 8, T = 2, NTN = 1;
+    static_assert(!FINAL || FACTOR * FACTOR <= 10, "one N-tile only");
+    using H0 = HalfTile<KS0>;
+    using H3 = HalfTile<3>;
+    constexpr int HB = H0::BYTES;  // KS0 >= 3: the first source has the largest half tile
+    constexpr int NH = 2 * NSRC;
+    constexpr int NSTEPS = 2 * (H0::STEPS + (NSRC - 1) * H3::STEPS);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem + 2 * HB;
+    volatile int* s_next = (volatile int*)(ring + kRingBytes);
+    const uint32_t lds0 = lds_addr(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int ntiles = tiles_per_img * a.n_img;
+    const int xcd = blockIdx.x & 7;
+    float bias[NTN];
+    bias[0] = a.bias[i];
+    const float beta = FINAL ? 0.f : a.beta[i];
+    H0 h0;
+    H3 h3;
+    h0.init(a.pitch, lane);
+    if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
+
+    auto coords = [&](int t, int& n, int& x0, int& y0) {
+        n = tile_div(t, a.div_tpi);
+        const int r = t - n * tiles_per_img, ty = tile_div(r, a.div_tx), tx = r - ty * a.tiles_x;
+        x0 = tx * kTW; y0 = a.y_begin + ty * TH;
+    };
+
+    if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
+    __syncthreads();
+    int cur = __builtin_amdgcn_readfirstlane(*s_next);
+    if (cur < 0) return;
+    int n, x0, y0;
+    coords(cur, n, x0, y0);
+    // first tile only: its first half and the first weight chunks are requested here; every later tile finds
+    // them already on the way (requested by the last half / the last steps of the tile before)
+    h0.template stage<PREC>(lds0, a.src[0], 0, a.img_stride, a.pitch, n, y0, x0, wave);
+#pragma unroll
+    for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
+    constexpr int NG0 = H0::G::NG;
+    // sequence numbers so far: half tile 1..NG0, chunks 0..3 = NG0+1..NG0+4; q[] is shifted before use (step_request)
+    StepStream st{0, 0, NSTEPS, false, NG0 + kRingAhead, {0, NG0 + 2, NG0 + 3, NG0 + 4}, NG0};
+    static_assert(kRingAhead == 4, "q[] initialiser");
+    // half 0 and chunk 0 (split: and 1) are in; the later chunks may still be in flight
+    wait_vm_barrier<0>(st.issued - (NG0 + 1 + (PREC == 1 ? 1 : 0)));
+
+    while (true) {
+        f32x16 acc[T], accx[PREC == 1 ? T : 1];
+#pragma unroll
+        for (int m = 0; m < T; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[m][r] = 0.f;
+                if constexpr (PREC == 1) accx[m][r] = 0.f;
+            }
+        int pulled = 0;
+        if (tid == 0) pulled = atomicAdd(&a.queue[xcd], 1);  // the answer is looked at by the end of half 0
+        int nn = 0, nx0 = 0, ny0 = 0, next = -1;
+        st.have_next = false;  // not known yet: nothing of the next tile is requested before half 1
+        auto do_half = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int src = j >> 1;
+            constexpr int KSJ = src == 0 ? KS0 : 3;                               // this half's kernel size
+            constexpr int KSN = (j + 1 < NH) ? (((j + 1) >> 1) == 0 ? KS0 : 3) : KS0;  // the half requested meanwhile
+            const uint32_t other = lds0 + ((j + 1) & 1) * HB;
+            const char* hb = smem + (j & 1) * HB;
+            if constexpr (j == 1) {  // the mailbox was published before the barrier that ended half 0
+                next = __builtin_amdgcn_readfirstlane(*s_next);
+                st.have_next = next >= 0;
+                if (st.have_next) coords(next, nn, nx0, ny0);
+            }
+            // half j+1 of this tile, or the next tile's half 0, goes into the buffer half j-1 has just left
+            HalfRequest rq;
+            if constexpr (j + 1 < NH) rq = HalfRequest{true, other, a.src[(j + 1) >> 1], (j + 1) & 1, n, y0, x0};
+            else rq = HalfRequest{st.have_next, other, a.src[0], 0, nn, ny0, nx0};
+            const HalfTile<KSN>* htn;
+            if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
+            if constexpr (PREC == 0) half_steps_f32<KSJ, T, KSN>(acc, hb, ring, a, st, rq, *htn, wave, lane, s_next, xcd, ntiles, pulled, j == 0);
+            else half_steps_h<KSJ, T, KSN>(acc, accx, hb, ring, a, st, rq, *htn, wave, lane, s_next, xcd, ntiles, pulled, j == 0);
+        };
+        do_half(std::integral_constant<int, 0>{});
+        do_half(std::integral_constant<int, 1>{});
+        if constexpr (NH > 2) { do_half(std::integral_constant<int, 2>{}); do_half(std::integral_constant<int, 3>{}); }
+        if constexpr (NH > 4) { do_half(std::integral_constant<int, 4>{}); do_half(std::integral_constant<int, 5>{}); }
+        if constexpr (FINAL) {
+            // bilinear residual: image tile + fixed weights staged in the buffer the last half has left (buffer 1)
+            char* lin = smem + HB;
+            lin_taps<TH, T, IMG_U8, 256, NTN>(acc, lin, lin + 8192, a, a.wpack + (size_t)NSTEPS * kChunkFloats, n, y0, x0, wave, lane, tid);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
+        }
+        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
+        if (!st.have_next) break;
+        n = nn; x0 = nx0; y0 = ny0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
 }
 
 // ---------------------------------------------------------------------------
@@ -979,6 +1323,31 @@ static hipError_t launch_stage_t(int stage, int factor, const StageArgs& a, int 
             return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
+}
+
+// Pipe form (8-row tiles, factor <= 3): grid = co-resident workgroups, LDS = two half tiles + ring + mailbox.
+template <int PREC>
+static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s) {
+    constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kRingBytes + 16, lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16;
+    switch (stage) {
+        case 1: return launch_with_lds(conv_stage_pipe_kernel<1, 5, false, false, false, PREC>, a, grid, lds5, s);
+        case 2: return launch_with_lds(conv_stage_pipe_kernel<2, 5, false, false, false, PREC>, a, grid, lds5, s);
+        case 3: return launch_with_lds(conv_stage_pipe_kernel<3, 5, false, false, false, PREC>, a, grid, lds5, s);
+        case 4:
+#define SR_FINAL(F)                                                                                                          \
+            if (img_u8 && out_u8) return launch_with_lds(conv_stage_pipe_kernel<3, 3, true, true, true, PREC, F>, a, grid, lds3, s); \
+            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_pipe_kernel<3, 3, true, false, false, PREC, F>, a, grid, lds3, s); \
+            return hipErrorInvalidValue;
+            if (factor == 3) { SR_FINAL(3) }
+            if (factor == 2) { SR_FINAL(2) }
+#undef SR_FINAL
+            return hipErrorInvalidValue;
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t sr_launch_stage_pipe(int stage, int factor, const StageArgs& a, int prec, int grid, bool img_u8, bool out_u8, hipStream_t s) {
+    return prec == 0 ? launch_stage_pipe_t<0>(stage, factor, a, grid, img_u8, out_u8, s)
+                     : launch_stage_pipe_t<1>(stage, factor, a, grid, img_u8, out_u8, s);
 }
 
 hipError_t sr_launch_stage(int stage, int factor, const StageArgs& a, int th, int prec, int nblk, bool img_u8,
