@@ -46,43 +46,11 @@ struct ParamLayout {
 
 constexpr int kChunk = 1024;  // floats per tap chunk (32 cin x 32 cout)
 
-// Append the taps of one [O][KS][KS][32] convolution as B-operand chunks:
-// chunk[(c*32 + o)*4 + q] = W[o][ky][kx][4c+q], output channels >= O zero.
-void pack_conv32(std::vector<float>& dst, const float* w, int O, int ks) {
-    for (int ky = 0; ky < ks; ++ky)
-        for (int kx = 0; kx < ks; ++kx) {
-            const size_t base = dst.size();
-            dst.resize(base + kChunk, 0.0f);
-            for (int c = 0; c < 8; ++c)
-                for (int o = 0; o < O; ++o)
-                    for (int q = 0; q < 4; ++q)
-                        dst[base + (c * 32 + o) * 4 + q] = w[(((size_t)o * ks + ky) * ks + kx) * 32 + 4 * c + q];
-        }
-}
-
-// Split-half flavour of pack_conv32: per tap 4 KB = [hi][lo], each
-// [cin/8 = 4][cout 32][8 halves]: w = hi + lo/2048 (see split_half in sr_kernels.hip).
+// w = hi + lo/2048 with hi, lo halves (see split_half in sr_kernels.hip)
 void split_half_host(float v, _Float16& hi, _Float16& lo) {
     hi = std::fabs(v) < 6.103515625e-05f ? (_Float16)0.0f : (_Float16)v;
     lo = (_Float16)((v - (float)hi) * 2048.0f);
 }
-void pack_conv32_h(std::vector<float>& dst, const float* w, int O, int ks) {
-    for (int ky = 0; ky < ks; ++ky)
-        for (int kx = 0; kx < ks; ++kx) {
-            const size_t base = dst.size();
-            dst.resize(base + kChunk, 0.0f);
-            _Float16* hp = (_Float16*)(dst.data() + base);  // 2048 halves: [0,1024) hi, [1024,2048) lo
-            for (int g = 0; g < 4; ++g)
-                for (int o = 0; o < O; ++o)
-                    for (int q = 0; q < 8; ++q) {
-                        _Float16 hi, lo;
-                        split_half_host(w[(((size_t)o * ks + ky) * ks + kx) * 32 + 8 * g + q], hi, lo);
-                        hp[(g * 32 + o) * 8 + q] = hi;
-                        hp[1024 + (g * 32 + o) * 8 + q] = lo;
-                    }
-        }
-}
-
 // The expand node's 3 f^2 channels ((dy*f+dx)*3+c, network.rs:39) are laid out in whole RGB
 // triples, 10 per 32-lane N-tile: lane j < 30 of tile nt carries channel 3*(10 nt + j/3) + j%3.
 // Returns that channel, or -1 for an unused lane.
@@ -92,66 +60,43 @@ int expand_channel(int f, int nt, int j) {
 }
 int expand_tiles(int f) { return (f * f + 9) / 10; }
 
-// conv7 / conv9 / conv10 ([3f^2][3][3][32]) as ring chunks: tap-major, then N-tile.
-void pack_expand(std::vector<float>& dst, const float* w, int f, bool split) {
-    for (int t = 0; t < 9; ++t)
-        for (int nt = 0; nt < expand_tiles(f); ++nt) {
-            const size_t base = dst.size();
-            dst.resize(base + kChunk, 0.0f);
-            _Float16* hp = (_Float16*)(dst.data() + base);
-            for (int j = 0; j < 32; ++j) {
-                const int ch = expand_channel(f, nt, j);
-                if (ch < 0) continue;
-                const float* src = w + ((size_t)ch * 9 + t) * 32;
-                for (int ci = 0; ci < 32; ++ci) {
-                    if (!split) {
-                        dst[base + ((ci / 4) * 32 + j) * 4 + ci % 4] = src[ci];
-                    } else {
-                        _Float16 hi, lo;
-                        split_half_host(src[ci], hi, lo);
-                        hp[((ci / 8) * 32 + j) * 8 + ci % 8] = hi;
-                        hp[1024 + ((ci / 8) * 32 + j) * 8 + ci % 8] = lo;
-                    }
-                }
-            }
-        }
-}
-
-// Pipe form (conv_stage_pipe_kernel): one chunk per STEP = two taps of one 16-channel half.  Steps run half 0
-// (channels 0-15) over tap pairs (0,1), (2,3), ... then half 1; a lone last tap leaves its slot zero.
-//   f32  : [q = 2 tapslot + rr][h 2][lane 32][4]   channel = 16 half + 8 rr + 4 h + e
-//   split: [hi | lo] x [tapslot 2][h 2][lane 32][8] channel = 16 half + 8 h + e
-// `lane_channel(j)` maps the MFMA column (lane) to the output channel of w ([O][ks][ks][32]) or -1.
+// Weight chunks of the stage kernels (both forms): one 4 KB chunk per STEP = two taps of one 16-channel half
+// (and, for a node with more than 32 output channels, per N-tile).  Steps run half 0 (channels 0-15) over the
+// tap pairs (0,1), (2,3), ... then half 1; a lone last tap leaves its slot zero.
+//   f32  : [q = 2 tapslot + rr][h 2][lane 32][4]    channel = 16 half + 8 rr + 4 h + e
+//   split: [hi | lo] x [tapslot 2][h 2][lane 32][8]  channel = 16 half + 8 h + e
+// `lane_channel(nt, j)` maps MFMA column j of N-tile nt to the output channel of w ([O][ks][ks][32]) or -1.
 template <typename F>
-void pack_pipe(std::vector<float>& dst, const float* w, int ks, bool split, F lane_channel) {
+void pack_steps(std::vector<float>& dst, const float* w, int ks, int ntn, bool split, F lane_channel) {
     const int nt = ks * ks, np = (nt + 1) / 2;
     for (int half = 0; half < 2; ++half)
-        for (int p = 0; p < np; ++p) {
-            const size_t base = dst.size();
-            dst.resize(base + kChunk, 0.0f);
-            _Float16* hp = (_Float16*)(dst.data() + base);
-            for (int ts = 0; ts < 2; ++ts) {
-                const int t = 2 * p + ts;
-                if (t >= nt) continue;
-                for (int j = 0; j < 32; ++j) {
-                    const int o = lane_channel(j);
-                    if (o < 0) continue;
-                    const float* src = w + ((size_t)o * nt + t) * 32 + 16 * half;
-                    for (int c = 0; c < 16; ++c) {
-                        if (!split) {
-                            const int rr = c / 8, h = (c / 4) % 2, e = c % 4;
-                            dst[base + (size_t)(2 * ts + rr) * 256 + (h * 32 + j) * 4 + e] = src[c];
-                        } else {
-                            _Float16 hi, lo;
-                            split_half_host(src[c], hi, lo);
-                            const int h = c / 8, e = c % 8;
-                            hp[ts * 512 + (h * 32 + j) * 8 + e] = hi;
-                            hp[1024 + ts * 512 + (h * 32 + j) * 8 + e] = lo;
+        for (int p = 0; p < np; ++p)
+            for (int tile = 0; tile < ntn; ++tile) {
+                const size_t base = dst.size();
+                dst.resize(base + kChunk, 0.0f);
+                _Float16* hp = (_Float16*)(dst.data() + base);
+                for (int ts = 0; ts < 2; ++ts) {
+                    const int t = 2 * p + ts;
+                    if (t >= nt) continue;
+                    for (int j = 0; j < 32; ++j) {
+                        const int o = lane_channel(tile, j);
+                        if (o < 0) continue;
+                        const float* src = w + ((size_t)o * nt + t) * 32 + 16 * half;
+                        for (int c = 0; c < 16; ++c) {
+                            if (!split) {
+                                const int rr = c / 8, h = (c / 4) % 2, e = c % 4;
+                                dst[base + (size_t)(2 * ts + rr) * 256 + (h * 32 + j) * 4 + e] = src[c];
+                            } else {
+                                _Float16 hi, lo;
+                                split_half_host(src[c], hi, lo);
+                                const int h = c / 8, e = c % 8;
+                                hp[ts * 512 + (h * 32 + j) * 8 + e] = hi;
+                                hp[1024 + ts * 512 + (h * 32 + j) * 8 + e] = lo;
+                            }
                         }
                     }
                 }
             }
-        }
 }
 
 // conv0 [32][5][5][3] -> 25 taps x [h 2][o 32][q 2], cin = 2h+q, cin 3 = zero pad.
@@ -203,8 +148,7 @@ struct sr_ctx {
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
     size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
-    size_t off_wp[2][5] = {{0}, {0}};  // pipe-form chunk order (f32, split); valid when pipe_ok
-    bool pipe_ok = false;              // factor <= 3: the final stage fits one N-tile
+    bool pipe_ok = false;  // factor <= 3: the final stage fits one N-tile, which is all the pipe form handles
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;
@@ -339,7 +283,10 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         pack_conv0(w, params + L.conv0);
         c->off_w0 = push(w);
         for (int split = 0; split < 2; ++split) {  // exact-f32 chunks, then the same stages in split-half form
-            auto conv = [&](const float* wp, int ks) { split ? pack_conv32_h(w, wp, 32, ks) : pack_conv32(w, wp, 32, ks); };
+            auto ident = [](int, int j) { return j; };
+            auto expand = [&](int nt, int j) { return expand_channel(factor, nt, j); };
+            auto conv = [&](const float* wp, int ks) { pack_steps(w, wp, ks, 1, split != 0, ident); };
+            auto exp3 = [&](const float* wp) { pack_steps(w, wp, 3, expand_tiles(factor), split != 0, expand); };
             size_t* off = split ? c->off_wh : c->off_w;
             w.clear(); conv(params + L.conv1, 5);
             off[1] = push(w);
@@ -348,29 +295,11 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
             w.clear(); conv(params + L.conv3, 5); conv(params + L.conv6, 3); conv(params + L.conv8, 3);
             off[3] = push(w);
             w.clear();
-            pack_expand(w, params + L.conv7, factor, split); pack_expand(w, params + L.conv9, factor, split);
-            pack_expand(w, params + L.conv10, factor, split);
+            exp3(params + L.conv7); exp3(params + L.conv9); exp3(params + L.conv10);
             pack_lin(w, factor);  // f32 in both modes: the residual is the signal, it stays on the exact path
             off[4] = push(w);
         }
-        c->pipe_ok = expand_tiles(factor) == 1;
-        if (c->pipe_ok)
-            for (int split = 0; split < 2; ++split) {
-                auto ident = [](int j) { return j; };
-                auto expand = [&](int j) { return expand_channel(factor, 0, j); };
-                auto conv = [&](const float* wp, int ks) { pack_pipe(w, wp, ks, split != 0, ident); };
-                w.clear(); conv(params + L.conv1, 5);
-                c->off_wp[split][1] = push(w);
-                w.clear(); conv(params + L.conv2, 5); conv(params + L.conv5, 3);
-                c->off_wp[split][2] = push(w);
-                w.clear(); conv(params + L.conv3, 5); conv(params + L.conv6, 3); conv(params + L.conv8, 3);
-                c->off_wp[split][3] = push(w);
-                w.clear();
-                pack_pipe(w, params + L.conv7, 3, split != 0, expand); pack_pipe(w, params + L.conv9, 3, split != 0, expand);
-                pack_pipe(w, params + L.conv10, 3, split != 0, expand);
-                pack_lin(w, factor);
-                c->off_wp[split][4] = push(w);
-            }
+        c->pipe_ok = expand_tiles(factor) == 1;  // the pipe form of the final stage handles one N-tile
         const size_t boff[4] = {L.f_bias, L.l_bias[0], L.l_bias[1], L.l_bias[2]};
         const size_t aoff[4] = {L.f_activ, L.l_activ[0], L.l_activ[1], L.l_activ[2]};
         for (int s = 0; s < 4; ++s) c->off_bias[s] = push(vec32(boff[s], 32));
@@ -539,12 +468,10 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
     float* feat[4];
     for (int k = 0; k < 4; ++k) feat[k] = c->d_feat[k] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
-    // SRHIP_PIPE = f32 / split / all / none selects the pipe form of the stage kernels per precision (experiment switch)
-    bool pipe = false;
-    if (const char* e = getenv("SRHIP_PIPE"))
-        pipe = !strcmp(e, "all") || (!strcmp(e, "f32") && c->precision == SR_PRECISION_F32) ||
-               (!strcmp(e, "split") && c->precision == SR_PRECISION_SPLIT_F16);
-    pipe = pipe && c->pipe_ok;
+    // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent) whenever the final
+    // stage fits one N-tile; bit-identical to the first form.  SRHIP_PIPE=none forces the first form (A/B runs).
+    bool pipe = c->pipe_ok;
+    if (const char* e = getenv("SRHIP_PIPE")) pipe = pipe && strcmp(e, "none") != 0;
     const bool persist = c->precision == SR_PRECISION_SPLIT_F16 || pipe;  // see conv_stage_kernel
     if (persist) HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of all stages
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -585,7 +512,6 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
                 if (grid > resident) grid = resident;
             }
             if (pipe && th == 8) {
-                a.wpack = P + c->off_wp[c->precision ? 1 : 0][st];
                 HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, grid, img_u8, out_u8, s));
             } else {
                 HIPCHK(c, sr_launch_stage(st, c->factor, a, th, c->precision, grid, img_u8, out_u8, s));

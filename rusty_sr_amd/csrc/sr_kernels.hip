@@ -435,137 +435,157 @@ __device__ __forceinline__ void ring_advance(int& gtap, int& slot, int ntaps_tot
     else ring_barrier<0>();
 }
 
-// One source's KS x KS taps.  The weight chunk of tap t+2 is requested (LDS-DMA)
-// while tap t computes, so a chunk has two full taps (~4000 cycles) to land.
-// NTN > 1: the node has more than 32 output channels (expand at factor 4: 48 = 2 N-tiles); every
-// (tap, N-tile) pair is one 4 KB chunk of the ring and accumulates into acc[nt * T + row].
-template <int TH, int KS, int T, int NTN = 1>
-__device__ __forceinline__ void conv_taps(f32x16 (&acc)[NTN * T], const char* tile, char* ring,
-                                          const float* __restrict__ wpack, int& gtap, int& slot,
-                                          int ntaps_total, int wave, int lane) {
-    using G = TileGeom<TH, KS>;
+// ---------------------------------------------------------------------------
+// The matrix work of one HALF of a source tile (16 of its 32 input channels), shared by both kernel forms.
+// A step = two taps x one half = one 4 KB weight chunk (layout: sr_api.cpp pack_pipe); steps walk the tap
+// pairs (0,1), (2,3), ...; a lone last tap is half a step.  Both forms sum in this same order, so their
+// results are bit-identical, whatever the tile height or the staging scheme.
+//   hb     : LDS planes of this half, plane stride PS: f32 4 planes of 4 channels; split 2 hi planes of 8
+//            channels, then (LO planes further on) their 2 lo planes
+//   Stream : where the chunks come from and what else to request meanwhile
+//              begin_step<P>()        issue this step's DMA requests (next weight chunk, a piece of a tile)
+//              slot()                 ring slot of the current chunk
+//              end_step<EXTRA>(last)  wait until chunk (current + 1 + EXTRA) has landed, barrier, advance
+// Software-pipelined by hand: f32 requests operand group g+1 before the 8 MFMAs of group g and the first group
+// of the next step right after the barrier, under the last group; split (12 MFMAs = ~400 cycles per step, one
+// LDS round trip) requests the whole next step's operands before this step's MFMAs.
+// ---------------------------------------------------------------------------
+template <int TWH, int PS, int KS, int T, int NTN, typename Stream>
+__device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[NTN * T], const char* hb, const char* ring, Stream& sm, int wave, int lane) {
+    constexpr int NT = KS * KS, NP = (NT + 1) / 2;
     const int i = lane & 31, h = lane >> 5;
     const int wlane = (h * 32 + i) * 16;
-    const char* abase = tile + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
-    // One tap = 4 operand groups (8 input channels each): T tile-row vectors + one weight vector, then
-    // 4 T MFMAs.  Software-pipelined by hand: the reads of group g+1 are issued before the MFMAs of group g,
-    // and the first group of the NEXT tap right after this tap's barrier, under its last MFMA group -- so a
-    // wave streams MFMAs without waiting for LDS even while its SIMD neighbour is staging or storing.
-    // (The compiler's own schedule waited lgkmcnt(0) in front of every group: ~77 % for a wave on its own.)
+    const char* abase = hb + h * PS + ((wave * T) * TWH + i) * 16;
     struct Ops { f32x4 a[T]; f32x4 b; };
-    auto load = [&](Ops& o, int ky, int kx, int sl, int rr) {
-        const char* wb = ring + sl * 4096 + wlane;
-        const char* ab = abase + (ky * G::TWH + kx) * 16;
-        o.b = *(const f32x4*)(wb + rr * 1024);
+    // operand group q of pair p: q = 2 * tapslot + rr  (rr: which 8 of the half's 16 channels)
+    auto load = [&](Ops& o, int p, int q, int sl) {
+        const int t = 2 * p + (q >> 1), ky = t / KS, kx = t - ky * KS;
+        const char* ab = abase + (q & 1) * 2 * PS + (ky * TWH + kx) * 16;
+        o.b = *(const f32x4*)(ring + sl * 4096 + wlane + q * 1024);
 #pragma unroll
-        for (int m = 0; m < T; ++m) o.a[m] = *(const f32x4*)(ab + rr * 2 * G::PLANE + m * G::TWH * 16);
+        for (int m = 0; m < T; ++m) o.a[m] = *(const f32x4*)(ab + m * TWH * 16);
     };
     auto mfma = [&](const Ops& o, int nt) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int m = 0; m < T; ++m)
-                acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[m][q], o.b[q], acc[nt * T + m], 0, 0, 0);
+                acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[m][e], o.b[e], acc[nt * T + m], 0, 0, 0);
     };
     Ops cur, nxt;
-    load(cur, 0, 0, slot, 0);
-    for (int ky = 0; ky < KS; ++ky) {
+    load(cur, 0, 0, sm.slot());
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
-          for (int nt = 0; nt < NTN; ++nt) {
-            ring_request(ring, wpack, gtap, slot, ntaps_total, wave, lane);
+      for (int nt = 0; nt < NTN; ++nt) {
+        const int ngroups = (2 * p + 1 < NT) ? 4 : 2;
+        if (p == 0 && nt == 0) sm.template begin_step<0>();
+        else if (p == 1 && nt == 0) sm.template begin_step<1>();
+        else if (p == 2 && nt == 0) sm.template begin_step<2>();
+        else if (p == 3 && nt == 0) sm.template begin_step<3>();
+        else sm.template begin_step<99>();
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-                load(nxt, ky, kx, slot, rr + 1);
+        for (int q = 0; q < 3; ++q) {
+            if (q + 1 < ngroups) {
+                load(nxt, p, q + 1, sm.slot());
                 __builtin_amdgcn_sched_barrier(0);
                 mfma(cur, nt);
                 __builtin_amdgcn_sched_barrier(0);
                 cur = nxt;
             }
-            ring_advance(gtap, slot, ntaps_total);  // chunk gtap has landed everywhere; `slot` is now its slot
-            // first group of the next step (same tap, next N-tile; or the next tap), if this source has one
-            const bool more = !(ky == KS - 1 && kx == KS - 1 && nt == NTN - 1);
-            if (more) {
-                const int nkx = nt + 1 < NTN ? kx : (kx + 1 < KS ? kx + 1 : 0);
-                const int nky = nt + 1 < NTN ? ky : (kx + 1 < KS ? ky : ky + 1);
-                load(nxt, nky, nkx, slot, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma(cur, nt);
-            __builtin_amdgcn_sched_barrier(0);
-            cur = nxt;
-          }
         }
+        const bool last = p == NP - 1 && nt == NTN - 1;
+        sm.template end_step<0>(last);
+        if (!last) load(nxt, nt + 1 < NTN ? p : p + 1, 0, sm.slot());
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(cur, nt);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
     }
 }
 
-// Split-half flavour of conv_taps: the LDS tile planes 0-3 hold the hi halves of
-// cin groups 0-7 / 8-15 / 16-23 / 24-31, planes 4-7 the lo halves; a weight chunk
-// is [hi: 4 x 32 cout x 8 halves][lo: same].  Per tap and tile row: 2 K-steps of
-// 16 cin x 3 products = 6 v_mfma_f32_32x32x16_f16 (192 cycles vs 1024 for f32).
-// Measured and rejected on MI355X (all within +-2 % of this form): operand reads of tap
-// t+1 issued by hand (inline asm) under tap t's MFMAs; no per-tap barrier; 8-wave
-// workgroups; the finished tile's epilogue deferred into the next tile's first taps.
-// The f16 matrix core is POWER-limited on real data (scripts/ubench_f16.hip: 2305 TF
-// issued with constant operands, 1596 TF with random ones; this kernel runs the
-// chip at ~2.07 GHz and ~930 TF issued), so cycles saved come back as lower clock.
-template <int TH, int KS, int T, int NTN = 1>
-__device__ __forceinline__ void conv_taps_h(f32x16 (&accm)[NTN * T], f32x16 (&accx)[NTN * T], const char* tile, char* ring,
-                                            const float* __restrict__ wpack, int& gtap, int& slot,
-                                            int ntaps_total, int wave, int lane) {
-    using G = TileGeom<TH, KS>;
+template <int TWH, int PS, int LO, int KS, int T, int NTN, typename Stream>
+__device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&accx)[NTN * T], const char* hb, const char* ring,
+                                             Stream& sm, int wave, int lane) {
+    constexpr int NT = KS * KS, NP = (NT + 1) / 2;
     const int i = lane & 31, h = lane >> 5;
     const int wlane = (h * 32 + i) * 16;
-    const char* abase = tile + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
-    // Software-pipelined one whole step ahead: the 4 + 4 T operand vectors of step s+1 are requested at the
-    // start of step s and land under its 6 T MFMAs (a step is only ~400 cycles of matrix work, about one LDS
-    // round trip).  The weight chunk of step s+1 must therefore be in the ring when step s starts, i.e. the
-    // barrier that ends step s-1 waits for chunk s+1, one more than the f32 loop needs (ring_advance<1>).
-    struct Ops { f16x8 bh[2], bl[2], ah[2][T], al[2][T]; };
-    auto load = [&](Ops& o, int ky, int kx, int sl) {
+    const char* abase = hb + h * PS + ((wave * T) * TWH + i) * 16;
+    struct Ops { f16x8 bh[2], bl[2], ah[2][T], al[2][T]; };  // chunk = [hi tap0 | hi tap1 | lo tap0 | lo tap1]
+    auto load = [&](Ops& o, int p, int sl) {
         const char* wb = ring + sl * 4096 + wlane;
-        const char* ab = abase + (ky * G::TWH + kx) * 16;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            o.bh[kk] = *(const f16x8*)(wb + kk * 1024);
-            o.bl[kk] = *(const f16x8*)(wb + 2048 + kk * 1024);
+        for (int ts = 0; ts < 2; ++ts) {
+            const int t = 2 * p + ts;
+            if (t < NT) {
+                const int ky = t / KS, kx = t - ky * KS;
+                const char* ab = abase + (ky * TWH + kx) * 16;
+                o.bh[ts] = *(const f16x8*)(wb + ts * 1024);
+                o.bl[ts] = *(const f16x8*)(wb + 2048 + ts * 1024);
 #pragma unroll
-            for (int m = 0; m < T; ++m) {
-                o.ah[kk][m] = *(const f16x8*)(ab + (kk * 2) * G::PLANE + m * G::TWH * 16);
-                o.al[kk][m] = *(const f16x8*)(ab + (4 + kk * 2) * G::PLANE + m * G::TWH * 16);
+                for (int m = 0; m < T; ++m) {
+                    o.ah[ts][m] = *(const f16x8*)(ab + m * TWH * 16);
+                    o.al[ts][m] = *(const f16x8*)(ab + LO * PS + m * TWH * 16);
+                }
             }
         }
     };
     Ops cur, nxt;
-    load(cur, 0, 0, slot);
-    for (int ky = 0; ky < KS; ++ky) {
+    load(cur, 0, sm.slot());
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
-          for (int nt = 0; nt < NTN; ++nt) {
-            ring_request(ring, wpack, gtap, slot, ntaps_total, wave, lane);
-            const bool more = !(ky == KS - 1 && kx == KS - 1 && nt == NTN - 1);
-            if (more) {
-                const int nkx = nt + 1 < NTN ? kx : (kx + 1 < KS ? kx + 1 : 0);
-                const int nky = nt + 1 < NTN ? ky : (kx + 1 < KS ? ky : ky + 1);
-                load(nxt, nky, nkx, slot == kRingSlots - 1 ? 0 : slot + 1);
+      for (int nt = 0; nt < NTN; ++nt) {
+        if (p == 0 && nt == 0) sm.template begin_step<0>();
+        else if (p == 1 && nt == 0) sm.template begin_step<1>();
+        else if (p == 2 && nt == 0) sm.template begin_step<2>();
+        else if (p == 3 && nt == 0) sm.template begin_step<3>();
+        else sm.template begin_step<99>();
+        const bool last = p == NP - 1 && nt == NTN - 1;
+        if (!last) load(nxt, nt + 1 < NTN ? p : p + 1, sm.slot() == kRingSlots - 1 ? 0 : sm.slot() + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts) {
+            if (2 * p + ts < NT) {
+#pragma unroll
+                for (int m = 0; m < T; ++m) accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bh[ts], accm[nt * T + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bl[ts], accx[nt * T + m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[ts][m], cur.bh[ts], accx[nt * T + m], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int m = 0; m < T; ++m) accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[kk][m], cur.bh[kk], accm[nt * T + m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[kk][m], cur.bl[kk], accx[nt * T + m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[kk][m], cur.bh[kk], accx[nt * T + m], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ring_advance<1>(gtap, slot, ntaps_total);
-            cur = nxt;
-          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        sm.template end_step<1>(last);
+        cur = nxt;
+      }
+    }
+}
+
+// Stream of the first kernel form: the whole tile is resident, chunks come through the ring in step order.
+struct RingStream {
+    char* ring;
+    const float* __restrict__ wpack;
+    int& gtap;
+    int& slot_;
+    int ntotal, wave, lane;
+    template <int P> __device__ __forceinline__ void begin_step() { ring_request(ring, wpack, gtap, slot_, ntotal, wave, lane); }
+    __device__ __forceinline__ int slot() const { return slot_; }
+    template <int EXTRA> __device__ __forceinline__ void end_step(bool) { ring_advance<EXTRA>(gtap, slot_, ntotal); }
+};
+
+// Both halves of one resident source tile (first kernel form).  f32 planes: 8 channel groups of 4; split planes:
+// 4 hi groups of 8 channels, then their 4 lo groups.
+template <int TH, int KS, int T, int NTN, int PREC>
+__device__ __forceinline__ void source_steps(f32x16 (&acc)[NTN * T], f32x16 (&accx)[PREC == 1 ? NTN * T : 1], const char* tile, char* ring,
+                                             const float* __restrict__ wpack, int& gtap, int& slot, int ntotal, int wave, int lane) {
+    using G = TileGeom<TH, KS>;
+    RingStream sm{ring, wpack, gtap, slot, ntotal, wave, lane};
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if constexpr (PREC == 0) half_steps_f32<G::TWH, G::PLANE, KS, T, NTN>(acc, tile + half * 4 * G::PLANE, ring, sm, wave, lane);
+        else half_steps_h<G::TWH, G::PLANE, 4, KS, T, NTN>(acc, accx, tile + half * 2 * G::PLANE, ring, sm, wave, lane);
     }
 }
 
@@ -749,7 +769,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    constexpr int NTAPS = (KS0 * KS0 + (NSRC - 1) * 9) * NTN;  // ring chunks: one per (tap, N-tile)
+    constexpr int NTAPS = 2 * ((KS0 * KS0 + 1) / 2 + (NSRC - 1) * 5) * NTN;  // ring chunks: one per (step, N-tile), see half_steps_*
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = tiles_per_img * a.n_img;
     const int xcd = blockIdx.x & 7;
@@ -797,8 +817,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
         int gtap = 0, slot = 0;
         auto taps = [&](auto ks_tag) {
             constexpr int KS = decltype(ks_tag)::value;
-            if constexpr (PREC == 0) conv_taps<TH, KS, T, NTN>(acc, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
-            else conv_taps_h<TH, KS, T, NTN>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+            source_steps<TH, KS, T, NTN, PREC>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
         };
         TL(0); TL(1);
         ring_barrier<0>();  // every wave's tile + weight DMAs (and earlier stores) have landed
@@ -962,124 +981,28 @@ __device__ __forceinline__ void request_piece(const HalfRequest& rq, const HalfT
 }
 
 
-// The steps of one half-source, exact f32.  hb: LDS half tile (4 planes of 4 channels).
-template <int KS, int T, int KSN>
-__device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[T], const char* hb, char* ring, const StageArgs& a,
-                                               StepStream& st, const HalfRequest& rq, const HalfTile<KSN>& htn, int wave, int lane,
-                                               volatile int* mailbox, int xcd, int ntiles, int pulled, bool publish) {
-    const float* __restrict__ wpack = a.wpack;
-    int* queue = a.queue;
-    using G = TileGeom<8, KS>;
-    constexpr int NT = KS * KS, NP = (NT + 1) / 2;
-    const int i = lane & 31, h = lane >> 5;
-    const int wlane = (h * 32 + i) * 16;
-    const char* abase = hb + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
-    struct Ops { f32x4 a[T]; f32x4 b; };
-    // operand group q of pair p: q = 2 * tapslot + rr  (rr: which 8 of the half's 16 channels)
-    auto load = [&](Ops& o, int p, int q, int sl) {
-        const int t = 2 * p + (q >> 1), ky = t / KS, kx = t - ky * KS;
-        const char* ab = abase + (q & 1) * 2 * G::PLANE + (ky * G::TWH + kx) * 16;
-        o.b = *(const f32x4*)(ring + sl * 4096 + wlane + q * 1024);
-#pragma unroll
-        for (int m = 0; m < T; ++m) o.a[m] = *(const f32x4*)(ab + m * G::TWH * 16);
-    };
-    auto mfma = [&](const Ops& o) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int m = 0; m < T; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[m][e], o.b[e], acc[m], 0, 0, 0);
-    };
-    Ops cur, nxt;
-    load(cur, 0, 0, st.slot);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        constexpr int dummy = 0; (void)dummy;
-        const int ngroups = (2 * p + 1 < NT) ? 4 : 2;
-        if (p == 0) request_piece<0, KSN, 0>(rq, htn, a, st, wave);
-        if (p == 1) request_piece<0, KSN, 1>(rq, htn, a, st, wave);
-        if (p == 2) request_piece<0, KSN, 2>(rq, htn, a, st, wave);
-        if (p == 3) request_piece<0, KSN, 3>(rq, htn, a, st, wave);
-        step_request(st, ring, wpack, wave, lane);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (q + 1 < ngroups) {
-                load(nxt, p, q + 1, st.slot);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma(cur);
-                __builtin_amdgcn_sched_barrier(0);
-                cur = nxt;
-            }
-        }
-        if (publish && p == NP - 1 && threadIdx.x == 0) *mailbox = queue_resolve(queue, xcd, ntiles, pulled);
-        step_advance<0>(st, p == NP - 1);
-        if (p + 1 < NP) load(nxt, p + 1, 0, st.slot);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
+// Stream of the pipe form: chunks through the ring with sequence-numbered waits, plus a piece of the next half
+// tile in each of the first four steps; the first half of a tile also publishes the next tile's number.
+template <int PREC, int KSN>
+struct PipeStream {
+    StepStream& st;
+    const HalfRequest& rq;
+    const HalfTile<KSN>& htn;
+    const StageArgs& a;
+    char* ring;
+    int wave, lane;
+    volatile int* mailbox;  // non-null: write queue_resolve(...) there before the last step's barrier
+    int xcd, ntiles, pulled;
+    template <int P> __device__ __forceinline__ void begin_step() {
+        if constexpr (P < 4) request_piece<PREC, KSN, P>(rq, htn, a, st, wave);
+        step_request(st, ring, a.wpack, wave, lane);
     }
-}
-
-// The steps of one half-source, split-half arithmetic.  hb planes: 0, 1 = hi halves of channels 0-7 / 8-15 of
-// this half, 2, 3 = their lo halves; chunk = [hi tap0 | hi tap1 | lo tap0 | lo tap1], 1 KB each.
-template <int KS, int T, int KSN>
-__device__ __forceinline__ void half_steps_h(f32x16 (&accm)[T], f32x16 (&accx)[T], const char* hb, char* ring,
-                                             const StageArgs& a, StepStream& st, const HalfRequest& rq, const HalfTile<KSN>& htn,
-                                             int wave, int lane, volatile int* mailbox, int xcd, int ntiles, int pulled, bool publish) {
-    const float* __restrict__ wpack = a.wpack;
-    int* queue = a.queue;
-    using G = TileGeom<8, KS>;
-    constexpr int NT = KS * KS, NP = (NT + 1) / 2;
-    const int i = lane & 31, h = lane >> 5;
-    const int wlane = (h * 32 + i) * 16;
-    const char* abase = hb + h * G::PLANE + ((wave * T) * G::TWH + i) * 16;
-    struct Ops { f16x8 bh[2], bl[2], ah[2][T], al[2][T]; };
-    auto load = [&](Ops& o, int p, int sl) {
-        const char* wb = ring + sl * 4096 + wlane;
-#pragma unroll
-        for (int ts = 0; ts < 2; ++ts) {
-            const int t = 2 * p + ts;
-            if (t < NT) {
-                const int ky = t / KS, kx = t - ky * KS;
-                const char* ab = abase + (ky * G::TWH + kx) * 16;
-                o.bh[ts] = *(const f16x8*)(wb + ts * 1024);
-                o.bl[ts] = *(const f16x8*)(wb + 2048 + ts * 1024);
-#pragma unroll
-                for (int m = 0; m < T; ++m) {
-                    o.ah[ts][m] = *(const f16x8*)(ab + m * G::TWH * 16);
-                    o.al[ts][m] = *(const f16x8*)(ab + 2 * G::PLANE + m * G::TWH * 16);
-                }
-            }
-        }
-    };
-    Ops cur, nxt;
-    load(cur, 0, st.slot);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        if (p == 0) request_piece<1, KSN, 0>(rq, htn, a, st, wave);
-        if (p == 1) request_piece<1, KSN, 1>(rq, htn, a, st, wave);
-        if (p == 2) request_piece<1, KSN, 2>(rq, htn, a, st, wave);
-        if (p == 3) request_piece<1, KSN, 3>(rq, htn, a, st, wave);
-        step_request(st, ring, wpack, wave, lane);
-        if (p + 1 < NP) load(nxt, p + 1, st.slot == kRingSlots - 1 ? 0 : st.slot + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ts = 0; ts < 2; ++ts) {
-            if (2 * p + ts < NT) {
-#pragma unroll
-                for (int m = 0; m < T; ++m) accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bh[ts], accm[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bl[ts], accx[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < T; ++m) accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[ts][m], cur.bh[ts], accx[m], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (publish && p == NP - 1 && threadIdx.x == 0) *mailbox = queue_resolve(queue, xcd, ntiles, pulled);
-        step_advance<1>(st, p == NP - 1);
-        cur = nxt;
+    __device__ __forceinline__ int slot() const { return st.slot; }
+    template <int EXTRA> __device__ __forceinline__ void end_step(bool last) {
+        if (last && mailbox && threadIdx.x == 0) *mailbox = queue_resolve(a.queue, xcd, ntiles, pulled);
+        step_advance<EXTRA>(st, last);
     }
-}
+};
 
 template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, int FACTOR = 3>
 __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
@@ -1165,8 +1088,10 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             else rq = HalfRequest{st.have_next, other, a.src[0], 0, nn, ny0, nx0};
             const HalfTile<KSN>* htn;
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
-            if constexpr (PREC == 0) half_steps_f32<KSJ, T, KSN>(acc, hb, ring, a, st, rq, *htn, wave, lane, s_next, xcd, ntiles, pulled, j == 0);
-            else half_steps_h<KSJ, T, KSN>(acc, accx, hb, ring, a, st, rq, *htn, wave, lane, s_next, xcd, ntiles, pulled, j == 0);
+            using GJ = TileGeom<8, KSJ>;
+            PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring, wave, lane, j == 0 ? s_next : nullptr, xcd, ntiles, pulled};
+            if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, 1>(acc, hb, ring, sm, wave, lane);
+            else half_steps_h<GJ::TWH, GJ::PLANE, 2, KSJ, T, 1>(acc, accx, hb, ring, sm, wave, lane);
         };
         do_half(std::integral_constant<int, 0>{});
         do_half(std::integral_constant<int, 1>{});

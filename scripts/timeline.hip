@@ -15,7 +15,7 @@ int main(int argc, char** argv) {
     for (auto& p : f) { hipMalloc(&p, npx * 128); hipMemset(p, 0, npx * 128); }
     hipMalloc(&dst, npx * 128); hipMalloc(&out, (size_t)H * W * 9 * 12);
     const size_t org = ((size_t)2 * pitch + 2) * 32;
-    hipMalloc(&w, 43 * 4096); hipMemset(w, 0, 43 * 4096);
+    hipMalloc(&w, 64 * 4096); hipMemset(w, 0, 64 * 4096);
     hipMalloc(&bias, 256); hipMemset(bias, 0, 256);
     StageArgs a{};
     a.src[0] = f[0] + org; a.src[1] = f[1] + org; a.src[2] = f[2] + org; a.wpack = w; a.bias = bias; a.beta = bias; a.dst = dst + org;
