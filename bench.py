@@ -58,8 +58,24 @@ def synth_u8(seed, h, w):
     return (s // 25).astype(np.uint8)
 
 
-STAGE_KERNEL = {1: "conv_stage_kernel<8, 1, 5", 2: "conv_stage_kernel<8, 2, 5", 3: "conv_stage_kernel<8, 3, 5",
-                4: "conv_stage_kernel<8, 3, 3", 0: "conv0_kernel<8"}
+STAGE_SHAPE = {1: (1, 5), 2: (2, 5), 3: (3, 5), 4: (3, 3)}  # stage -> (sources, first kernel size)
+
+
+def kernel_matches(name, stage, precision):
+    """Does a rocprofv3 kernel name belong to this stage in this arithmetic mode (factor-3 instance)?
+    pipe form : conv_stage_pipe_kernel<NSRC, KS0, FINAL, IMG_U8, OUT_U8, PREC, FACTOR>
+    first form: conv_stage_kernel<TH, NSRC, KS0, FINAL, IMG_U8, OUT_U8, PREC, PERSIST, NW[, FACTOR]>"""
+    prec = 0 if precision == "f32" else 1
+    if stage == 0:
+        return name.startswith("void conv0_kernel<8") and name.rstrip(">(Conv0Args)").endswith(f", {prec}")
+    nsrc, ks = STAGE_SHAPE[stage]
+    if f"conv_stage_pipe_kernel<{nsrc}, {ks}, " in name:
+        args = name[name.index("<") + 1:name.rindex(">")].split(", ")
+        return int(args[5]) == prec and int(args[6]) == 3
+    if f"conv_stage_kernel<8, {nsrc}, {ks}, " in name:
+        args = name[name.index("<") + 1:name.rindex(">")].split(", ")
+        return int(args[6]) == prec and (len(args) < 10 or int(args[9]) == 3)
+    return False
 
 
 def pmc_traffic(stage, H, W, precision="f32"):
@@ -71,9 +87,8 @@ def pmc_traffic(stage, H, W, precision="f32"):
         return None
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        tag = ", 0, false, 4" if precision == "f32" else ", 1, true, 4"
-        names = [n for n in d if STAGE_KERNEL[stage] in n and tag in n and "hbm_read_bytes" in d[n]]
-        names.sort(key=lambda n: 0 if (", 4, 3>" in n or n.endswith(", 4>(StageArgs)")) else 1)  # the factor-3 instance
+        names = [n for n in d if kernel_matches(n, stage, precision) and "hbm_read_bytes" in d[n]]
+        names.sort(key=lambda n: 0 if "pipe" in n else 1)  # the form the engine runs at this size
         if names:
             v = d[names[0]]
             return {"hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v.get("hbm_write_bytes", 0)),
@@ -238,7 +253,7 @@ def main():
             peak, issued = PEAK_F16_MFMA_TFLOPS, 3 * ach
             note = ("v_mfma_f32_32x32x16_f16, 3 products per algorithmic product: achieved counts ALGORITHMIC FLOPs "
                     f"against the f16 dense peak (issued rate {issued:.1f} TFLOP/s); the ceiling of this scheme is peak/3")
-        result["roofline"] = {"bound": "mfma", "kernel": f"conv_stage_kernel stage {k}", "achieved": round(ach, 2),
+        result["roofline"] = {"bound": "mfma", "kernel": f"stage {k} (conv_stage_pipe_kernel<{STAGE_SHAPE[k][0]}, {STAGE_SHAPE[k][1]}, ...>)" if k else "conv0_kernel", "achieved": round(ach, 2),
                               "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                               "traffic": pmc_traffic(k, H, W, args.precision),
                               "avg_launch_ms": round(float(stage_ms[k]), 4), "note": note}

@@ -479,15 +479,12 @@ __device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[NTN * T], const cha
 #pragma unroll
       for (int nt = 0; nt < NTN; ++nt) {
         const int ngroups = (2 * p + 1 < NT) ? 4 : 2;
-        if (p == 0 && nt == 0) sm.template begin_step<0>();
-        else if (p == 1 && nt == 0) sm.template begin_step<1>();
-        else if (p == 2 && nt == 0) sm.template begin_step<2>();
-        else if (p == 3 && nt == 0) sm.template begin_step<3>();
-        else sm.template begin_step<99>();
+        sm.begin_step();
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             if (q + 1 < ngroups) {
                 load(nxt, p, q + 1, sm.slot());
+                if (nt == 0) sm.piece((p * 4 + q) / NTN);  // one gather instruction per operand group
                 __builtin_amdgcn_sched_barrier(0);
                 mfma(cur, nt);
                 __builtin_amdgcn_sched_barrier(0);
@@ -497,6 +494,7 @@ __device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[NTN * T], const cha
         const bool last = p == NP - 1 && nt == NTN - 1;
         sm.template end_step<0>(last);
         if (!last) load(nxt, nt + 1 < NTN ? p : p + 1, 0, sm.slot());
+        if (nt == 0) sm.piece((p * 4 + 3) / NTN);
         __builtin_amdgcn_sched_barrier(0);
         mfma(cur, nt);
         __builtin_amdgcn_sched_barrier(0);
@@ -537,13 +535,10 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int nt = 0; nt < NTN; ++nt) {
-        if (p == 0 && nt == 0) sm.template begin_step<0>();
-        else if (p == 1 && nt == 0) sm.template begin_step<1>();
-        else if (p == 2 && nt == 0) sm.template begin_step<2>();
-        else if (p == 3 && nt == 0) sm.template begin_step<3>();
-        else sm.template begin_step<99>();
+        sm.begin_step();
         const bool last = p == NP - 1 && nt == NTN - 1;
         if (!last) load(nxt, nt + 1 < NTN ? p : p + 1, sm.slot() == kRingSlots - 1 ? 0 : sm.slot() + 1);
+        if (nt == 0) { sm.piece(2 * p); sm.piece(2 * p + 1); }  // two gather instructions per step
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts) {
@@ -570,7 +565,8 @@ struct RingStream {
     int& gtap;
     int& slot_;
     int ntotal, wave, lane;
-    template <int P> __device__ __forceinline__ void begin_step() { ring_request(ring, wpack, gtap, slot_, ntotal, wave, lane); }
+    __device__ __forceinline__ void begin_step() { ring_request(ring, wpack, gtap, slot_, ntotal, wave, lane); }
+    __device__ __forceinline__ void piece(int) {}
     __device__ __forceinline__ int slot() const { return slot_; }
     template <int EXTRA> __device__ __forceinline__ void end_step(bool) { ring_advance<EXTRA>(gtap, slot_, ntotal); }
 };
@@ -914,6 +910,14 @@ struct HalfTile {
 #pragma unroll
         for (int g = G0; g < G1 && g < G::NG; ++g) lds_dma16<0>(origin, off[g], dst + g * 1024);
     }
+    // one gather instruction of that request: pixel group g (64 tile pixels) of this wave's plane
+    template <int PREC>
+    __device__ __forceinline__ void stage_one(int g, uint32_t buf, const float* __restrict__ src, int khalf, long img_stride,
+                                              int pitch, int n, int y0, int x0, int wave) const {
+        const int chunk = PREC == 0 ? 4 * khalf + wave : (wave < 2 ? 2 * khalf + wave : 4 + 2 * khalf + (wave - 2));
+        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) + chunk * 16);
+        lds_dma16<0>(origin, off[g], __builtin_amdgcn_readfirstlane(buf + wave * G::PLANE + g * 1024));
+    }
 };
 
 // Bookkeeping of the pipe form's DMA traffic.  Every LDS-DMA instruction a wave issues gets a sequence number;
@@ -968,17 +972,6 @@ struct HalfRequest {
     const float* src;
     int khalf, n, y0, x0;
 };
-template <int PREC, int KSN, int P>
-__device__ __forceinline__ void request_piece(const HalfRequest& rq, const HalfTile<KSN>& ht, const StageArgs& a, StepStream& st, int wave) {
-    constexpr int g0 = 2 * P, g1 = 2 * P + 2, ng = HalfTile<KSN>::G::NG;
-    if constexpr (g0 < ng) {
-        if (rq.active) {
-            ht.template stage<PREC, g0, g1>(rq.buf, rq.src, rq.khalf, a.img_stride, a.pitch, rq.n, rq.y0, rq.x0, wave);
-            st.issued += (g1 < ng ? g1 : ng) - g0;
-            st.tile_seq = st.issued;
-        }
-    }
-}
 
 
 // Stream of the pipe form: chunks through the ring with sequence-numbered waits, plus a piece of the next half
@@ -993,9 +986,13 @@ struct PipeStream {
     int wave, lane;
     volatile int* mailbox;  // non-null: write queue_resolve(...) there before the last step's barrier
     int xcd, ntiles, pulled;
-    template <int P> __device__ __forceinline__ void begin_step() {
-        if constexpr (P < 4) request_piece<PREC, KSN, P>(rq, htn, a, st, wave);
-        step_request(st, ring, a.wpack, wave, lane);
+    __device__ __forceinline__ void begin_step() { step_request(st, ring, a.wpack, wave, lane); }
+    // gather instruction number g of the half tile being requested (compile-time after unrolling)
+    __device__ __forceinline__ void piece(int g) {
+        if (g < HalfTile<KSN>::G::NG && rq.active) {
+            htn.template stage_one<PREC>(g, rq.buf, rq.src, rq.khalf, a.img_stride, a.pitch, rq.n, rq.y0, rq.x0, wave);
+            st.tile_seq = ++st.issued;
+        }
     }
     __device__ __forceinline__ int slot() const { return st.slot; }
     template <int EXTRA> __device__ __forceinline__ void end_step(bool last) {
