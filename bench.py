@@ -67,7 +67,7 @@ def kernel_matches(name, stage, precision):
     first form: conv_stage_kernel<TH, NSRC, KS0, FINAL, IMG_U8, OUT_U8, PREC, PERSIST, NW[, FACTOR]>"""
     prec = 0 if precision == "f32" else 1
     if stage == 0:
-        return name.startswith("void conv0_kernel<8") and name.rstrip(">(Conv0Args)").endswith(f", {prec}")
+        return name.startswith("void conv0_kernel<8, ") and name[name.index("<") + 1:name.rindex(">")].split(", ")[-1] == str(prec)
     nsrc, ks = STAGE_SHAPE[stage]
     if f"conv_stage_pipe_kernel<{nsrc}, {ks}, " in name:
         args = name[name.index("<") + 1:name.rindex(">")].split(", ")
