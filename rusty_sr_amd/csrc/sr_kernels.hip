@@ -1003,6 +1003,8 @@ struct PipeStream {
 
 template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, int FACTOR = 3>
 __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
+    TL_BEGIN();
+    TL_DECL();
     __builtin_amdgcn_s_setprio(3);
     constexpr int TH = 8, T = 2, NTN = 1;
     static_assert(!FINAL || FACTOR * FACTOR <= 10, "one N-tile only");
@@ -1063,6 +1065,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
                 acc[m][r] = 0.f;
                 if constexpr (PREC == 1) accx[m][r] = 0.f;
             }
+        TL(0); TL(1);
         int pulled = 0;
         if (tid == 0) pulled = atomicAdd(&a.queue[xcd], 1);  // the answer is looked at by the end of half 0
         int nn = 0, nx0 = 0, ny0 = 0, next = -1;
@@ -1092,8 +1095,11 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         };
         do_half(std::integral_constant<int, 0>{});
         do_half(std::integral_constant<int, 1>{});
+        TL(2);
         if constexpr (NH > 2) { do_half(std::integral_constant<int, 2>{}); do_half(std::integral_constant<int, 3>{}); }
+        TL(3);
         if constexpr (NH > 4) { do_half(std::integral_constant<int, 4>{}); do_half(std::integral_constant<int, 5>{}); }
+        TL(4);
         if constexpr (FINAL) {
             // bilinear residual: image tile + fixed weights staged in the buffer the last half has left (buffer 1)
             char* lin = smem + HB;
@@ -1101,11 +1107,14 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
         }
+        TL(5); TL(6); TL(8);
         stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
+        TL(7);
         if (!st.have_next) break;
         n = nn; x0 = nx0; y0 = ny0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
+    TL_END();
 }
 
 // ---------------------------------------------------------------------------

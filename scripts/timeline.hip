@@ -3,11 +3,13 @@
 #define SR_TIMELINE 1
 #include "../rusty_sr_amd/csrc/sr_kernels.hip"
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <cstdio>
 #include <vector>
 int main(int argc, char** argv) {
     const int stage = argc > 1 ? atoi(argv[1]) : 1, th = argc > 2 ? atoi(argv[2]) : 8, prec = argc > 3 ? atoi(argv[3]) : 0;
+    const bool pipe = argc > 4 && !strcmp(argv[4], "pipe");  // the pipe form (8-row tiles, persistent)
     const int H = 1080, W = 1920;
     const int pitch = W + 4; const long img_stride = (long)(H + 14) * pitch;
     const size_t npx = (size_t)img_stride + 2 * pitch + 64;
@@ -26,13 +28,14 @@ int main(int argc, char** argv) {
     int nblk = a.tiles_x * a.tiles_y; a.n_img = 1; int* dq; hipMalloc(&dq, 64); hipMemset(dq, 0, 64); a.queue = dq;
     long long* tl; hipMalloc(&tl, (size_t)nblk * 128);
     hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &tl, sizeof(tl));
-    if (prec == 1 || getenv("TL_PERSIST")) nblk = 512;  // persistent form: co-resident workgroups pull tiles from the queue
+    if (prec == 1 || pipe || getenv("TL_PERSIST")) nblk = 512;  // persistent form: co-resident workgroups pull tiles from the queue
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int rep = 0; rep < 6; ++rep) {
         hipMemset(dq, 0, 64);
         hipEventRecord(e0, 0);
-        sr_launch_stage(stage, 3, a, th, prec, nblk, false, false, 0);
+        if (pipe) sr_launch_stage_pipe(stage, 3, a, prec, nblk, false, false, 0);
+        else sr_launch_stage(stage, 3, a, th, prec, nblk, false, false, 0);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -50,6 +53,17 @@ int main(int argc, char** argv) {
         printf("  %-28s mean %9.0f  p10 %8lld  p50 %8lld  p90 %8lld  max %8lld cycles\n", name, s / nblk,
                d[nblk / 10], d[nblk / 2], d[nblk * 9 / 10], d[nblk - 1]);
     };
+    if (pipe) {
+        printf("pipe form, prec %d, stage %d, %d workgroups; sums over the tiles of a workgroup (thread 0, s_memtime cycles)\n", prec, stage, nblk);
+        stat("source 0 (both halves)", 1, 2);
+        if (stage >= 2) stat("source 1", 2, 3);
+        if (stage >= 3) stat("source 2", 3, 4);
+        if (stage == 4) stat("bilinear taps", 4, 5);
+        stat("epilogue", 8, 7); stat("all tiles of the workgroup", 1, 7);
+        double tiles = 0; for (int b = 0; b < nblk; ++b) tiles += (double)h[b * 16 + 12];
+        printf("  tiles per workgroup: %.2f\n", tiles / nblk);
+        return 0;
+    }
     printf("prec %d, ", prec); printf("stage %d, TH=%d, %d workgroups (timestamps of thread 0; s_memtime shader cycles)\n", stage, th, nblk);
     stat("stage tile src0", 1, 2); stat("taps src0", 2, 3);
     if (stage >= 2) { stat("stage tile src1", 3, 4); stat("taps src1", 4, 5); stat("src2 (stage+taps)", 5, 6); }
