@@ -78,10 +78,12 @@ void pack_steps(std::vector<float>& dst, const float* w, int ks, int ntn, bool s
                 for (int ts = 0; ts < 2; ++ts) {
                     const int t = 2 * p + ts;
                     if (t >= nt) continue;
+                    // the split loop walks the taps column by column (row re-use, half_steps_h), the f32 loop row by row
+                    const int tap = split ? (t % ks) * ks + t / ks : t;
                     for (int j = 0; j < 32; ++j) {
                         const int o = lane_channel(tile, j);
                         if (o < 0) continue;
-                        const float* src = w + ((size_t)o * nt + t) * 32 + 16 * half;
+                        const float* src = w + ((size_t)o * nt + tap) * 32 + 16 * half;
                         for (int c = 0; c < 16; ++c) {
                             if (!split) {
                                 const int rr = c / 8, h = (c / 4) % 2, e = c % 4;

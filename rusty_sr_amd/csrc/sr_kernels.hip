@@ -511,33 +511,62 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
     const int wlane = (h * 32 + i) * 16;
     const char* abase = hb + h * PS + ((wave * T) * TWH + i) * 16;
     struct Ops { f16x8 bh[2], bl[2], ah[2][T], al[2][T]; };  // chunk = [hi tap0 | hi tap1 | lo tap0 | lo tap1]
-    auto load = [&](Ops& o, int p, int sl) {
+    // The split loop walks the taps COLUMN by column (tap t = kernel column t / KS, kernel row t % KS): row m of
+    // tap (ky, kx) is tile row ky + m of column kx, so vertically adjacent taps share tile rows.  A row that the
+    // current or the previous step already holds is copied between registers instead of read again: 12 LDS reads
+    // per 5-tap column and half instead of 20.  This mode is bound by LDS operand traffic (one ds_read_b128 per
+    // lane per 32-cycle MFMA saturates the LDS at full MFMA rate), VALU copies are free here.
+    auto row_id = [](int p, int ts, int m) {  // which (column, tile row) operand slot (ts, m) of step p holds; < 0: none
+        const int t = 2 * p + ts;
+        return t < NT ? (t / KS) * 16 + (t % KS) + m : -1;
+    };
+    auto load = [&](Ops& o, const Ops& prev, int pp, int p, int sl) {  // pp: the step `prev` holds, or -1
         const char* wb = ring + sl * 4096 + wlane;
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts) {
             const int t = 2 * p + ts;
-            if (t < NT) {
-                const int ky = t / KS, kx = t - ky * KS;
-                const char* ab = abase + (ky * TWH + kx) * 16;
-                o.bh[ts] = *(const f16x8*)(wb + ts * 1024);
-                o.bl[ts] = *(const f16x8*)(wb + 2048 + ts * 1024);
+            if (t >= NT) continue;
+            o.bh[ts] = *(const f16x8*)(wb + ts * 1024);
+            o.bl[ts] = *(const f16x8*)(wb + 2048 + ts * 1024);
 #pragma unroll
-                for (int m = 0; m < T; ++m) {
-                    o.ah[ts][m] = *(const f16x8*)(ab + m * TWH * 16);
-                    o.al[ts][m] = *(const f16x8*)(ab + LO * PS + m * TWH * 16);
+            for (int m = 0; m < T; ++m) {
+                const int id = row_id(p, ts, m);
+                bool have = false;
+#pragma unroll
+                for (int ts2 = 0; ts2 < 2; ++ts2)
+#pragma unroll
+                    for (int m2 = 0; m2 < T; ++m2) {
+                        if (!have && (ts2 * T + m2) < (ts * T + m) && row_id(p, ts2, m2) == id) {
+                            o.ah[ts][m] = o.ah[ts2][m2]; o.al[ts][m] = o.al[ts2][m2]; have = true;
+                        }
+                    }
+#pragma unroll
+                for (int ts2 = 0; ts2 < 2; ++ts2)
+#pragma unroll
+                    for (int m2 = 0; m2 < T; ++m2) {
+                        if (!have && pp >= 0 && row_id(pp, ts2, m2) == id) {
+                            o.ah[ts][m] = prev.ah[ts2][m2]; o.al[ts][m] = prev.al[ts2][m2]; have = true;
+                        }
+                    }
+                if (!have) {
+                    const int kx = t / KS, ky = t - kx * KS;
+                    const char* ab = abase + ((ky + m) * TWH + kx) * 16;
+                    o.ah[ts][m] = *(const f16x8*)ab;
+                    o.al[ts][m] = *(const f16x8*)(ab + LO * PS);
                 }
             }
         }
     };
     Ops cur, nxt;
-    load(cur, 0, sm.slot());
+    load(cur, cur, -1, 0, sm.slot());
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int nt = 0; nt < NTN; ++nt) {
         sm.begin_step();
         const bool last = p == NP - 1 && nt == NTN - 1;
-        if (!last) load(nxt, nt + 1 < NTN ? p : p + 1, sm.slot() == kRingSlots - 1 ? 0 : sm.slot() + 1);
+        // (with two N-tiles the same taps run again on the next chunk: everything is found in `cur`)
+        if (!last) load(nxt, cur, p, nt + 1 < NTN ? p : p + 1, sm.slot() == kRingSlots - 1 ? 0 : sm.slot() + 1);
         if (nt == 0) { sm.piece(2 * p); sm.piece(2 * p + 1); }  // two gather instructions per step
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
