@@ -614,6 +614,32 @@ __device__ __forceinline__ void source_steps(f32x16 (&acc)[NTN * T], f32x16 (&ac
     }
 }
 
+// The nine fixed-weight taps of the bilinear residual on a staged image tile s_x ([pixel][4] f32, edge-replicated)
+// with the weights s_w (9 x NTN x 128 floats) -- shared by both kernel forms.
+template <int TH, int T, int NTN>
+__device__ __forceinline__ void lin_mfma(f32x16 (&acc)[NTN * T], const float* s_x, const float* s_w, int wave, int lane) {
+    constexpr int TWH = kTW + 2;
+    const int i = lane & 31, h = lane >> 5;
+    const float* xa = s_x + ((wave * T) * TWH + i) * 4 + h * 2;
+    const float* wb = s_w + (h * 32 + i) * 2;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                const f32x2 b = *(const f32x2*)(wb + ((ky * 3 + kx) * NTN + nt) * 128);
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    const f32x2 av = *(const f32x2*)(xa + ((m + ky) * TWH + kx) * 4);
+                    acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[nt * T + m], 0, 0, 0);
+                    acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[nt * T + m], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
 // Final stage only: the bilinear x3 residual (LinearInterp, network.rs:27) as nine
 // more taps of a 4-channel (RGB + zero) source.  The image tile is staged with
 // edge-REPLICATED coordinates (the interp clamps indices, it does not zero-pad),
@@ -640,25 +666,7 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], char* tile, cha
         *(f32x4*)&s_x[p * 4] = v;
     }
     __syncthreads();
-    const int i = lane & 31, h = lane >> 5;
-    const float* xa = s_x + ((wave * T) * TWH + i) * 4 + h * 2;
-    const float* wb = s_w + (h * 32 + i) * 2;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) {
-                const f32x2 b = *(const f32x2*)(wb + ((ky * 3 + kx) * NTN + nt) * 128);
-#pragma unroll
-                for (int m = 0; m < T; ++m) {
-                    const f32x2 av = *(const f32x2*)(xa + ((m + ky) * TWH + kx) * 4);
-                    acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[nt * T + m], 0, 0, 0);
-                    acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[nt * T + m], 0, 0, 0);
-                }
-            }
-        }
-    }
+    lin_mfma<TH, T, NTN>(acc, s_x, s_w, wave, lane);
 }
 
 // What happens to a finished tile: bias + BeLU -> the node's feature map (exact f32 or split-half pairs), or,
@@ -1003,6 +1011,68 @@ struct HalfRequest {
 };
 
 
+__device__ __forceinline__ void wait_vm(int pending) {  // s_waitcnt vmcnt(pending), pending any value (>= 16: waits for all)
+    switch (pending) {
+#define SR_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
+        SR_CASE(11) SR_CASE(12) SR_CASE(13) SR_CASE(14) SR_CASE(15)
+#undef SR_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// Final stage of the pipe form: the input pixels the bilinear taps need (a (8+2) x (32+2) tile, edge-replicated
+// coordinates: LinearInterp clamps indices) are requested at the start of the tile's LAST half and parked in
+// registers, so that their latency runs under that half's matrix work.  Inline-asm loads: the compiler would
+// otherwise wait for them with vmcnt(0), i.e. for every DMA of the next tile too; here the wait is numbered like
+// all the others (StepStream).  Every thread loads two pixels (the second one clamped when it has none).
+template <bool IMG_U8>
+struct LinPrefetch {
+    static constexpr int TWH = kTW + 2, THH = 8 + 2, NPIX = THH * TWH;
+    uint32_t raw[2][3];
+    int seq;
+    __device__ __forceinline__ void issue(const StageArgs& a, int n, int y0, int x0, int tid, StepStream& st) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = min(tid + 256 * k, NPIX - 1);
+            const int py = p / TWH, px = p - py * TWH;
+            const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
+            const size_t gp = (size_t)n * a.H * a.W + (size_t)gy * a.W + gx;
+            if constexpr (IMG_U8) {
+                const uint8_t* q = (const uint8_t*)a.img + gp * a.img_ch;
+                asm volatile("global_load_ubyte %0, %1, off" : "=v"(raw[k][0]) : "v"(q) : "memory");
+                asm volatile("global_load_ubyte %0, %1, off offset:1" : "=v"(raw[k][1]) : "v"(q) : "memory");
+                asm volatile("global_load_ubyte %0, %1, off offset:2" : "=v"(raw[k][2]) : "v"(q) : "memory");
+            } else {
+                const float* q = (const float*)a.img + gp * 3;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(raw[k][0]) : "v"(q) : "memory");
+                asm volatile("global_load_dword %0, %1, off offset:4" : "=v"(raw[k][1]) : "v"(q) : "memory");
+                asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(raw[k][2]) : "v"(q) : "memory");
+            }
+        }
+        st.issued += 6;
+        seq = st.issued;
+    }
+    // wait for the pixels, convert (img_to_data: u8 / 255, true division) and write the [pixel][4] tile
+    __device__ __forceinline__ void store(float* s_x, int tid, const StepStream& st) {
+        wait_vm(st.issued - seq);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = tid + 256 * k;
+            if (p < NPIX) {
+                f32x4 v;
+                if constexpr (IMG_U8) {
+                    v.x = __fdiv_rn((float)raw[k][0], 255.0f); v.y = __fdiv_rn((float)raw[k][1], 255.0f); v.z = __fdiv_rn((float)raw[k][2], 255.0f);
+                } else {
+                    v.x = __uint_as_float(raw[k][0]); v.y = __uint_as_float(raw[k][1]); v.z = __uint_as_float(raw[k][2]);
+                }
+                v.w = 0.f;
+                *(f32x4*)&s_x[p * 4] = v;
+            }
+        }
+    }
+};
+
 // Stream of the pipe form: chunks through the ring with sequence-numbered waits, plus a piece of the next half
 // tile in each of the first four steps; the first half of a tile also publishes the next tile's number.
 template <int PREC, int KSN>
@@ -1045,6 +1115,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem + 2 * HB;
     volatile int* s_next = (volatile int*)(ring + kRingBytes);
+    float* s_wlin = (float*)(ring + kRingBytes + 16);  // final stage: the 9 x 128 fixed weights of the bilinear taps, loaded once
     const uint32_t lds0 = lds_addr(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1068,11 +1139,16 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     };
 
     if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
+    if constexpr (FINAL) {
+        const float* wlin = a.wpack + (size_t)NSTEPS * kChunkFloats;
+        for (int k = tid; k < 9 * 128; k += 256) s_wlin[k] = wlin[k];
+    }
     __syncthreads();
     int cur = __builtin_amdgcn_readfirstlane(*s_next);
     if (cur < 0) return;
     int n, x0, y0;
     coords(cur, n, x0, y0);
+    LinPrefetch<IMG_U8> linpx;
     // first tile only: its first half and the first weight chunks are requested here; every later tile finds
     // them already on the way (requested by the last half / the last steps of the tile before)
     h0.template stage<PREC>(lds0, a.src[0], 0, a.img_stride, a.pitch, n, y0, x0, wave);
@@ -1115,6 +1191,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             HalfRequest rq;
             if constexpr (j + 1 < NH) rq = HalfRequest{true, other, a.src[(j + 1) >> 1], (j + 1) & 1, n, y0, x0};
             else rq = HalfRequest{st.have_next, other, a.src[0], 0, nn, ny0, nx0};
+            if constexpr (FINAL && j == NH - 1) linpx.issue(a, n, y0, x0, tid, st);
             const HalfTile<KSN>* htn;
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
             using GJ = TileGeom<8, KSJ>;
@@ -1130,11 +1207,16 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         if constexpr (NH > 4) { do_half(std::integral_constant<int, 4>{}); do_half(std::integral_constant<int, 5>{}); }
         TL(4);
         if constexpr (FINAL) {
-            // bilinear residual: image tile + fixed weights staged in the buffer the last half has left (buffer 1)
-            char* lin = smem + HB;
-            lin_taps<TH, T, IMG_U8, 256, NTN>(acc, lin, lin + 8192, a, a.wpack + (size_t)NSTEPS * kChunkFloats, n, y0, x0, wave, lane, tid);
+            // bilinear residual: the image tile goes into the buffer the last half has just left (buffer 1)
+            float* s_x = (float*)(smem + HB);
+            linpx.store(s_x, tid, st);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            lin_mfma<TH, T, NTN>(acc, s_x, s_wlin, wave, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
+            asm volatile("" ::: "memory");
         }
         TL(5); TL(6); TL(8);
         stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
@@ -1288,7 +1370,8 @@ static hipError_t launch_stage_t(int stage, int factor, const StageArgs& a, int 
 // Pipe form (8-row tiles, factor <= 3): grid = co-resident workgroups, LDS = two half tiles + ring + mailbox.
 template <int PREC>
 static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s) {
-    constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kRingBytes + 16, lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16;
+    constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kRingBytes + 16;
+    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 128 * sizeof(float);  // + bilinear weights
     switch (stage) {
         case 1: return launch_with_lds(conv_stage_pipe_kernel<1, 5, false, false, false, PREC>, a, grid, lds5, s);
         case 2: return launch_with_lds(conv_stage_pipe_kernel<2, 5, false, false, false, PREC>, a, grid, lds5, s);
