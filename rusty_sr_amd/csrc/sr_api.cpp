@@ -3,6 +3,7 @@
 // without a HIP device sr_create fails with SR_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -491,7 +492,8 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
             a.pitch = c->pitch; a.img_stride = c->img_stride;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
-            HIPCHK(c, sr_launch_conv0(a, th, c->precision, nblk, img_u8, s));
+            a.n_tiles = nblk;
+            HIPCHK(c, sr_launch_conv0(a, th, c->precision, std::min(nblk, 8 * (c->cus > 0 ? c->cus : 256)), img_u8, s));
         } else {
             StageArgs a{};
             float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];

@@ -27,6 +27,7 @@ struct Conv0Args {
     long img_stride;      // feature-map image stride in pixels
     int y_begin, y_end;   // rows to compute
     int tiles_x, tiles_y;
+    int n_tiles;          // images * tiles_x * tiles_y; the grid may be smaller (workgroups loop over tiles)
     TileDiv div_tpi, div_tx;
 };
 

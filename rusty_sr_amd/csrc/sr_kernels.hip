@@ -228,26 +228,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // conv0's 12.8 KB of weights are loaded once per workgroup, which then walks its share of the tiles
+    // (grid = a few workgroups per CU, sr_launch_conv0); the image is small and L2-resident on every XCD, so the
+    // tile -> XCD mapping does not matter here
+    for (int k = tid; k < 25 * 128; k += kThreads) s_w[k] = a.wpack[k];
+    // img_to_data (main.rs:170) is u8 / 255 with a true division; one table entry per byte value replaces
+    // ~10 VALU instructions per sample (the f32 MFMA shares the vector ALU)
+    __shared__ float s_lut[256];
+    if constexpr (IMG_U8) s_lut[tid] = __fdiv_rn((float)tid, 255.0f);
+    const float bias = a.bias[i], beta = a.beta[i];
+  for (int bid = blockIdx.x; bid < a.n_tiles; bid += gridDim.x) {
     const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
     const int ty = tile_div(t, a.div_tx), tx = t - ty * a.tiles_x;
     const int x0 = tx * kTW, y0 = a.y_begin + ty * TH;
     const size_t img_px0 = (size_t)n * a.H * a.W;
 
-    for (int k = tid; k < 25 * 128; k += kThreads) s_w[k] = a.wpack[k];
+    __syncthreads();  // the previous tile's reads of s_x are done
     for (int p = tid; p < NPIX; p += kThreads) {
         const int py = p / TWH, px = p - py * TWH;
         const int gy = y0 - 2 + py, gx = x0 - 2 + px;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
             const size_t gp = img_px0 + (size_t)gy * a.W + gx;
-            v.x = load_img(a.img, a.img_ch, IMG_U8, gp, 0);
-            v.y = load_img(a.img, a.img_ch, IMG_U8, gp, 1);
-            v.z = load_img(a.img, a.img_ch, IMG_U8, gp, 2);
+            if constexpr (IMG_U8) {
+                const uint8_t* q = (const uint8_t*)a.img + gp * a.img_ch;
+                v.x = s_lut[q[0]]; v.y = s_lut[q[1]]; v.z = s_lut[q[2]];
+            } else {
+                v.x = load_img(a.img, a.img_ch, false, gp, 0);
+                v.y = load_img(a.img, a.img_ch, false, gp, 1);
+                v.z = load_img(a.img, a.img_ch, false, gp, 2);
+            }
         }
         *(f32x4*)&s_x[p * 4] = v;
     }
-    const float bias = a.bias[i], beta = a.beta[i];
     __syncthreads();
 
     f32x16 acc[T];
@@ -301,6 +314,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
             }
         }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------
