@@ -208,14 +208,15 @@ def test_graph_forward_mirror(params):
         g.forward(1, [inp], p[:-1])
 
 
-def test_full_size_properties_1080p(engines, params):
-    """BASELINE configs[2] (1920x1080): too large for the oracle in seconds, so use
+@pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840)])
+def test_full_size_properties_1080p(engines, params, H, W):
+    """BASELINE configs[2] (1920x1080) and configs[3]'s image (3840x2160) on one GPU: too large for the oracle in seconds, so use
     size-independent properties: (a) a 96-row window recomputed on its own with a
     7-row halo is bit-identical; (b) a 64x64 crop matches the oracle run on the crop
     plus halo; (c) the u8 path equals quantising the f32 path."""
     import torch
     eng = engines["imagenet"]
-    px = synth_u8(2, 1, 1080, 1920)
+    px = synth_u8(2 if H == 1080 else 3, 1, H, W)
     xt = torch.from_numpy(px).cuda()
     # true IEEE division on the host (torch divides by a scalar as x * (1/255): 1 ulp off)
     x32 = torch.from_numpy(oracle.img_to_data(px)).cuda()
@@ -226,6 +227,11 @@ def test_full_size_properties_1080p(engines, params):
     crop = oracle.img_to_data(px[0, 300 - 7:364 + 7, 900 - 7:964 + 7])
     want = oracle.forward(params["imagenet"], crop)[0][21:-21, 21:-21]
     got = full[0, 900:1092, 2700:2892].cpu().numpy()
+    assert np.abs(got - want).max() < TIGHT
+    # ... and one in the bottom-right corner (true image edges on two sides: zero padding there, halo on the others)
+    crop = oracle.img_to_data(px[0, H - 71:, W - 71:])
+    want = oracle.forward(params["imagenet"], crop)[0][21:, 21:]
+    got = full[0, 3 * (H - 64):, 3 * (W - 64):].cpu().numpy()
     assert np.abs(got - want).max() < TIGHT
     out8 = eng.upscale_rgba8_dev(xt)
     torch.cuda.synchronize()
