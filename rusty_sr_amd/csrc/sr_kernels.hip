@@ -27,10 +27,17 @@
 //  * a workgroup (4 waves) owns a TH x 32 pixel tile; the source tile + halo is
 //    staged in LDS in a channel-group-planar layout [cin/4][pixel][4 f32] so
 //    that every A-operand fetch is one conflict-free ds_read_b128;
-//  * weights are pre-packed on the host into 4 KB per-tap chunks in the exact
-//    order the B-operand ds_read_b128 wants ([cin/4][cout][4]) and streamed by
-//    LDS-DMA through a 3-slot ring two taps ahead of use, one barrier per tap;
-//  * LDS per workgroup <= 68 KB -> 2 workgroups per CU (3 with 4-row tiles);
+//  * weights are pre-packed on the host into 4 KB chunks, one per STEP (two taps x 16 input channels), in the
+//    exact order the B-operand ds_read_b128 wants, and streamed by LDS-DMA through a 5-slot ring four steps
+//    ahead of use, one barrier per step;
+//  * stages 1-4 come in two forms that share the matrix loops, the step order and the weight chunks and are
+//    bit-identical: the PIPE form (conv_stage_pipe_kernel: half tiles double-buffered in LDS, gather DMA of
+//    the next half / the next tile's first half spread under the current half's MFMAs, persistent) for 8-row
+//    tiles, and the FIRST form (conv_stage_kernel: whole source tile resident) for small images (4-row
+//    tiles) and two N-tiles (factor 4);
+//  * LDS per workgroup 76-78 KB -> 2 workgroups per CU;
+//  * a second arithmetic mode (split-half: activations and weights as hi + lo/2048 half pairs, three
+//    v_mfma_f32_32x32x16_f16 per product, f32 accumulation) runs the same structure on the f16 matrix cores;
 //  * bias + BeLU (or bias + depth-to-space [+ u8 RGBA quantisation]) are fused
 //    into the epilogue: no elementwise kernel exists.
 #include <hip/hip_runtime.h>
