@@ -471,12 +471,12 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
     float* feat[4];
     for (int k = 0; k < 4; ++k) feat[k] = c->d_feat[k] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
-    // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent) whenever the final
-    // stage fits one N-tile; bit-identical to the first form.  SRHIP_PIPE=none forces the first form (A/B runs).
-    bool pipe = c->pipe_ok;
-    if (const char* e = getenv("SRHIP_PIPE")) pipe = pipe && strcmp(e, "none") != 0;
-    const bool persist = c->precision == SR_PRECISION_SPLIT_F16 || pipe;  // see conv_stage_kernel
-    if (persist) HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of all stages
+    // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent); its final stage
+    // handles one N-tile, so factor 4 falls back to the first form there only.  The two forms are bit-identical.
+    // SRHIP_PIPE=none forces the first form everywhere (A/B runs).
+    bool pipe = true;
+    if (const char* e = getenv("SRHIP_PIPE")) pipe = strcmp(e, "none") != 0;
+    HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of the persistent kernels
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
         int y0 = top - margin[st], y1 = bot + margin[st];
@@ -510,12 +510,15 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.n_img = n; a.queue = c->d_queue + st * 8;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
+            const bool use_pipe = pipe && th == 8 && (st < 4 || c->pipe_ok);
+            // persistent kernels (the pipe form; the first form in split-half mode) get one workgroup per resident
+            // slot -- 2 per CU with 8-row tiles, 3 with 4-row tiles -- and pull tiles from the queue
             int grid = nblk;
-            if (persist) {  // the workgroups that are co-resident: 2 per CU with 8-row tiles, 3 with 4-row tiles
+            if (use_pipe || c->precision == SR_PRECISION_SPLIT_F16) {
                 const int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);
                 if (grid > resident) grid = resident;
             }
-            if (pipe && th == 8) {
+            if (use_pipe) {
                 HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, grid, img_u8, out_u8, s));
             } else {
                 HIPCHK(c, sr_launch_stage(st, c->factor, a, th, c->precision, grid, img_u8, out_u8, s));

@@ -422,6 +422,12 @@ def test_other_factors_against_the_restatement(factor, precision):
     out = eng.upscale_band_f32_dev(xt[20 - 7:33 + 7].contiguous(), 7, 7)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy(), full[factor * 20:factor * 33])
+    # an image with more 8-row tiles than resident workgroups: persistent pipe-form stages (1-3, and the final
+    # stage unless it needs two N-tiles) feeding / fed by first-form ones; whole output against the restatement
+    px = synth_u8(91, 1, 296, 1100)
+    x = oracle.img_to_data(px)
+    got = eng.upscale_f32(x)
+    assert np.abs(got - oracle.forward_factor(p, x, factor)).max() < TIGHT
     eng.close()
 
 
