@@ -151,7 +151,6 @@ struct sr_ctx {
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
     size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
-    bool pipe_ok = false;  // factor <= 3: the final stage fits one N-tile, which is all the pipe form handles
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;
@@ -302,7 +301,6 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
             pack_lin(w, factor);  // f32 in both modes: the residual is the signal, it stays on the exact path
             off[4] = push(w);
         }
-        c->pipe_ok = expand_tiles(factor) == 1;  // the pipe form of the final stage handles one N-tile
         const size_t boff[4] = {L.f_bias, L.l_bias[0], L.l_bias[1], L.l_bias[2]};
         const size_t aoff[4] = {L.f_activ, L.l_activ[0], L.l_activ[1], L.l_activ[2]};
         for (int s = 0; s < 4; ++s) c->off_bias[s] = push(vec32(boff[s], 32));
@@ -471,9 +469,8 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
     float* feat[4];
     for (int k = 0; k < 4; ++k) feat[k] = c->d_feat[k] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
-    // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent); its final stage
-    // handles one N-tile, so factor 4 falls back to the first form there only.  The two forms are bit-identical.
-    // SRHIP_PIPE=none forces the first form everywhere (A/B runs).
+    // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent), 4-row tiles (small
+    // images) the first form; the two are bit-identical.  SRHIP_PIPE=none forces the first form everywhere (A/B runs).
     bool pipe = true;
     if (const char* e = getenv("SRHIP_PIPE")) pipe = strcmp(e, "none") != 0;
     HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of the persistent kernels
@@ -510,7 +507,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.n_img = n; a.queue = c->d_queue + st * 8;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
-            const bool use_pipe = pipe && th == 8 && (st < 4 || c->pipe_ok);
+            const bool use_pipe = pipe && th == 8;
             // persistent kernels (the pipe form; the first form in split-half mode) get one workgroup per resident
             // slot -- 2 per CU with 8-row tiles, 3 with 4-row tiles -- and pull tiles from the queue
             int grid = nblk;

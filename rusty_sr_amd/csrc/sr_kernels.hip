@@ -33,8 +33,7 @@
 //  * stages 1-4 come in two forms that share the matrix loops, the step order and the weight chunks and are
 //    bit-identical: the PIPE form (conv_stage_pipe_kernel: half tiles double-buffered in LDS, gather DMA of
 //    the next half / the next tile's first half spread under the current half's MFMAs, persistent) for 8-row
-//    tiles, and the FIRST form (conv_stage_kernel: whole source tile resident) for small images (4-row
-//    tiles) and two N-tiles (factor 4);
+//    tiles, and the FIRST form (conv_stage_kernel: whole source tile resident) for small images (4-row tiles);
 //  * LDS per workgroup 76-78 KB -> 2 workgroups per CU;
 //  * a second arithmetic mode (split-half: activations and weights as hi + lo/2048 half pairs, three
 //    v_mfma_f32_32x32x16_f16 per product, f32 accumulation) runs the same structure on the f16 matrix cores;
@@ -505,7 +504,7 @@ __device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[NTN * T], const cha
         for (int q = 0; q < 3; ++q) {
             if (q + 1 < ngroups) {
                 load(nxt, p, q + 1, sm.slot());
-                if (nt == 0) sm.piece((p * 4 + q) / NTN);  // one gather instruction per operand group
+                if (((p * NTN + nt) * 4 + q) % NTN == 0) sm.piece(((p * NTN + nt) * 4 + q) / NTN);  // one gather instruction per NTN operand groups
                 __builtin_amdgcn_sched_barrier(0);
                 mfma(cur, nt);
                 __builtin_amdgcn_sched_barrier(0);
@@ -515,7 +514,7 @@ __device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[NTN * T], const cha
         const bool last = p == NP - 1 && nt == NTN - 1;
         sm.template end_step<0>(last);
         if (!last) load(nxt, nt + 1 < NTN ? p : p + 1, 0, sm.slot());
-        if (nt == 0) sm.piece((p * 4 + 3) / NTN);
+        if (((p * NTN + nt) * 4 + 3) % NTN == 0) sm.piece(((p * NTN + nt) * 4 + 3) / NTN);
         __builtin_amdgcn_sched_barrier(0);
         mfma(cur, nt);
         __builtin_amdgcn_sched_barrier(0);
@@ -928,7 +927,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
 // but the epilogue is left outside the matrix stream: no staging waits between sources, no prologue per
 // tile (persistent workgroups, tiles from the per-XCD queue).  A step = two taps of one half = one 4 KB
 // weight chunk = 32 f32 / 12 f16 MFMAs per wave, same size as a whole tap of the first form.
-// Restrictions: 8-row tiles, 4 waves, one N-tile (factor 2 and 3); everything else runs the first form.
+// 8-row tiles, 4 waves; 4-row tiles (small images) run the first form.
 // ---------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier(int pending) {  // s_waitcnt vmcnt(pending) lgkmcnt(0); s_barrier
@@ -1126,13 +1125,13 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     TL_BEGIN();
     TL_DECL();
     __builtin_amdgcn_s_setprio(3);
-    constexpr int TH = 8, T = 2, NTN = 1;
-    static_assert(!FINAL || FACTOR * FACTOR <= 10, "one N-tile only");
+    constexpr int TH = 8, T = 2;
+    constexpr int NTN = FINAL ? (FACTOR * FACTOR + 9) / 10 : 1;  // N-tiles of the node (expand at factor 4: 48 channels = 2)
     using H0 = HalfTile<KS0>;
     using H3 = HalfTile<3>;
     constexpr int HB = H0::BYTES;  // KS0 >= 3: the first source has the largest half tile
     constexpr int NH = 2 * NSRC;
-    constexpr int NSTEPS = 2 * (H0::STEPS + (NSRC - 1) * H3::STEPS);
+    constexpr int NSTEPS = 2 * (H0::STEPS + (NSRC - 1) * H3::STEPS) * NTN;  // weight chunks per tile: one per (step, N-tile)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem + 2 * HB;
     volatile int* s_next = (volatile int*)(ring + kRingBytes);
@@ -1146,7 +1145,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     const int ntiles = tiles_per_img * a.n_img;
     const int xcd = blockIdx.x & 7;
     float bias[NTN];
-    bias[0] = a.bias[i];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) bias[nt] = a.bias[nt * 32 + i];
     const float beta = FINAL ? 0.f : a.beta[i];
     H0 h0;
     H3 h3;
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
     if constexpr (FINAL) {
         const float* wlin = a.wpack + (size_t)NSTEPS * kChunkFloats;
-        for (int k = tid; k < 9 * 128; k += 256) s_wlin[k] = wlin[k];
+        for (int k = tid; k < 9 * NTN * 128; k += 256) s_wlin[k] = wlin[k];
     }
     __syncthreads();
     int cur = __builtin_amdgcn_readfirstlane(*s_next);
@@ -1183,9 +1183,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     wait_vm_barrier<0>(st.issued - (NG0 + 1 + (PREC == 1 ? 1 : 0)));
 
     while (true) {
-        f32x16 acc[T], accx[PREC == 1 ? T : 1];
+        f32x16 acc[NTN * T], accx[PREC == 1 ? NTN * T : 1];
 #pragma unroll
-        for (int m = 0; m < T; ++m)
+        for (int m = 0; m < NTN * T; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[m][r] = 0.f;
@@ -1217,8 +1217,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
             using GJ = TileGeom<8, KSJ>;
             PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring, wave, lane, j == 0 ? s_next : nullptr, xcd, ntiles, pulled};
-            if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, 1>(acc, hb, ring, sm, wave, lane);
-            else half_steps_h<GJ::TWH, GJ::PLANE, 2, KSJ, T, 1>(acc, accx, hb, ring, sm, wave, lane);
+            if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN>(acc, hb, ring, sm, wave, lane);
+            else half_steps_h<GJ::TWH, GJ::PLANE, 2, KSJ, T, NTN>(acc, accx, hb, ring, sm, wave, lane);
         };
         do_half(std::integral_constant<int, 0>{});
         do_half(std::integral_constant<int, 1>{});
@@ -1392,7 +1392,7 @@ static hipError_t launch_stage_t(int stage, int factor, const StageArgs& a, int 
 template <int PREC>
 static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s) {
     constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kRingBytes + 16;
-    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 128 * sizeof(float);  // + bilinear weights
+    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 2 * 128 * sizeof(float);  // + bilinear weights (<= 2 N-tiles)
     switch (stage) {
         case 1: return launch_with_lds(conv_stage_pipe_kernel<1, 5, false, false, false, PREC>, a, grid, lds5, s);
         case 2: return launch_with_lds(conv_stage_pipe_kernel<2, 5, false, false, false, PREC>, a, grid, lds5, s);
@@ -1404,6 +1404,7 @@ static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a,
             return hipErrorInvalidValue;
             if (factor == 3) { SR_FINAL(3) }
             if (factor == 2) { SR_FINAL(2) }
+            if (factor == 4) { SR_FINAL(4) }
 #undef SR_FINAL
             return hipErrorInvalidValue;
     }
