@@ -111,6 +111,16 @@ int sr_upscale_rgba8(sr_ctx* ctx, const uint8_t* in, int in_channels, int n, int
  * download.  The reference has no counterpart (its tensors never leave host memory,
  * main.rs:168-175); buffers from sr_host_alloc are page-locked, which lets the copies run at
  * PCIe rate and truly overlap -- any host memory is accepted. */
+/* One image across several GPUs from one process: ctxs[k] (sr_net contexts of the same parameters, normally one
+ * per device, created with sr_create(.., device k)) produces a contiguous share of the rows, a multiple of 8.
+ * The SR_HALO rows a share needs from its neighbours are read from the caller's image itself, so the devices
+ * exchange nothing; results are bit-identical to the single-device call.  This is the host-memory counterpart
+ * of the RCCL halo exchange of device-resident bands (rusty_sr_amd/shard.py); the reference has neither
+ * (one CPU, main.rs:171).  Shares run concurrently, one host thread per context. */
+int sr_upscale_f32_multi(sr_ctx* const* ctxs, int n_ctx, const float* in, int h, int w, float* out);
+int sr_upscale_rgba8_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* in, int in_channels, int h, int w,
+                           uint8_t* out_rgba);
+
 int sr_set_pipeline(sr_ctx* ctx, int enabled);         /* default: enabled */
 int sr_host_alloc(void** out, size_t bytes);           /* SR_E_NO_DEVICE without a GPU */
 void sr_host_free(void* p);

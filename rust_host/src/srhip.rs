@@ -42,6 +42,9 @@ extern "C" {
     pub fn sr_upscale_band_rgba8_dev(ctx: *mut SrCtx, d_in: *const u8, in_channels: c_int, h_ext: c_int, w: c_int,
                                      halo_top: c_int, halo_bot: c_int, d_out: *mut u8, stream: *mut c_void) -> c_int;
     pub fn sr_read_feature(ctx: *mut SrCtx, which: c_int, out_host: *mut f32, cap_floats: usize) -> c_int;
+    pub fn sr_upscale_f32_multi(ctxs: *const *mut SrCtx, n_ctx: c_int, input: *const f32, h: c_int, w: c_int, out: *mut f32) -> c_int;
+    pub fn sr_upscale_rgba8_multi(ctxs: *const *mut SrCtx, n_ctx: c_int, input: *const u8, in_channels: c_int, h: c_int, w: c_int,
+                                  out_rgba: *mut u8) -> c_int;
     pub fn sr_set_pipeline(ctx: *mut SrCtx, enabled: c_int) -> c_int;
     pub fn sr_host_alloc(out: *mut *mut c_void, bytes: usize) -> c_int;  // page-locked host memory
     pub fn sr_host_free(p: *mut c_void);

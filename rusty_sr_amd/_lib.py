@@ -34,6 +34,8 @@ SYMBOLS = {
     "sr_upscale_band_rgba8_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_read_feature": (_i, [_vp, _i, _fp, _sz]),
     "sr_set_precision": (_i, [_vp, _i]),
+    "sr_upscale_f32_multi": (_i, [C.POINTER(_vp), _i, _fp, _i, _i, _fp]),
+    "sr_upscale_rgba8_multi": (_i, [C.POINTER(_vp), _i, _u8p, _i, _i, _i, _u8p]),
     "sr_set_pipeline": (_i, [_vp, _i]),
     "sr_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "sr_host_free": (None, [_vp]),

@@ -23,7 +23,7 @@ def build_lib(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = LIB + f".{os.getpid()}.tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
            "-x", "hip", *[os.path.join(CSRC, f) for f in SOURCES], "-o", tmp]
     if verbose:
         print(" ".join(cmd))

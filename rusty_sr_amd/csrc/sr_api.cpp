@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/srhip.h"
@@ -548,7 +549,9 @@ struct Chunk {
 // all have the SAME extended height E (so the zero borders of the feature maps stay valid and
 // nothing is re-cleared between chunks): band k owns rows [y0,y1) and carries the E rows
 // [start, start+E) with start = clamp(y0 - SR_HALO, 0, h - E).
-std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_px_bytes, size_t out_px_bytes) {
+// [y_lo, y_hi): the image rows this call is to produce (a whole image: 0, h; a device's share of a multi-GPU
+// call: its rows, sr_net and n == 1 only).
+std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_px_bytes, size_t out_px_bytes, int y_lo, int y_hi) {
     std::vector<Chunk> plan;
     const int f = c->factor;
     const size_t in_img = (size_t)h * w * in_px_bytes;
@@ -563,16 +566,18 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_p
         }
         return plan;
     }
+    const bool part = y_lo > 0 || y_hi < h;  // a share of the image: always in band form (halo rows from the image itself)
+    const int span = y_hi - y_lo;
     int bands = 1;
-    if (pipe && n == 1 && c->graph == SR_GRAPH_SR_NET && (size_t)h * w >= ((size_t)1 << 19)) {
-        bands = h / 192;  // >= 192 own rows per band keeps the 14 recomputed rows under 7.5 %
+    if (pipe && n == 1 && c->graph == SR_GRAPH_SR_NET && (size_t)span * w >= ((size_t)1 << 19)) {
+        bands = span / 192;  // >= 192 own rows per band keeps the 14 recomputed rows under 7.5 %
         if (bands > 8) bands = 8;
     }
     if (bands >= 2) {
-        const int rows = (h + bands - 1) / bands, E = rows + 2 * SR_HALO;
+        const int rows = (span + bands - 1) / bands, E = rows + 2 * SR_HALO;
         bool ok = E <= h;
         for (int k = 0; k < bands && ok; ++k) {
-            const int y0 = k * rows, y1 = std::min(h, y0 + rows);
+            const int y0 = y_lo + k * rows, y1 = std::min(y_hi, y0 + rows);
             int start = std::max(0, y0 - SR_HALO);
             if (start > h - E) start = h - E;
             const int ht = y0 - start, hb = start + E - y1;
@@ -584,6 +589,13 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_p
         if (ok) return plan;
         plan.clear();
     }
+    if (part) {  // one band: the rows themselves plus SR_HALO rows on every side that is not an image edge
+        const int start = std::max(0, y_lo - SR_HALO), end = std::min(h, y_hi + SR_HALO);
+        plan.push_back({(size_t)start * w * in_px_bytes, (size_t)(end - start) * w * in_px_bytes,
+                        (size_t)y_lo * f * w * f * out_px_bytes, (size_t)span * f * w * f * out_px_bytes, 1, end - start,
+                        y_lo - start, end - y_hi});
+        return plan;
+    }
     plan.push_back({0, (size_t)n * in_img, 0, (size_t)n * out_img, n, h, 0, 0});
     return plan;
 }
@@ -592,14 +604,20 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_p
 // three streams.  Issue order is H2D(i+1), kernels(i+1), D2H(i): with pageable caller memory the
 // runtime blocks the calling thread inside each copy, and this order keeps kernels queued behind
 // it; with pinned memory (sr_host_alloc) all three engines run concurrently.
-int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, int w, void* out, bool out_u8) {
+int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, int w, void* out, bool out_u8, int y_lo = 0,
+             int y_hi = -1) {
     if (!c || !in || !out || n <= 0 || h <= 0 || w <= 0) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
     if (c->graph == SR_GRAPH_DOWNSAMPLE && (h < 3 || w < 3)) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET && img_u8 != out_u8) return SR_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t in_px = img_u8 ? (size_t)img_ch : 3 * sizeof(float), out_px = out_u8 ? 4 : 3 * sizeof(float);
-    const std::vector<Chunk> plan = plan_chunks(c, n, h, w, in_px, out_px);
+    if (y_hi < 0) y_hi = h;
+    if (y_lo < 0 || y_hi > h || y_lo >= y_hi) return SR_E_INVALID;
+    if ((y_lo > 0 || y_hi < h) && (n != 1 || c->graph != SR_GRAPH_SR_NET)) return SR_E_INVALID;
+    if (y_lo > 0 && y_lo < SR_HALO) return SR_E_HALO;
+    if (y_hi < h && h - y_hi < SR_HALO) return SR_E_HALO;
+    const std::vector<Chunk> plan = plan_chunks(c, n, h, w, in_px, out_px, y_lo, y_hi);
     const int nch = (int)plan.size();
     const int slots = nch > 1 ? 2 : 1;
     size_t in_max = 0, out_max = 0;
@@ -689,6 +707,41 @@ int sr_upscale_f32(sr_ctx* c, const float* in, int n, int h, int w, float* out) 
 
 int sr_upscale_rgba8(sr_ctx* c, const uint8_t* in, int in_channels, int n, int h, int w, uint8_t* out) {
     return run_host(c, in, true, in_channels, n, h, w, out, true);
+}
+
+// One image, several GPUs, one process: device k produces its share of the rows from the caller's image directly
+// (the 7 halo rows either side are just more rows of the same host buffer, so nothing is exchanged between
+// devices); one host thread per context drives its pipeline.  Shares are multiples of 8 rows (whole tiles).
+static int run_multi(sr_ctx* const* ctxs, int n_ctx, const void* in, bool img_u8, int img_ch, int h, int w, void* out, bool out_u8) {
+    if (!ctxs || n_ctx <= 0 || !in || !out || h <= 0 || w <= 0) return SR_E_INVALID;
+    for (int k = 0; k < n_ctx; ++k)
+        if (!ctxs[k] || ctxs[k]->graph != SR_GRAPH_SR_NET || ctxs[k]->factor != ctxs[0]->factor) return SR_E_INVALID;
+    int rows = (h + n_ctx - 1) / n_ctx;
+    rows = std::max(8, (rows + 7) / 8 * 8);
+    const int used = (h + rows - 1) / rows;
+    if (used == 1) return run_host(ctxs[0], in, img_u8, img_ch, 1, h, w, out, out_u8);
+    // the last share must not be thinner than the halo its neighbour reads from it
+    std::vector<int> lo(used), hi(used);
+    for (int k = 0; k < used; ++k) { lo[k] = k * rows; hi[k] = std::min(h, lo[k] + rows); }
+    if (hi[used - 1] - lo[used - 1] < SR_HALO) { hi[used - 2] = h; lo.pop_back(); hi.pop_back(); }
+    const int parts = (int)lo.size();
+    if (parts == 1) return run_host(ctxs[0], in, img_u8, img_ch, 1, h, w, out, out_u8);
+    std::vector<int> rc(parts, SR_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < parts; ++k)
+        th.emplace_back([&, k] { rc[k] = run_host(ctxs[k], in, img_u8, img_ch, 1, h, w, out, out_u8, lo[k], hi[k]); });
+    for (auto& t : th) t.join();
+    for (int k = 0; k < parts; ++k)
+        if (rc[k] != SR_OK) return rc[k];
+    return SR_OK;
+}
+
+int sr_upscale_f32_multi(sr_ctx* const* ctxs, int n_ctx, const float* in, int h, int w, float* out) {
+    return run_multi(ctxs, n_ctx, in, false, 3, h, w, out, false);
+}
+
+int sr_upscale_rgba8_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* in, int in_channels, int h, int w, uint8_t* out) {
+    return run_multi(ctxs, n_ctx, in, true, in_channels, h, w, out, true);
 }
 
 int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {

@@ -206,6 +206,31 @@ class Engine:
         return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value}
 
 
+def upscale_multi(engines, px: np.ndarray, out: np.ndarray = None) -> np.ndarray:
+    """One image over several engines (normally one per GPU) from this process: sr_upscale_*_multi.  px (H,W,3|4) u8
+    -> (3H,3W,4) u8 RGBA, or (H,W,3) f32 -> (3H,3W,3) f32; bit-identical to the single-engine call."""
+    L = _lib.lib()
+    arr = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
+    f = engines[0].factor
+    if px.dtype == np.uint8:
+        px = np.ascontiguousarray(px)
+        h, w, c = px.shape
+        if out is None:
+            out = np.empty((f * h, f * w, 4), dtype=np.uint8)
+        u8p = C.POINTER(C.c_uint8)
+        _lib.check(L.sr_upscale_rgba8_multi(arr, len(engines), px.ctypes.data_as(u8p), c, h, w, out.ctypes.data_as(u8p)))
+    else:
+        px = np.ascontiguousarray(px, dtype=np.float32)
+        h, w, c = px.shape
+        if c != 3:
+            raise ValueError("expected 3 channels")
+        if out is None:
+            out = np.empty((f * h, f * w, 3), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        _lib.check(L.sr_upscale_f32_multi(arr, len(engines), px.ctypes.data_as(fp), h, w, out.ctypes.data_as(fp)))
+    return out
+
+
 class PinnedBuffer:
     """Page-locked host memory from sr_host_alloc, exposed as a numpy array (`.array`)."""
 

@@ -9,6 +9,8 @@
 // reference's (-p -c -d): --device N, --precision f32|split_f16, --timing.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cctype>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,6 +39,7 @@ const char* kUsage =
     "    -p, --parameters <PARAMETERS>    Sets which built-in parameters to use with the neural net [values: imagenet,\n"
     "                                     imagenetlinear, anime, bilinear]\n"
     "        --device <N>                 HIP device index [default: 0]\n"
+    "        --devices <N,N,...>          spread one image over several GPUs (row shares, halo rows from the image)\n"
     "        --precision <MODE>           f32 (exact) or split_f16 (2x faster, same 1e-4 parity bar) [default: f32]\n\n"
     "ARGS:\n    <INPUT_FILE>     Sets the input image to upscale\n    <OUTPUT_FILE>    Sets the output file to write/overwrite (.png recommended)\n";
 
@@ -71,6 +74,7 @@ int main(int argc, char** argv) {
     std::string parameters, custom, precision = "f32";
     bool has_p = false, has_c = false, downsample = false, timing = false;
     int device = 0;
+    std::vector<int> devices;
     if (argc >= 2 && !strcmp(argv[1], "train"))  // main.rs:119-121
         die("the `train` sub-command is not part of this build (the MI355X engine covers the upscale path only)", 2);
     for (int k = 1; k < argc; ++k) {
@@ -88,6 +92,15 @@ int main(int argc, char** argv) {
         else if (a == "-c" || a == "--custom") { custom = value("--custom <PARAMETER_FILE>"); has_c = true; }
         else if (a.rfind("--custom=", 0) == 0) { custom = a.substr(9); has_c = true; }
         else if (a == "--device") device = atoi(value("--device <N>").c_str());
+        else if (a == "--devices") {
+            const std::string list = value("--devices <N,N,...>");
+            for (size_t pos0 = 0; pos0 <= list.size();) {
+                const size_t comma = std::min(list.find(',', pos0), list.size());
+                if (comma == pos0 || !isdigit((unsigned char)list[pos0])) usage_error("'" + list + "' isn't a valid value for '--devices <N,N,...>'");
+                devices.push_back(atoi(list.substr(pos0, comma - pos0).c_str()));
+                pos0 = comma + 1;
+            }
+        }
         else if (a == "--precision") precision = value("--precision <MODE>");
         else if (a.size() > 1 && a[0] == '-') usage_error("Found argument '" + a + "' which wasn't expected, or isn't valid in this context");
         else pos.push_back(a);
@@ -132,10 +145,15 @@ int main(int argc, char** argv) {
     }
     fflush(stdout);
 
-    sr_ctx* ctx = nullptr;
-    int rc = sr_create_graph(&ctx, graph, params.empty() ? nullptr : params.data(), params.size(), SR_FACTOR, device);
-    if (rc != SR_OK) die(sr_strerror(rc));  // SR_E_PARAM_COUNT carries the text of main.rs:162
-    if (graph == SR_GRAPH_SR_NET) sr_set_precision(ctx, precision == "f32" ? SR_PRECISION_F32 : SR_PRECISION_SPLIT_F16);
+    if (devices.empty() || graph != SR_GRAPH_SR_NET) devices.assign(1, devices.empty() ? device : devices[0]);
+    std::vector<sr_ctx*> ctxs(devices.size(), nullptr);
+    int rc = SR_OK;
+    for (size_t k = 0; k < devices.size(); ++k) {
+        rc = sr_create_graph(&ctxs[k], graph, params.empty() ? nullptr : params.data(), params.size(), SR_FACTOR, devices[k]);
+        if (rc != SR_OK) die(sr_strerror(rc));  // SR_E_PARAM_COUNT carries the text of main.rs:162
+        if (graph == SR_GRAPH_SR_NET) sr_set_precision(ctxs[k], precision == "f32" ? SR_PRECISION_F32 : SR_PRECISION_SPLIT_F16);
+    }
+    sr_ctx* ctx = ctxs[0];
 
     srpng::Image in;
     std::string err;
@@ -151,7 +169,8 @@ int main(int argc, char** argv) {
     if (sr_host_alloc(&pinned, out_bytes) != SR_OK) { pinned = nullptr; pageable.resize(out_bytes); }
     uint8_t* out = pinned ? (uint8_t*)pinned : pageable.data();
     // img_to_data + graph.forward + data_to_img(..).to_rgba(), fused on the device (main.rs:168-175)
-    rc = sr_upscale_rgba8(ctx, in.rgba.data(), 4, 1, in.h, in.w, out);
+    rc = ctxs.size() > 1 ? sr_upscale_rgba8_multi(ctxs.data(), (int)ctxs.size(), in.rgba.data(), 4, in.h, in.w, out)
+                         : sr_upscale_rgba8(ctx, in.rgba.data(), 4, 1, in.h, in.w, out);
     if (rc != SR_OK) die(std::string(sr_strerror(rc)) + (rc == SR_E_HIP ? " (hipError " + std::to_string(sr_last_hip_error(ctx)) + ")" : ""));
     if (timing) {
         double tot = 0, h2d = 0, d2h = 0;
@@ -163,6 +182,6 @@ int main(int argc, char** argv) {
     if (!srpng::encode_file(pos[1], out, ow, oh, err)) die("Could not write output file (" + err + ")");  // main.rs:175
     puts(" Done");
     sr_host_free(pinned);
-    sr_destroy(ctx);
+    for (sr_ctx* c : ctxs) sr_destroy(c);
     return 0;
 }

@@ -269,6 +269,28 @@ def test_host_pipeline_bands_are_bit_identical(engines, h, w):
     np.testing.assert_array_equal(got8p, want8)
 
 
+@pytest.mark.parametrize("precision", ["f32", "split_f16"])
+def test_multi_context_call_is_bit_identical(params, precision):
+    """sr_upscale_*_multi: one image over several contexts (one per GPU in production; the test box has one GPU, so
+    the contexts share it -- same code path, same threads).  Shares are whole 8-row tiles with halo rows taken from
+    the caller's image; any number of contexts must reproduce the single-context result bit for bit."""
+    import rusty_sr_amd as r
+    engs = [r.Engine(params["imagenet"], device=0, precision=precision) for _ in range(3)]
+    try:
+        for (h, w) in ((37, 50), (100, 64), (600, 900)):
+            px = synth_u8(h, 1, h, w)[0]
+            x = oracle.img_to_data(px)
+            want32, want8 = engs[0].upscale_f32(x), engs[0].upscale_rgba8(px)
+            for k in (1, 2, 3):
+                np.testing.assert_array_equal(r.upscale_multi(engs[:k], x), want32, err_msg=f"f32 {h}x{w} on {k}")
+                np.testing.assert_array_equal(r.upscale_multi(engs[:k], px), want8, err_msg=f"u8 {h}x{w} on {k}")
+        with pytest.raises(r.SrError):
+            r.upscale_multi([engs[0], r.bilinear_net()], px)
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_host_pipeline_batch_chunks(engines, params):
     """A batch goes through the host pipeline in chunks of whole images (ragged last chunk);
     every image equals its own single-image call, and config D's shape (n x 512 x 512) works."""

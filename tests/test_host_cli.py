@@ -243,6 +243,11 @@ def test_cli_end_to_end(png, tmp_path, params):
     want = oracle.upscale_rgba8(params["imagenet"], png.decode_any(jpg)[None, ..., :3])[0]
     d = png.decode(out)[..., :3].astype(int) - want[..., :3].astype(int)
     assert np.abs(d).max() <= 1 and (d != 0).mean() < 1e-3
+    # --devices: one image over several contexts (the test box has one GPU: both shares run on device 0)
+    r = _run(os.path.join(GOLDEN, "butterfly_lr.png"), str(out2), "--devices", "0,0")
+    assert r.returncode == 0, r.stderr
+    r = _run(os.path.join(GOLDEN, "butterfly_lr.png"), str(out))
+    np.testing.assert_array_equal(png.decode(out2), png.decode(out))
     # -p bilinear and -d
     src = tmp_path / "src.png"
     px = synth_u8(40, 1, 33, 47)[0]
