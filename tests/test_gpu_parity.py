@@ -318,7 +318,7 @@ def test_pipe_form_equals_first_form_bit_for_bit(engines, params, monkeypatch):
     form.  SRHIP_TH / SRHIP_PIPE are the library's experiment switches (read at every call)."""
     eng = engines["imagenet"]
     rng = np.random.default_rng(5)
-    shapes = [(1, 8, 32), (1, 9, 33), (2, 40, 70), (1, 64, 1024), (3, 37, 129), (1, 130, 700), (1, 300, 515)]
+    shapes = [(1, 8, 32), (1, 9, 33), (2, 40, 70), (1, 64, 1024), (3, 37, 129), (1, 130, 700), (1, 300, 515), (1, 2000, 40), (1, 16, 3000)]
     for (n, h, w) in shapes:
         px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
         x = oracle.img_to_data(px)
