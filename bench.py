@@ -120,7 +120,26 @@ def cpu_baseline(params, px_u8, budget_s=12.0):
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": round(mp / dt, 3), "unit": "output MP/s", "cores": cores, "kind": "port",
+    single = None
+    try:  # also one thread (closest to what alumina 0.1.1 does for n = 1), on a ~4 s sample
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        try:
+            t0 = time.perf_counter()
+            oracle.forward(params, x[:8], native=True)
+            t8 = time.perf_counter() - t0
+            r1 = int(min(h, max(8, 8 * 4.0 / max(t8, 1e-6))))
+            t0 = time.perf_counter()
+            oracle.forward(params, x[:r1], native=True)
+            d1 = time.perf_counter() - t0
+            single = {"value": round(r1 * w * 9 / 1e6 / d1, 4), "unit": "output MP/s", "cores": 1,
+                      "sample": f"top {r1} rows, one OpenMP thread; GFLOP/s={r1 * w * FLOP_PER_PX / d1 / 1e9:.2f}"}
+        finally:
+            gomp.omp_set_num_threads(cores)
+    except Exception:
+        pass
+    return {"value": round(mp / dt, 3), "unit": "output MP/s", "cores": cores, "kind": "port", "single_thread": single,
             "sample": f"top {rows} rows of the {w}x{h} workload image, f32 in/out, second of two passes, OpenMP on {cores} threads "
                       f"(oracle/sr_oracle.c, gcc -O3 -march=native); GFLOP/s={rows * w * FLOP_PER_PX / dt / 1e9:.1f}",
             "cpu": model}
