@@ -103,16 +103,18 @@ void pack_steps(std::vector<float>& dst, const float* w, int ks, int ntn, bool s
             }
 }
 
-// conv0 [32][5][5][3] -> 25 taps x [h 2][o 32][q 2], cin = 2h+q, cin 3 = zero pad.
+// conv0 [32][5][5][3]: K packed per kernel row -- slot k = 3 kx + c (15 used of 16) -- as
+// [ky 5][jj 4][h 2][o 32][e 2] with k = 2 (2 jj + e) + h  (conv0_kernel: B[k][o] for MFMA j = 2 jj + e).
 void pack_conv0(std::vector<float>& dst, const float* w) {
-    dst.assign(25 * 128, 0.0f);
-    for (int t = 0; t < 25; ++t)
-        for (int h = 0; h < 2; ++h)
-            for (int o = 0; o < 32; ++o)
-                for (int q = 0; q < 2; ++q) {
-                    const int ci = 2 * h + q;
-                    if (ci < 3) dst[t * 128 + (h * 32 + o) * 2 + q] = w[((size_t)o * 25 + t) * 3 + ci];
-                }
+    dst.assign(5 * 8 * 64, 0.0f);
+    for (int ky = 0; ky < 5; ++ky)
+        for (int jj = 0; jj < 4; ++jj)
+            for (int h = 0; h < 2; ++h)
+                for (int o = 0; o < 32; ++o)
+                    for (int e = 0; e < 2; ++e) {
+                        const int k = 2 * (2 * jj + e) + h;
+                        if (k < 15) dst[(((ky * 4 + jj) * 2 + h) * 32 + o) * 2 + e] = w[(((size_t)o * 5 + ky) * 5 + k / 3) * 3 + k % 3];
+                    }
 }
 
 // LinearInterp x f (network.rs:27) as a 3x3 convolution of the edge-replicated 3-channel

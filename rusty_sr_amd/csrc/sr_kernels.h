@@ -18,7 +18,7 @@ inline TileDiv make_tile_div(uint32_t d) {
 
 struct Conv0Args {
     const void* img;      // n*H*W*3 f32, or n*H*W*img_ch u8
-    const float* wpack;   // 25 taps x [cin/2][cout 32][2]  (cin 3 zero-padded to 4)
+    const float* wpack;   // [ky 5][j/2 4][h 2][cout 32][2]: K packed per kernel row (15 of 16 slots), see pack_conv0
     const float* bias;    // 32
     const float* beta;    // 32
     float* dst;           // padded feature map (see FeatGeom), pointer to pixel (0,0) of image 0
@@ -33,7 +33,7 @@ struct Conv0Args {
 
 struct StageArgs {
     const float* src[3];  // NHWC 32-channel feature maps, zero-bordered (pointer to pixel (0,0))
-    const float* wpack;   // one 4 KB chunk per tap, sources concatenated: [cin/4][cout 32][4]
+    const float* wpack;   // one 4 KB chunk per step (2 taps x 16 channels [x N-tile]), sources concatenated: sr_api.cpp pack_steps
     const float* bias;    // 32 per N-tile (final stage: expand_bias in the triple layout, see sr_api.cpp)
     const float* beta;    // 32 (unused by the final stage)
     float* dst;           // non-final: padded feature map

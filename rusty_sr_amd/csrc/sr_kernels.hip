@@ -220,15 +220,16 @@ __device__ __forceinline__ void for_each_acc_row(F&& f) {
 }  // namespace
 
 // ---------------------------------------------------------------------------
-// Stage 0: conv0 5x5 3->32 + bias + BeLU.  K = 25 taps x 4 (3 ch + zero pad),
-// two MFMAs per tap; x tile (with halo) and all of conv0's weights sit in LDS.
+// Stage 0: conv0 5x5 3->32 + bias + BeLU.  The x tile (with halo) sits in LDS as [pixel][3 channels]; along a
+// kernel row the 5 taps x 3 channels are 15 CONSECUTIVE floats from pixel i on, so K is packed per kernel row:
+// 15 -> 16 slots = 8 MFMAs (K = 2 each) instead of 5 taps x (3 -> 4 channels) = 10.  40 MFMAs per tile row.
 // ---------------------------------------------------------------------------
 template <int TH, bool IMG_U8, int PREC>
 __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     constexpr int T = TH / 4;
     constexpr int TWH = kTW + 4, THH = TH + 4, NPIX = THH * TWH;
-    __shared__ __attribute__((aligned(16))) float s_x[NPIX * 4];
-    __shared__ __attribute__((aligned(16))) float s_w[25 * 128];
+    __shared__ __attribute__((aligned(16))) float s_x[NPIX * 3 + 16];  // + the zero-weight slot 15 of the last pixel
+    __shared__ __attribute__((aligned(16))) float s_w[5 * 8 * 64];     // [ky][j/2][h][cout][2]: B[k = 2 j + h][cout]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     // conv0's 12.8 KB of weights are loaded once per workgroup, which then walks its share of the tiles
     // (grid = a few workgroups per CU, sr_launch_conv0); the image is small and L2-resident on every XCD, so the
     // tile -> XCD mapping does not matter here (measured: no change in kernel time either way)
-    for (int k = tid; k < 25 * 128; k += kThreads) s_w[k] = a.wpack[k];
+    for (int k = tid; k < 5 * 8 * 64; k += kThreads) s_w[k] = a.wpack[k];
+    if (tid < 16) s_x[NPIX * 3 + tid] = 0.f;
     // img_to_data (main.rs:170) is u8 / 255 with a true division; one table entry per byte value replaces
     // ~10 VALU instructions per sample (the f32 MFMA shares the vector ALU)
     __shared__ float s_lut[256];
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
                 v.z = load_img(a.img, a.img_ch, false, gp, 2);
             }
         }
-        *(f32x4*)&s_x[p * 4] = v;
+        s_x[p * 3] = v.x; s_x[p * 3 + 1] = v.y; s_x[p * 3 + 2] = v.z;
     }
     __syncthreads();
 
@@ -275,18 +277,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    const float* xa = s_x + ((wave * T) * TWH + i) * 4 + h * 2;
+    const float* xa = s_x + ((wave * T) * TWH + i) * 3 + h;   // slot k = 2 j + h of pixel i's kernel row
     const float* wb = s_w + (h * 32 + i) * 2;
 #pragma unroll
     for (int ky = 0; ky < 5; ++ky) {
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) {
-            const f32x2 b = *(const f32x2*)(wb + (ky * 5 + kx) * 128);
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x2 b = *(const f32x2*)(wb + (ky * 4 + jj) * 128);
 #pragma unroll
             for (int m = 0; m < T; ++m) {
-                const f32x2 av = *(const f32x2*)(xa + ((m + ky) * TWH + kx) * 4);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[m], 0, 0, 0);
+                const float* row = xa + (m + ky) * TWH * 3;
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[4 * jj], b.x, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[4 * jj + 2], b.y, acc[m], 0, 0, 0);
             }
         }
     }
