@@ -48,7 +48,9 @@ enum sr_status {
     SR_E_HIP = -5,         /* a HIP runtime call failed; sr_last_hip_error() has the code */
     SR_E_NOMEM = -6,
     SR_E_BYTEVEC = -7,     /* main.rs:138 "ByteVec conversion failed" */
-    SR_E_HALO = -8         /* band call with a halo that is neither 0 nor >= SR_HALO */
+    SR_E_HALO = -8,        /* band call with a halo that is neither 0 nor >= SR_HALO (or a band thinner than SR_HALO) */
+    SR_E_COMM = -9         /* librccl missing, no communicator on the context, or an RCCL call failed;
+                              sr_last_comm_error() has the ncclResult_t */
 };
 
 /* Replaces: `<Vec<f32>>::decode::<u32>(blob)` (bytevec 0.2.0; reference
@@ -115,11 +117,20 @@ int sr_upscale_rgba8(sr_ctx* ctx, const uint8_t* in, int in_channels, int n, int
  * per device, created with sr_create(.., device k)) produces a contiguous share of the rows, a multiple of 8.
  * The SR_HALO rows a share needs from its neighbours are read from the caller's image itself, so the devices
  * exchange nothing; results are bit-identical to the single-device call.  This is the host-memory counterpart
- * of the RCCL halo exchange of device-resident bands (rusty_sr_amd/shard.py); the reference has neither
+ * of the RCCL halo exchange of device-resident bands (sr_upscale_sharded_* below); the reference has neither
  * (one CPU, main.rs:171).  Shares run concurrently, one host thread per context. */
 int sr_upscale_f32_multi(sr_ctx* const* ctxs, int n_ctx, const float* in, int h, int w, float* out);
 int sr_upscale_rgba8_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* in, int in_channels, int h, int w,
                            uint8_t* out_rgba);
+
+/* Many images across several GPUs from one process -- throughput mode: image i goes to ctxs[i mod n_ctx]
+ * (contexts of the same parameters and arithmetic mode, one per device), parameters replicated, no exchange;
+ * each context runs its images through its own upload / compute / download pipeline on its own host thread.
+ * in / out are the whole batch (n images, host memory).  The reference processes one image per process
+ * (main.rs:164-171); its users loop over files. */
+int sr_upscale_f32_batch_multi(sr_ctx* const* ctxs, int n_ctx, const float* in, int n, int h, int w, float* out);
+int sr_upscale_rgba8_batch_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* in, int in_channels, int n, int h, int w,
+                                 uint8_t* out_rgba);
 
 int sr_set_pipeline(sr_ctx* ctx, int enabled);         /* default: enabled */
 int sr_host_alloc(void** out, size_t bytes);           /* SR_E_NO_DEVICE without a GPU */
@@ -146,6 +157,37 @@ int sr_upscale_band_f32_dev(sr_ctx* ctx, const float* d_in, int h_ext, int w, in
 int sr_upscale_band_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels, int h_ext, int w,
                               int halo_top, int halo_bot, uint8_t* d_out_rgba, void* stream);
 
+/* ---- One image sharded over several GPUs, DEVICE-RESIDENT: RCCL halo exchange inside the library ----
+ * The reference has no counterpart (one CPU, main.rs:171).  A context can own one RCCL communicator
+ * (librccl is dlopen'ed on first use; a host needs no torch and no MPI).  Rank r of n holds a contiguous
+ * row band of the image in its GPU's memory (bands in rank order, every band >= SR_HALO rows, same width);
+ * sr_upscale_sharded_*_dev sends the band's first / last SR_HALO rows to ranks r-1 / r+1 and receives theirs
+ * (one grouped ncclSend / ncclRecv pair per neighbour over xGMI, queued on `stream`), then runs the band form
+ * of the conv stack (sr_upscale_band_*_dev) and writes the band's 3*h_band output rows to d_out.  The rows of
+ * all ranks together are bit-identical to the single-GPU call.
+ *
+ * One process per GPU (the normal form):  rank 0 calls sr_comm_unique_id and hands the 128 bytes to the other
+ * ranks by whatever means the host has (a file, a socket, an environment variable, torch.distributed);
+ * every rank then calls sr_comm_init_rank (collective: returns when all n ranks have joined).
+ * One process, n GPUs: sr_comm_init_all on n contexts of distinct devices (ncclCommInitAll; rank = index), then
+ * sr_upscale_sharded_*_all drives all bands from the calling thread (grouped exchange, synchronous). */
+#define SR_COMM_ID_BYTES 128
+int sr_comm_available(void);                            /* 1 if librccl could be loaded */
+int sr_comm_unique_id(uint8_t* id, size_t cap);         /* cap >= SR_COMM_ID_BYTES */
+int sr_comm_init_rank(sr_ctx* ctx, const uint8_t* id, size_t id_len, int rank, int nranks);
+int sr_comm_init_all(sr_ctx* const* ctxs, int n);
+void sr_comm_destroy(sr_ctx* ctx);                      /* sr_destroy does this too */
+int sr_comm_rank(sr_ctx* ctx, int* rank, int* nranks);  /* 0 of 1 without a communicator */
+int sr_last_comm_error(sr_ctx* ctx);                    /* ncclResult_t of the last failed RCCL call */
+int sr_last_comm_ms(sr_ctx* ctx, double* comm_ms);      /* device time of the last exchange (needs sr_set_profiling) */
+int sr_upscale_sharded_f32_dev(sr_ctx* ctx, const float* d_band, int h_band, int w, float* d_out, void* stream);
+int sr_upscale_sharded_rgba8_dev(sr_ctx* ctx, const uint8_t* d_band, int in_channels, int h_band, int w,
+                                 uint8_t* d_out_rgba, void* stream);
+int sr_upscale_sharded_f32_all(sr_ctx* const* ctxs, int n, const float* const* d_bands, const int* h_bands, int w,
+                               float* const* d_outs);
+int sr_upscale_sharded_rgba8_all(sr_ctx* const* ctxs, int n, const uint8_t* const* d_bands, int in_channels,
+                                 const int* h_bands, int w, uint8_t* const* d_outs);
+
 /* Arithmetic of the conv stack.
  *   SR_PRECISION_F32       (default) v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate --
  *                          the same arithmetic class as the reference's f32 CPU path.
@@ -155,6 +197,13 @@ int sr_upscale_band_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels,
  *                          (tests/test_gpu_parity.py runs every parity test in both modes). */
 enum sr_precision { SR_PRECISION_F32 = 0, SR_PRECISION_SPLIT_F16 = 1 };
 int sr_set_precision(sr_ctx* ctx, int mode);
+
+/* Experiment switches -- none changes a result bit, they exist for A/B timing and for the tests that prove
+ * exactly that.  key "th": tile height, value "" (automatic), "4" / "8" (all stages) or five digits (one per stage);
+ * "pipe": "none" forces the first form of the stage kernels; "bw": width in tiles of the column blocks the tile
+ * queue walks ("" automatic, "0" plain row-major).  Defaults come from SRHIP_TH / SRHIP_PIPE / SRHIP_BW, read once
+ * in sr_create.  Unknown key: SR_E_INVALID. */
+int sr_set_experiment(sr_ctx* ctx, const char* key, const char* value);
 
 /* Test hook: copy the post-activation feature maps of the most recent call
  * (image 0) to host: which = 0..3 -> f, l1, l2, l3 (h*w*32 f32 each).  The

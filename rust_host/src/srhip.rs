@@ -19,6 +19,9 @@ pub const SR_GRAPH_DOWNSAMPLE: c_int = 2;
 pub const SR_PRECISION_F32: c_int = 0;
 pub const SR_PRECISION_SPLIT_F16: c_int = 1;
 pub const SR_FACTOR: c_int = 3;
+pub const SR_E_COMM: c_int = -9;
+pub const SR_HALO: c_int = 7;
+pub const SR_COMM_ID_BYTES: c_int = 128;
 
 extern "C" {
     pub fn sr_rsr_decode(blob: *const u8, len: usize, out: *mut f32, cap: usize, n_out: *mut usize) -> c_int;
@@ -45,6 +48,28 @@ extern "C" {
     pub fn sr_upscale_f32_multi(ctxs: *const *mut SrCtx, n_ctx: c_int, input: *const f32, h: c_int, w: c_int, out: *mut f32) -> c_int;
     pub fn sr_upscale_rgba8_multi(ctxs: *const *mut SrCtx, n_ctx: c_int, input: *const u8, in_channels: c_int, h: c_int, w: c_int,
                                   out_rgba: *mut u8) -> c_int;
+    pub fn sr_upscale_f32_batch_multi(ctxs: *const *mut SrCtx, n_ctx: c_int, input: *const f32, n: c_int, h: c_int, w: c_int,
+                                      out: *mut f32) -> c_int;
+    pub fn sr_upscale_rgba8_batch_multi(ctxs: *const *mut SrCtx, n_ctx: c_int, input: *const u8, in_channels: c_int, n: c_int,
+                                        h: c_int, w: c_int, out_rgba: *mut u8) -> c_int;
+    // RCCL communicator inside the library + device-resident row bands (one image over several GPUs)
+    pub fn sr_comm_available() -> c_int;
+    pub fn sr_comm_unique_id(id: *mut u8, cap: usize) -> c_int;
+    pub fn sr_comm_init_rank(ctx: *mut SrCtx, id: *const u8, id_len: usize, rank: c_int, nranks: c_int) -> c_int;
+    pub fn sr_comm_init_all(ctxs: *const *mut SrCtx, n: c_int) -> c_int;
+    pub fn sr_comm_destroy(ctx: *mut SrCtx);
+    pub fn sr_comm_rank(ctx: *mut SrCtx, rank: *mut c_int, nranks: *mut c_int) -> c_int;
+    pub fn sr_last_comm_error(ctx: *mut SrCtx) -> c_int;
+    pub fn sr_last_comm_ms(ctx: *mut SrCtx, comm_ms: *mut f64) -> c_int;
+    pub fn sr_upscale_sharded_f32_dev(ctx: *mut SrCtx, d_band: *const f32, h_band: c_int, w: c_int, d_out: *mut f32,
+                                      stream: *mut c_void) -> c_int;
+    pub fn sr_upscale_sharded_rgba8_dev(ctx: *mut SrCtx, d_band: *const u8, in_channels: c_int, h_band: c_int, w: c_int,
+                                        d_out: *mut u8, stream: *mut c_void) -> c_int;
+    pub fn sr_upscale_sharded_f32_all(ctxs: *const *mut SrCtx, n: c_int, d_bands: *const *const f32, h_bands: *const c_int,
+                                      w: c_int, d_outs: *const *mut f32) -> c_int;
+    pub fn sr_upscale_sharded_rgba8_all(ctxs: *const *mut SrCtx, n: c_int, d_bands: *const *const u8, in_channels: c_int,
+                                        h_bands: *const c_int, w: c_int, d_outs: *const *mut u8) -> c_int;
+    pub fn sr_set_experiment(ctx: *mut SrCtx, key: *const c_char, value: *const c_char) -> c_int;
     pub fn sr_set_pipeline(ctx: *mut SrCtx, enabled: c_int) -> c_int;
     pub fn sr_host_alloc(out: *mut *mut c_void, bytes: usize) -> c_int;  // page-locked host memory
     pub fn sr_host_free(p: *mut c_void);
@@ -73,6 +98,13 @@ pub fn rsr_decode(blob: &[u8]) -> Result<Vec<f32>, String> {
         return Err(strerror(rc));
     }
     Ok(out)
+}
+
+/// 128 opaque bytes of ncclGetUniqueId for `Engine::comm_init_rank` (rank 0 only).
+pub fn comm_unique_id() -> Result<Vec<u8>, String> {
+    let mut id = vec![0u8; SR_COMM_ID_BYTES as usize];
+    let rc = unsafe { sr_comm_unique_id(id.as_mut_ptr(), id.len()) };
+    if rc == SR_OK { Ok(id) } else { Err(strerror(rc)) }
 }
 
 /// Owning handle of one engine context: a graph, its parameters, one GPU.
@@ -124,6 +156,37 @@ impl Engine {
         let mut out = vec![0f32; ow as usize * oh as usize * 3];
         let rc = unsafe { sr_upscale_f32(self.ctx, values.as_ptr(), 1, h as c_int, w as c_int, out.as_mut_ptr()) };
         if rc == SR_OK { Ok(out) } else { Err(strerror(rc)) }
+    }
+
+    /// One image over several GPUs of this process: image (w x h, RGBA) split into `engines.len()` row shares, one per
+    /// engine / device, halo rows read from `rgba` itself (sr_upscale_rgba8_multi).
+    pub fn upscale_rgba8_multi(engines: &mut [Engine], rgba: &[u8], w: u32, h: u32) -> Result<Vec<u8>, String> {
+        assert_eq!(rgba.len(), w as usize * h as usize * 4);
+        let ctxs: Vec<*mut SrCtx> = engines.iter().map(|e| e.ctx).collect();
+        let mut out = vec![0u8; w as usize * 3 * h as usize * 3 * 4];
+        let rc = unsafe {
+            sr_upscale_rgba8_multi(ctxs.as_ptr(), ctxs.len() as c_int, rgba.as_ptr(), 4, h as c_int, w as c_int, out.as_mut_ptr())
+        };
+        if rc == SR_OK { Ok(out) } else { Err(strerror(rc)) }
+    }
+
+    /// A batch dealt round-robin (image i -> engine i mod N), one host thread per engine inside the library.
+    pub fn upscale_rgba8_batch_multi(engines: &mut [Engine], rgba: &[u8], n: u32, w: u32, h: u32) -> Result<Vec<u8>, String> {
+        assert_eq!(rgba.len(), n as usize * w as usize * h as usize * 4);
+        let ctxs: Vec<*mut SrCtx> = engines.iter().map(|e| e.ctx).collect();
+        let mut out = vec![0u8; n as usize * w as usize * 3 * h as usize * 3 * 4];
+        let rc = unsafe {
+            sr_upscale_rgba8_batch_multi(ctxs.as_ptr(), ctxs.len() as c_int, rgba.as_ptr(), 4, n as c_int, h as c_int, w as c_int,
+                                         out.as_mut_ptr())
+        };
+        if rc == SR_OK { Ok(out) } else { Err(strerror(rc)) }
+    }
+
+    /// One process per GPU: join the band communicator.  Rank 0 obtains `id` from `comm_unique_id()` and hands it to
+    /// the other ranks (file, socket, environment) before every rank calls this.
+    pub fn comm_init_rank(&mut self, id: &[u8], rank: c_int, nranks: c_int) -> Result<(), String> {
+        let rc = unsafe { sr_comm_init_rank(self.ctx, id.as_ptr(), id.len(), rank, nranks) };
+        if rc == SR_OK { Ok(()) } else { Err(format!("{} (ncclResult {})", strerror(rc), unsafe { sr_last_comm_error(self.ctx) })) }
     }
 
     pub fn last_timing(&mut self) -> (f64, f64, f64) {

@@ -11,7 +11,8 @@ SR_NUM_PARAMS = 130459
 SR_HALO = 7
 
 SR_OK, SR_E_INVALID, SR_E_PARAM_COUNT, SR_E_FACTOR, SR_E_NO_DEVICE = 0, -1, -2, -3, -4
-SR_E_HIP, SR_E_NOMEM, SR_E_BYTEVEC, SR_E_HALO = -5, -6, -7, -8
+SR_E_HIP, SR_E_NOMEM, SR_E_BYTEVEC, SR_E_HALO, SR_E_COMM = -5, -6, -7, -8, -9
+SR_COMM_ID_BYTES = 128
 SR_PRECISION_F32, SR_PRECISION_SPLIT_F16 = 0, 1
 SR_GRAPH_SR_NET, SR_GRAPH_BILINEAR, SR_GRAPH_DOWNSAMPLE = 0, 1, 2
 
@@ -36,6 +37,21 @@ SYMBOLS = {
     "sr_set_precision": (_i, [_vp, _i]),
     "sr_upscale_f32_multi": (_i, [C.POINTER(_vp), _i, _fp, _i, _i, _fp]),
     "sr_upscale_rgba8_multi": (_i, [C.POINTER(_vp), _i, _u8p, _i, _i, _i, _u8p]),
+    "sr_upscale_f32_batch_multi": (_i, [C.POINTER(_vp), _i, _fp, _i, _i, _i, _fp]),
+    "sr_upscale_rgba8_batch_multi": (_i, [C.POINTER(_vp), _i, _u8p, _i, _i, _i, _i, _u8p]),
+    "sr_comm_available": (_i, []),
+    "sr_comm_unique_id": (_i, [_u8p, _sz]),
+    "sr_comm_init_rank": (_i, [_vp, _u8p, _sz, _i, _i]),
+    "sr_comm_init_all": (_i, [C.POINTER(_vp), _i]),
+    "sr_comm_destroy": (None, [_vp]),
+    "sr_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "sr_last_comm_error": (_i, [_vp]),
+    "sr_last_comm_ms": (_i, [_vp, _dp]),
+    "sr_upscale_sharded_f32_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "sr_upscale_sharded_rgba8_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sr_upscale_sharded_f32_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "sr_upscale_sharded_rgba8_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), _i, C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "sr_set_experiment": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "sr_set_pipeline": (_i, [_vp, _i]),
     "sr_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "sr_host_free": (None, [_vp]),
@@ -85,4 +101,6 @@ def check(status, ctx=None):
         detail = ""
         if ctx and status == SR_E_HIP:
             detail = f"hipError {lib().sr_last_hip_error(ctx)}"
+        if ctx and status == SR_E_COMM:
+            detail = f"ncclResult {lib().sr_last_comm_error(ctx)}"
         raise SrError(status, detail)

@@ -5,30 +5,46 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrhip.so")
-SOURCES = ["sr_kernels.hip", "sr_api.cpp"]
-HEADERS = ["sr_kernels.h", os.path.join("..", "..", "include", "srhip.h")]
+SOURCES = ["sr_kernels.hip", "sr_api.cpp", "sr_comm.cpp"]
+HEADERS = ["sr_kernels.h", "sr_internal.h", os.path.join("..", "..", "include", "srhip.h")]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build_lib(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> rusty_sr_amd/libsrhip.so.  Cross-compiles
-    without a GPU.  Returns the library path."""
-    if not force and not _stale():
-        return LIB
+    """hipcc --offload-arch=gfx950 -> rusty_sr_amd/libsrhip.so.  Cross-compiles without a GPU.  Each source is
+    compiled to its own object (build/, git-ignored) so that a change to the host side does not recompile the
+    kernels.  Returns the library path."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = LIB + f".{os.getpid()}.tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-           "-x", "hip", *[os.path.join(CSRC, f) for f in SOURCES], "-o", tmp]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp, LIB)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, relink = [], force or not os.path.exists(LIB)
+    for f in SOURCES:
+        src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", obj + f".{os.getpid()}.tmp"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(obj + f".{os.getpid()}.tmp", obj)
+            relink = True
+    if relink or _newer(LIB, objs):
+        tmp = LIB + f".{os.getpid()}.tmp"
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", *objs, "-ldl", "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -14,6 +14,7 @@
 
 #include "../../include/srhip.h"
 #include "sr_kernels.h"
+#include "sr_internal.h"
 
 namespace {
 
@@ -47,6 +48,7 @@ struct ParamLayout {
 };
 
 constexpr int kChunk = 1024;  // floats per tap chunk (32 cin x 32 cout)
+constexpr int kAutoBlockWidth = 0;  // default tile order of the stage kernels (StageArgs::bw); SRHIP_BW / sr_set_experiment("bw") override
 
 // w = hi + lo/2048 with hi, lo halves (see split_half in sr_kernels.hip)
 void split_half_host(float v, _Float16& hi, _Float16& lo) {
@@ -147,45 +149,6 @@ void pack_lin(std::vector<float>& dst, int f) {
 
 }  // namespace
 
-struct sr_ctx {
-    int device = 0;
-    int cus = 0, clock_mhz = 0;
-    char name[128] = {0};
-    hipStream_t stream = nullptr;
-    float* d_params = nullptr;  // all packed parameters, one allocation
-    size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
-    int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
-    int graph = SR_GRAPH_SR_NET;
-    int factor = SR_FACTOR;
-    float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3 (zero-bordered, see sr_kernels.h)
-    size_t feat_cap_px = 0;       // allocated padded pixels per map
-    int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
-    int pitch = 0; long img_stride = 0;
-    int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
-    // host-pointer entry points: two in / out slots so that chunk i+1 uploads and chunk i-1
-    // downloads while chunk i computes (run_host)
-    void* d_in[2] = {nullptr, nullptr};  size_t in_cap[2] = {0, 0};
-    void* d_out[2] = {nullptr, nullptr}; size_t out_cap[2] = {0, 0};
-    hipStream_t copy_in = nullptr, copy_out = nullptr;
-    std::vector<hipEvent_t> pool;  // per-chunk timing / ordering events of run_host, grown on demand
-    int pipeline = 1;              // 0: one upload, one pass, one download
-    int last_chunks = 0;
-    hipEvent_t ev[8] = {nullptr};
-    bool profiling = false;
-    double total_ms = 0, stage_ms[5] = {0}, h2d_ms = 0, d2h_ms = 0;
-    int last_h = 0, last_w = 0;
-    int last_hip = 0;
-};
-
-#define HIPCHK(ctx, expr)                         \
-    do {                                          \
-        hipError_t e__ = (expr);                  \
-        if (e__ != hipSuccess) {                  \
-            (ctx)->last_hip = (int)e__;           \
-            return e__ == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP; \
-        }                                         \
-    } while (0)
-
 extern "C" {
 
 const char* sr_strerror(int s) {
@@ -200,7 +163,8 @@ const char* sr_strerror(int s) {
         case SR_E_HIP: return "HIP runtime error";
         case SR_E_NOMEM: return "out of device memory";
         case SR_E_BYTEVEC: return "ByteVec conversion failed";  // reference main.rs:138
-        case SR_E_HALO: return "band halo must be 0 (true image edge) or >= SR_HALO";
+        case SR_E_HALO: return "band halo must be 0 (true image edge) or >= SR_HALO, and a sharded band at least SR_HALO rows";
+        case SR_E_COMM: return "RCCL communicator missing or failed (librccl not loadable, sr_comm_init_* not called, or an RCCL error)";
         default: return "unknown error";
     }
 }
@@ -258,6 +222,16 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->device = device;
     c->graph = graph;
     c->factor = factor;
+    // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
+    static const char* const kSwitch[3][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}};
+    for (const auto& sw : kSwitch)
+        if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
+    {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
+        unsigned long long hsh = 1469598103934665603ull;
+        const unsigned char* pb = (const unsigned char*)params;
+        for (size_t i = 0; i < n_params * sizeof(float); ++i) { hsh ^= pb[i]; hsh *= 1099511628211ull; }
+        c->params_hash = hsh;
+    }
     int rc = [&]() -> int {
         HIPCHK(c, hipSetDevice(device));
         hipDeviceProp_t prop;
@@ -334,6 +308,7 @@ void sr_destroy(sr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    sr_comm_release(c);
     for (auto& p : c->d_feat) if (p) (void)hipFree(p);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_queue) (void)hipFree(c->d_queue);
@@ -356,6 +331,24 @@ int sr_num_params(int graph) { return graph == SR_GRAPH_SR_NET ? SR_NUM_PARAMS :
 int sr_set_precision(sr_ctx* c, int mode) {
     if (!c || (mode != SR_PRECISION_F32 && mode != SR_PRECISION_SPLIT_F16)) return SR_E_INVALID;
     c->precision = mode;
+    return SR_OK;
+}
+
+int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
+    if (!c || !key) return SR_E_INVALID;
+    const char* v = value ? value : "";
+    if (!strcmp(key, "th")) {          // tile height: "" automatic, one digit (4 | 8) for all stages, or five digits
+        for (int k = 0; k < 5; ++k) {
+            const char ch = strlen(v) == 5 ? v[k] : v[0];
+            c->env_th[k] = ch == '4' ? 4 : (ch == '8' ? 8 : 0);
+        }
+    } else if (!strcmp(key, "pipe")) { // "none": first form of the stage kernels everywhere
+        c->env_pipe = strcmp(v, "none") != 0;
+    } else if (!strcmp(key, "bw")) {   // tile-order column-block width in tiles; "" / negative: automatic, 0: plain row-major
+        c->env_bw = *v ? atoi(v) : -1;
+    } else {
+        return SR_E_INVALID;
+    }
     return SR_OK;
 }
 
@@ -422,7 +415,9 @@ int ensure_features(sr_ctx* c, int n, int H, int W, int tiles_x, hipStream_t s) 
     return SR_OK;
 }
 
-int ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
+}  // namespace
+
+int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return SR_OK;
     if (*p) HIPCHK(c, hipFree(*p));
     *p = nullptr; *cap = 0;
@@ -434,8 +429,8 @@ int ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
 // The whole conv stack on device buffers.  Rows [halo_top, H - halo_bot) of each
 // of the n images are produced; each earlier stage computes just the extra rows
 // the later ones read (f +-5, l1 +-3, l2 +-2, l3 +-1 around the band).
-int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top,
-              int halo_bot, void* d_out, bool out_u8, hipStream_t s) {
+int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top,
+                 int halo_bot, void* d_out, bool out_u8, hipStream_t s) {
     if (!c || !d_img || !d_out) return SR_E_INVALID;
     if (n <= 0 || H <= 0 || W <= 0) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
@@ -464,9 +459,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     const long tiles8 = (long)n * tiles_x * ((bot - top + 7) / 8);
     const int th_all = tiles8 >= 2L * (c->cus > 0 ? c->cus : 256) ? 8 : 4;
     int ths[5] = {th_all, th_all, th_all, th_all, th_all};
-    if (const char* e = getenv("SRHIP_TH")) {  // experiment override: one digit for all stages, or five
-        for (int k = 0; k < 5; ++k) { const char ch = strlen(e) == 5 ? e[k] : e[0]; ths[k] = ch == '4' ? 4 : 8; }
-    }
+    for (int k = 0; k < 5; ++k) if (c->env_th[k]) ths[k] = c->env_th[k];  // SRHIP_TH experiment override
     const float* P = c->d_params;
     const bool prof = c->profiling;
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
@@ -474,8 +467,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     for (int k = 0; k < 4; ++k) feat[k] = c->d_feat[k] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
     // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent), 4-row tiles (small
     // images) the first form; the two are bit-identical.  SRHIP_PIPE=none forces the first form everywhere (A/B runs).
-    bool pipe = true;
-    if (const char* e = getenv("SRHIP_PIPE")) pipe = strcmp(e, "none") != 0;
+    const bool pipe = c->env_pipe;
     HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of the persistent kernels
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
@@ -510,6 +502,7 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.n_img = n; a.queue = c->d_queue + st * 8;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
+            set_tile_order(a, c->env_bw >= 0 ? c->env_bw : kAutoBlockWidth);
             const bool use_pipe = pipe && th == 8;
             // persistent kernels (the pipe form; the first form in split-half mode) get one workgroup per resident
             // slot -- 2 per CU with 8-row tiles, 3 with 4-row tiles -- and pull tiles from the queue
@@ -540,31 +533,43 @@ int run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int 
     return SR_OK;
 }
 
-// One unit of the host pipeline: a whole image of a batch, or a row band of a single image
+namespace {
+
+// One unit of the host pipeline: some whole images of a batch, or a row band of a single image
 // with the halo rows it needs (band == untiled bit for bit, see sr_upscale_band_*).
 struct Chunk {
-    size_t in_off, in_bytes, out_off, out_bytes;
+    size_t in_off, in_bytes, out_off, out_bytes;  // of the chunk's FIRST image / of the band, in the caller's buffers
     int n, h_ext, halo_top, halo_bot;
+    size_t in_step, out_step;                     // n > 1: distance between consecutive images of the chunk in the caller's
+                                                  // buffers (= the image size for a contiguous batch, stride x that for a deal)
 };
 
-// Split the job.  Batches go image by image.  A single large sr_net image goes as row bands that
+// Which images of the caller's batch a call processes: first, first + stride, ... (count of them).  A plain call is
+// {0, 1, n}; a context's share of a round-robin deal over N contexts is {k, N, ceil((n - k) / N)}.
+struct Deal {
+    int first, stride, count;
+};
+
+// Split the job.  Batches go in chunks of ~1M px of whole images.  A single large sr_net image goes as row bands that
 // all have the SAME extended height E (so the zero borders of the feature maps stay valid and
 // nothing is re-cleared between chunks): band k owns rows [y0,y1) and carries the E rows
 // [start, start+E) with start = clamp(y0 - SR_HALO, 0, h - E).
 // [y_lo, y_hi): the image rows this call is to produce (a whole image: 0, h; a device's share of a multi-GPU
 // call: its rows, sr_net and n == 1 only).
-std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_px_bytes, size_t out_px_bytes, int y_lo, int y_hi) {
+std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t in_px_bytes, size_t out_px_bytes, int y_lo, int y_hi) {
     std::vector<Chunk> plan;
-    const int f = c->factor;
+    const int f = c->factor, n = deal.count;
     const size_t in_img = (size_t)h * w * in_px_bytes;
     const size_t out_img = c->graph == SR_GRAPH_DOWNSAMPLE ? (size_t)(h / 3) * (w / 3) * out_px_bytes
                                                            : (size_t)h * f * w * f * out_px_bytes;
+    const size_t in_step = in_img * deal.stride, out_step = out_img * deal.stride;
     const bool pipe = c->pipeline && !c->profiling;  // per-stage profiling times one undivided pass
     const int per = (int)std::max<size_t>(1, ((size_t)1 << 20) / ((size_t)h * w));  // images per chunk: ~1M px of work
     if (pipe && n > per) {
         for (int i = 0; i < n; i += per) {
             const int m = std::min(per, n - i);
-            plan.push_back({i * in_img, m * in_img, i * out_img, m * out_img, m, h, 0, 0});
+            const size_t img = (size_t)deal.first + (size_t)i * deal.stride;
+            plan.push_back({img * in_img, m * in_img, img * out_img, m * out_img, m, h, 0, 0, in_step, out_step});
         }
         return plan;
     }
@@ -575,6 +580,7 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_p
         bands = span / 192;  // >= 192 own rows per band keeps the 14 recomputed rows under 7.5 %
         if (bands > 8) bands = 8;
     }
+    const size_t img0_in = (size_t)deal.first * in_img, img0_out = (size_t)deal.first * out_img;
     if (bands >= 2) {
         const int rows = (span + bands - 1) / bands, E = rows + 2 * SR_HALO;
         bool ok = E <= h;
@@ -585,20 +591,21 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_p
             const int ht = y0 - start, hb = start + E - y1;
             ok = y1 > y0 && (ht == 0 || ht >= SR_HALO) && (hb == 0 || hb >= SR_HALO) && (ht == 0) == (y0 == 0) &&
                  (hb == 0) == (y1 == h);
-            plan.push_back({(size_t)start * w * in_px_bytes, (size_t)E * w * in_px_bytes,
-                            (size_t)y0 * f * w * f * out_px_bytes, (size_t)(y1 - y0) * f * w * f * out_px_bytes, 1, E, ht, hb});
+            plan.push_back({img0_in + (size_t)start * w * in_px_bytes, (size_t)E * w * in_px_bytes,
+                            img0_out + (size_t)y0 * f * w * f * out_px_bytes, (size_t)(y1 - y0) * f * w * f * out_px_bytes, 1, E, ht, hb,
+                            0, 0});
         }
         if (ok) return plan;
         plan.clear();
     }
     if (part) {  // one band: the rows themselves plus SR_HALO rows on every side that is not an image edge
         const int start = std::max(0, y_lo - SR_HALO), end = std::min(h, y_hi + SR_HALO);
-        plan.push_back({(size_t)start * w * in_px_bytes, (size_t)(end - start) * w * in_px_bytes,
-                        (size_t)y_lo * f * w * f * out_px_bytes, (size_t)span * f * w * f * out_px_bytes, 1, end - start,
-                        y_lo - start, end - y_hi});
+        plan.push_back({img0_in + (size_t)start * w * in_px_bytes, (size_t)(end - start) * w * in_px_bytes,
+                        img0_out + (size_t)y_lo * f * w * f * out_px_bytes, (size_t)span * f * w * f * out_px_bytes, 1, end - start,
+                        y_lo - start, end - y_hi, 0, 0});
         return plan;
     }
-    plan.push_back({0, (size_t)n * in_img, 0, (size_t)n * out_img, n, h, 0, 0});
+    plan.push_back({img0_in, (size_t)n * in_img, img0_out, (size_t)n * out_img, n, h, 0, 0, in_step, out_step});
     return plan;
 }
 
@@ -606,9 +613,10 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, int n, int h, int w, size_t in_p
 // three streams.  Issue order is H2D(i+1), kernels(i+1), D2H(i): with pageable caller memory the
 // runtime blocks the calling thread inside each copy, and this order keeps kernels queued behind
 // it; with pinned memory (sr_host_alloc) all three engines run concurrently.
-int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, int w, void* out, bool out_u8, int y_lo = 0,
+int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int h, int w, void* out, bool out_u8, int y_lo = 0,
              int y_hi = -1) {
-    if (!c || !in || !out || n <= 0 || h <= 0 || w <= 0) return SR_E_INVALID;
+    const int n = deal.count;
+    if (!c || !in || !out || n <= 0 || h <= 0 || w <= 0 || deal.first < 0 || deal.stride < 1) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
     if (c->graph == SR_GRAPH_DOWNSAMPLE && (h < 3 || w < 3)) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET && img_u8 != out_u8) return SR_E_INVALID;
@@ -619,14 +627,14 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, i
     if ((y_lo > 0 || y_hi < h) && (n != 1 || c->graph != SR_GRAPH_SR_NET)) return SR_E_INVALID;
     if (y_lo > 0 && y_lo < SR_HALO) return SR_E_HALO;
     if (y_hi < h && h - y_hi < SR_HALO) return SR_E_HALO;
-    const std::vector<Chunk> plan = plan_chunks(c, n, h, w, in_px, out_px, y_lo, y_hi);
+    const std::vector<Chunk> plan = plan_chunks(c, deal, h, w, in_px, out_px, y_lo, y_hi);
     const int nch = (int)plan.size();
     const int slots = nch > 1 ? 2 : 1;
     size_t in_max = 0, out_max = 0;
     for (const Chunk& k : plan) { in_max = std::max(in_max, k.in_bytes); out_max = std::max(out_max, k.out_bytes); }
     for (int sl = 0; sl < slots; ++sl) {
-        int rc = ensure_buf(c, &c->d_in[sl], &c->in_cap[sl], in_max);
-        if (rc == SR_OK) rc = ensure_buf(c, &c->d_out[sl], &c->out_cap[sl], out_max);
+        int rc = sr_ensure_buf(c, &c->d_in[sl], &c->in_cap[sl], in_max);
+        if (rc == SR_OK) rc = sr_ensure_buf(c, &c->d_out[sl], &c->out_cap[sl], out_max);
         if (rc != SR_OK) return rc;
     }
     // events per chunk: 0 upload begins, 1 upload done, 2 kernels begin, 3 kernels done, 4 download done
@@ -638,31 +646,48 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, i
     auto ev = [&](int i, int k) { return c->pool[(size_t)i * 5 + k]; };
     const char* src = (const char*)in;
     char* dst = (char*)out;
+    // a chunk's images are contiguous on the device; in the caller's buffers they are in_step / out_step apart
+    auto copy_images = [&](const Chunk& k, bool up, int sl) -> int {
+        const bool contiguous = k.n == 1 || (up ? k.in_step == k.in_bytes / k.n : k.out_step == k.out_bytes / k.n);
+        const int pieces = contiguous ? 1 : k.n;
+        const size_t in_img = k.in_bytes / (contiguous ? 1 : k.n), out_img = k.out_bytes / (contiguous ? 1 : k.n);
+        for (int j = 0; j < pieces; ++j) {
+            if (up) HIPCHK(c, hipMemcpyAsync((char*)c->d_in[sl] + j * in_img, src + k.in_off + j * k.in_step, in_img, hipMemcpyHostToDevice, c->copy_in));
+            else HIPCHK(c, hipMemcpyAsync(dst + k.out_off + j * k.out_step, (const char*)c->d_out[sl] + j * out_img, out_img, hipMemcpyDeviceToHost, c->copy_out));
+        }
+        return SR_OK;
+    };
     auto issue_front = [&](int i) -> int {  // upload + kernels of chunk i
         const Chunk& k = plan[i];
         const int sl = i % slots;
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->copy_in, ev(i - 2, 3), 0));  // slot's previous reader
         HIPCHK(c, hipEventRecord(ev(i, 0), c->copy_in));
-        HIPCHK(c, hipMemcpyAsync(c->d_in[sl], src + k.in_off, k.in_bytes, hipMemcpyHostToDevice, c->copy_in));
+        int rc = copy_images(k, true, sl);
+        if (rc != SR_OK) return rc;
         HIPCHK(c, hipEventRecord(ev(i, 1), c->copy_in));
         HIPCHK(c, hipStreamWaitEvent(c->stream, ev(i, 1), 0));
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, ev(i - 2, 4), 0));   // slot's previous download
         HIPCHK(c, hipEventRecord(ev(i, 2), c->stream));
-        const int rc = run_stack(c, c->d_in[sl], img_u8, img_ch, k.n, k.h_ext, w, k.halo_top, k.halo_bot, c->d_out[sl],
-                                 out_u8, c->stream);
+        rc = sr_run_stack(c, c->d_in[sl], img_u8, img_ch, k.n, k.h_ext, w, k.halo_top, k.halo_bot, c->d_out[sl],
+                          out_u8, c->stream);
         if (rc != SR_OK) return rc;
         HIPCHK(c, hipEventRecord(ev(i, 3), c->stream));
+        return SR_OK;
+    };
+    auto issue_back = [&](int i) -> int {  // download of chunk i
+        HIPCHK(c, hipStreamWaitEvent(c->copy_out, ev(i, 3), 0));
+        const int rc = copy_images(plan[i], false, i % slots);
+        if (rc != SR_OK) return rc;
+        HIPCHK(c, hipEventRecord(ev(i, 4), c->copy_out));
         return SR_OK;
     };
     int rc = issue_front(0);
     for (int i = 0; i < nch && rc == SR_OK; ++i) {
         if (i + 1 < nch) rc = issue_front(i + 1);
-        if (rc != SR_OK) break;
-        HIPCHK(c, hipStreamWaitEvent(c->copy_out, ev(i, 3), 0));
-        HIPCHK(c, hipMemcpyAsync(dst + plan[i].out_off, c->d_out[i % slots], plan[i].out_bytes, hipMemcpyDeviceToHost, c->copy_out));
-        HIPCHK(c, hipEventRecord(ev(i, 4), c->copy_out));
+        if (rc == SR_OK) rc = issue_back(i);
     }
-    // drain everything before returning, also on failure: the caller's buffers must not be in flight
+    // drain everything before returning, ALSO on failure: copies into / out of the caller's buffers and kernels on
+    // the context's stream must not be in flight once the call has returned
     const hipError_t e1 = hipStreamSynchronize(c->copy_in), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->copy_out);
     if (rc != SR_OK) return rc;
     HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
@@ -679,59 +704,75 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, int n, int h, i
     return SR_OK;
 }
 
+// Contexts that cooperate on one call must be distinct objects computing the same function: same graph, factor,
+// arithmetic mode and parameters -- or the "bit-identical to the single-device call" guarantee silently breaks
+// (a seam between shares), and one context driven from two threads at once races on its workspace.
+int check_context_set(sr_ctx* const* ctxs, int n_ctx) {
+    if (!ctxs || n_ctx <= 0) return SR_E_INVALID;
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!ctxs[k] || ctxs[k]->graph != SR_GRAPH_SR_NET) return SR_E_INVALID;
+        if (ctxs[k]->factor != ctxs[0]->factor || ctxs[k]->precision != ctxs[0]->precision ||
+            ctxs[k]->params_hash != ctxs[0]->params_hash) return SR_E_INVALID;
+        for (int j = 0; j < k; ++j) if (ctxs[j] == ctxs[k]) return SR_E_INVALID;
+    }
+    return SR_OK;
+}
+
 }  // namespace
+
+int sr_check_context_set(sr_ctx* const* ctxs, int n_ctx) { return check_context_set(ctxs, n_ctx); }
 
 extern "C" {
 
 int sr_upscale_f32_dev(sr_ctx* c, const float* d_in, int n, int h, int w, float* d_out, void* stream) {
-    return run_stack(c, d_in, false, 3, n, h, w, 0, 0, d_out, false, (hipStream_t)stream);
+    return sr_run_stack(c, d_in, false, 3, n, h, w, 0, 0, d_out, false, (hipStream_t)stream);
 }
 
 int sr_upscale_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, int n, int h, int w,
                          uint8_t* d_out, void* stream) {
-    return run_stack(c, d_in, true, in_channels, n, h, w, 0, 0, d_out, true, (hipStream_t)stream);
+    return sr_run_stack(c, d_in, true, in_channels, n, h, w, 0, 0, d_out, true, (hipStream_t)stream);
 }
 
 int sr_upscale_band_f32_dev(sr_ctx* c, const float* d_in, int h_ext, int w, int halo_top, int halo_bot,
                             float* d_out, void* stream) {
-    return run_stack(c, d_in, false, 3, 1, h_ext, w, halo_top, halo_bot, d_out, false, (hipStream_t)stream);
+    return sr_run_stack(c, d_in, false, 3, 1, h_ext, w, halo_top, halo_bot, d_out, false, (hipStream_t)stream);
 }
 
 int sr_upscale_band_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, int h_ext, int w,
                               int halo_top, int halo_bot, uint8_t* d_out, void* stream) {
-    return run_stack(c, d_in, true, in_channels, 1, h_ext, w, halo_top, halo_bot, d_out, true,
-                     (hipStream_t)stream);
+    return sr_run_stack(c, d_in, true, in_channels, 1, h_ext, w, halo_top, halo_bot, d_out, true,
+                        (hipStream_t)stream);
 }
 
 int sr_upscale_f32(sr_ctx* c, const float* in, int n, int h, int w, float* out) {
-    return run_host(c, in, false, 3, n, h, w, out, false);
+    return run_host(c, in, false, 3, Deal{0, 1, n}, h, w, out, false);
 }
 
 int sr_upscale_rgba8(sr_ctx* c, const uint8_t* in, int in_channels, int n, int h, int w, uint8_t* out) {
-    return run_host(c, in, true, in_channels, n, h, w, out, true);
+    return run_host(c, in, true, in_channels, Deal{0, 1, n}, h, w, out, true);
 }
 
 // One image, several GPUs, one process: device k produces its share of the rows from the caller's image directly
 // (the 7 halo rows either side are just more rows of the same host buffer, so nothing is exchanged between
 // devices); one host thread per context drives its pipeline.  Shares are multiples of 8 rows (whole tiles).
 static int run_multi(sr_ctx* const* ctxs, int n_ctx, const void* in, bool img_u8, int img_ch, int h, int w, void* out, bool out_u8) {
-    if (!ctxs || n_ctx <= 0 || !in || !out || h <= 0 || w <= 0) return SR_E_INVALID;
-    for (int k = 0; k < n_ctx; ++k)
-        if (!ctxs[k] || ctxs[k]->graph != SR_GRAPH_SR_NET || ctxs[k]->factor != ctxs[0]->factor) return SR_E_INVALID;
+    if (!in || !out || h <= 0 || w <= 0) return SR_E_INVALID;
+    const int chk = check_context_set(ctxs, n_ctx);
+    if (chk != SR_OK) return chk;
     int rows = (h + n_ctx - 1) / n_ctx;
     rows = std::max(8, (rows + 7) / 8 * 8);
     const int used = (h + rows - 1) / rows;
-    if (used == 1) return run_host(ctxs[0], in, img_u8, img_ch, 1, h, w, out, out_u8);
+    if (used == 1) return run_host(ctxs[0], in, img_u8, img_ch, Deal{0, 1, 1}, h, w, out, out_u8);
     // the last share must not be thinner than the halo its neighbour reads from it
     std::vector<int> lo(used), hi(used);
     for (int k = 0; k < used; ++k) { lo[k] = k * rows; hi[k] = std::min(h, lo[k] + rows); }
     if (hi[used - 1] - lo[used - 1] < SR_HALO) { hi[used - 2] = h; lo.pop_back(); hi.pop_back(); }
     const int parts = (int)lo.size();
-    if (parts == 1) return run_host(ctxs[0], in, img_u8, img_ch, 1, h, w, out, out_u8);
+    if (parts == 1) return run_host(ctxs[0], in, img_u8, img_ch, Deal{0, 1, 1}, h, w, out, out_u8);
     std::vector<int> rc(parts, SR_OK);
     std::vector<std::thread> th;
     for (int k = 0; k < parts; ++k)
-        th.emplace_back([&, k] { rc[k] = run_host(ctxs[k], in, img_u8, img_ch, 1, h, w, out, out_u8, lo[k], hi[k]); });
+        th.emplace_back([&, k] { rc[k] = run_host(ctxs[k], in, img_u8, img_ch, Deal{0, 1, 1}, h, w, out, out_u8, lo[k], hi[k]); });
     for (auto& t : th) t.join();
     for (int k = 0; k < parts; ++k)
         if (rc[k] != SR_OK) return rc[k];
@@ -744,6 +785,35 @@ int sr_upscale_f32_multi(sr_ctx* const* ctxs, int n_ctx, const float* in, int h,
 
 int sr_upscale_rgba8_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* in, int in_channels, int h, int w, uint8_t* out) {
     return run_multi(ctxs, n_ctx, in, true, in_channels, h, w, out, true);
+}
+
+// Many images, several GPUs, one process (throughput mode, BASELINE configs[4]): image i goes to context i mod n_ctx,
+// parameters are replicated, nothing is exchanged.  One host thread per context runs that context's images through
+// its own upload / compute / download pipeline (chunks of ~1M px, so several small images share a launch).
+static int run_batch_multi(sr_ctx* const* ctxs, int n_ctx, const void* in, bool img_u8, int img_ch, int n, int h, int w, void* out,
+                           bool out_u8) {
+    if (!in || !out || n <= 0 || h <= 0 || w <= 0) return SR_E_INVALID;
+    const int chk = check_context_set(ctxs, n_ctx);
+    if (chk != SR_OK) return chk;
+    const int used = std::min(n_ctx, n);
+    if (used == 1) return run_host(ctxs[0], in, img_u8, img_ch, Deal{0, 1, n}, h, w, out, out_u8);
+    std::vector<int> rc(used, SR_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < used; ++k)
+        th.emplace_back([&, k] { rc[k] = run_host(ctxs[k], in, img_u8, img_ch, Deal{k, used, (n - k + used - 1) / used}, h, w, out, out_u8); });
+    for (auto& t : th) t.join();
+    for (int k = 0; k < used; ++k)
+        if (rc[k] != SR_OK) return rc[k];
+    return SR_OK;
+}
+
+int sr_upscale_f32_batch_multi(sr_ctx* const* ctxs, int n_ctx, const float* in, int n, int h, int w, float* out) {
+    return run_batch_multi(ctxs, n_ctx, in, false, 3, n, h, w, out, false);
+}
+
+int sr_upscale_rgba8_batch_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* in, int in_channels, int n, int h, int w,
+                                 uint8_t* out) {
+    return run_batch_multi(ctxs, n_ctx, in, true, in_channels, n, h, w, out, true);
 }
 
 int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {

@@ -1,0 +1,307 @@
+// sr_comm.cpp -- multi-GPU part of the C ABI: one RCCL communicator per context and the sharded entry points
+// (SURVEY.md 8(b) "one RCCL communicator inside the context", 8(e)(i) halo-recompute exchange).
+//
+// The reference runs graph.forward on one CPU (main.rs:171) and has no collective of any kind.  What shards is
+// the output: every output pixel depends on a 15x15 input window (SR_HALO = 7), so an image splits into
+// contiguous row bands; a band needs the 7 input rows either side of it from its neighbours, recomputes the
+// overlap and writes its own rows -- bit-identical to the undivided call.  The exchange is one grouped
+// ncclSend / ncclRecv pair per neighbour (<= 7 * W * 12 B each: latency-bound, one xGMI link per direction),
+// issued on the stream the band's kernels follow on, so no host synchronisation sits between them.
+//
+// librccl is loaded lazily (dlopen of the SONAME): a process that already holds RCCL -- a torch process -- gets
+// that same instance, a plain C / Rust host gets the system one, and a single-GPU user never needs it at all.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "sr_internal.h"
+
+int sr_check_context_set(sr_ctx* const* ctxs, int n_ctx);  // sr_api.cpp
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) return;
+        bool all = true;
+        auto sym = [&](auto& fn, const char* name) {
+            fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(r.handle, name));
+            all = all && fn != nullptr;
+        };
+        sym(r.GetUniqueId, "ncclGetUniqueId");
+        sym(r.CommInitRank, "ncclCommInitRank");
+        sym(r.CommInitAll, "ncclCommInitAll");
+        sym(r.CommDestroy, "ncclCommDestroy");
+        sym(r.Send, "ncclSend");
+        sym(r.Recv, "ncclRecv");
+        sym(r.GroupStart, "ncclGroupStart");
+        sym(r.GroupEnd, "ncclGroupEnd");
+        sym(r.GetErrorString, "ncclGetErrorString");
+        r.ok = all;
+    });
+    return r.ok ? &r : nullptr;
+}
+
+#define NCCLCHK(ctx, expr)                              \
+    do {                                                \
+        ncclResult_t r__ = (expr);                      \
+        if (r__ != ncclSuccess) {                       \
+            if (ctx) (ctx)->last_nccl = (int)r__;       \
+            return SR_E_COMM;                           \
+        }                                               \
+    } while (0)
+
+struct BandGeom {
+    int top, bot, h_ext;
+    size_t row_bytes;
+};
+
+BandGeom band_geom(const sr_ctx* c, int h_band, int w, size_t px_bytes) {
+    BandGeom g;
+    g.top = c->comm_rank > 0 ? SR_HALO : 0;
+    g.bot = c->comm_rank < c->comm_nranks - 1 ? SR_HALO : 0;
+    g.h_ext = g.top + h_band + g.bot;
+    g.row_bytes = (size_t)w * px_bytes;
+    return g;
+}
+
+// Queue the band copy and this rank's four point-to-point operations on `s`.  The caller brackets the calls of
+// all ranks it drives with ONE ncclGroupStart / ncclGroupEnd (a single-threaded multi-GPU host must, or the first
+// rank's send blocks for a receive nobody has posted yet).
+int post_exchange(sr_ctx* c, Rccl* R, const void* d_band, int h_band, const BandGeom& g, hipStream_t s) {
+    const char* band = (const char*)d_band;
+    char* ext = (char*)c->d_ext;
+    const size_t halo = (size_t)SR_HALO * g.row_bytes;
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    if (g.top) {
+        NCCLCHK(c, R->Send(band, halo, ncclUint8, c->comm_rank - 1, comm, s));
+        NCCLCHK(c, R->Recv(ext, halo, ncclUint8, c->comm_rank - 1, comm, s));
+    }
+    if (g.bot) {
+        NCCLCHK(c, R->Send(band + (size_t)(h_band - SR_HALO) * g.row_bytes, halo, ncclUint8, c->comm_rank + 1, comm, s));
+        NCCLCHK(c, R->Recv(ext + (size_t)(g.top + h_band) * g.row_bytes, halo, ncclUint8, c->comm_rank + 1, comm, s));
+    }
+    return SR_OK;
+}
+
+int prepare_band(sr_ctx* c, const void* d_band, int h_band, int w, size_t px_bytes, BandGeom& g, hipStream_t s) {
+    if (!c || !d_band || h_band <= 0 || w <= 0) return SR_E_INVALID;
+    if (c->graph != SR_GRAPH_SR_NET) return SR_E_INVALID;
+    if (c->comm_nranks > 1 && !c->comm) return SR_E_COMM;
+    if (c->comm_nranks > 1 && h_band < SR_HALO) return SR_E_HALO;  // a neighbour reads SR_HALO rows of this band
+    HIPCHK(c, hipSetDevice(c->device));
+    g = band_geom(c, h_band, w, px_bytes);
+    const int rc = sr_ensure_buf(c, &c->d_ext, &c->ext_cap, (size_t)g.h_ext * g.row_bytes);
+    if (rc != SR_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync((char*)c->d_ext + (size_t)g.top * g.row_bytes, d_band, (size_t)h_band * g.row_bytes,
+                             hipMemcpyDeviceToDevice, s));
+    return SR_OK;
+}
+
+// one process per GPU: exchange + band pass of this rank, asynchronous on `s`
+int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, int w, void* d_out, hipStream_t s) {
+    if (!d_out) return SR_E_INVALID;
+    if (u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    BandGeom g;
+    int rc = prepare_band(c, d_band, h_band, w, u8 ? (size_t)img_ch : 3 * sizeof(float), g, s);
+    if (rc != SR_OK) return rc;
+    if (c->comm_nranks > 1) {
+        Rccl* R = rccl();
+        if (!R) return SR_E_COMM;
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[0], s));
+        NCCLCHK(c, R->GroupStart());
+        rc = post_exchange(c, R, d_band, h_band, g, s);
+        const ncclResult_t ge = R->GroupEnd();
+        if (rc != SR_OK) return rc;
+        NCCLCHK(c, ge);
+        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[1], s));
+    }
+    rc = sr_run_stack(c, c->d_ext, u8, img_ch, 1, g.h_ext, w, g.top, g.bot, d_out, u8, s);
+    if (rc == SR_OK && c->profiling && c->comm_nranks > 1) {  // sr_run_stack has synchronised on its last event
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_comm[0], c->ev_comm[1]));
+        c->comm_ms = ms;
+    }
+    return rc;
+}
+
+// one process, all ranks: every band of one image, synchronous
+int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, const int* h_bands, bool u8, int img_ch, int w,
+                    void* const* d_outs) {
+    if (!d_bands || !h_bands || !d_outs) return SR_E_INVALID;
+    int rc = sr_check_context_set(ctxs, n);
+    if (rc != SR_OK) return rc;
+    if (u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    for (int k = 0; k < n; ++k)
+        if (ctxs[k]->comm_nranks != n || ctxs[k]->comm_rank != k || !d_outs[k]) return SR_E_INVALID;
+    Rccl* R = n > 1 ? rccl() : nullptr;
+    if (n > 1 && !R) return SR_E_COMM;
+    std::vector<BandGeom> g(n);
+    const size_t px = u8 ? (size_t)img_ch : 3 * sizeof(float);
+    for (int k = 0; k < n; ++k) {
+        rc = prepare_band(ctxs[k], d_bands[k], h_bands[k], w, px, g[k], ctxs[k]->stream);
+        if (rc != SR_OK) return rc;
+    }
+    if (n > 1) {
+        NCCLCHK(ctxs[0], R->GroupStart());
+        for (int k = 0; k < n && rc == SR_OK; ++k) {
+            (void)hipSetDevice(ctxs[k]->device);
+            rc = post_exchange(ctxs[k], R, d_bands[k], h_bands[k], g[k], ctxs[k]->stream);
+        }
+        const ncclResult_t ge = R->GroupEnd();
+        if (rc == SR_OK && ge != ncclSuccess) { ctxs[0]->last_nccl = (int)ge; rc = SR_E_COMM; }
+    }
+    for (int k = 0; k < n && rc == SR_OK; ++k)
+        rc = sr_run_stack(ctxs[k], ctxs[k]->d_ext, u8, img_ch, 1, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, ctxs[k]->stream);
+    int first = rc;
+    for (int k = 0; k < n; ++k) {  // drain every device, also on failure
+        (void)hipSetDevice(ctxs[k]->device);
+        const hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
+        if (e != hipSuccess && first == SR_OK) { ctxs[k]->last_hip = (int)e; first = SR_E_HIP; }
+    }
+    return first;
+}
+
+}  // namespace
+
+void sr_comm_release(sr_ctx* c) {
+    if (!c) return;
+    if (c->comm) {
+        if (Rccl* R = rccl()) (void)R->CommDestroy((ncclComm_t)c->comm);
+        c->comm = nullptr;
+    }
+    c->comm_rank = 0; c->comm_nranks = 1;
+    if (c->d_ext) { (void)hipFree(c->d_ext); c->d_ext = nullptr; c->ext_cap = 0; }
+    for (auto& e : c->ev_comm) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+}
+
+extern "C" {
+
+int sr_comm_available(void) { return rccl() ? 1 : 0; }
+
+int sr_comm_unique_id(uint8_t* id, size_t cap) {
+    if (!id || cap < SR_COMM_ID_BYTES) return SR_E_INVALID;
+    static_assert(SR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "srhip.h and rccl.h disagree on the id size");
+    Rccl* R = rccl();
+    if (!R) return SR_E_COMM;
+    ncclUniqueId u;
+    if (R->GetUniqueId(&u) != ncclSuccess) return SR_E_COMM;
+    memcpy(id, u.internal, SR_COMM_ID_BYTES);
+    return SR_OK;
+}
+
+static int comm_events(sr_ctx* c) {
+    for (auto& e : c->ev_comm) if (!e) HIPCHK(c, hipEventCreate(&e));
+    return SR_OK;
+}
+
+int sr_comm_init_rank(sr_ctx* c, const uint8_t* id, size_t id_len, int rank, int nranks) {
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks) return SR_E_INVALID;
+    if (c->graph != SR_GRAPH_SR_NET) return SR_E_INVALID;
+    sr_comm_release(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = comm_events(c);
+    if (rc != SR_OK) return rc;
+    if (nranks > 1) {
+        if (!id || id_len < SR_COMM_ID_BYTES) return SR_E_INVALID;
+        Rccl* R = rccl();
+        if (!R) return SR_E_COMM;
+        ncclUniqueId u;
+        memcpy(u.internal, id, SR_COMM_ID_BYTES);
+        ncclComm_t comm = nullptr;
+        NCCLCHK(c, R->CommInitRank(&comm, nranks, u, rank));
+        c->comm = comm;
+    }
+    c->comm_rank = rank; c->comm_nranks = nranks;
+    return SR_OK;
+}
+
+int sr_comm_init_all(sr_ctx* const* ctxs, int n) {
+    int rc = sr_check_context_set(ctxs, n);
+    if (rc != SR_OK) return rc;
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j]->device == ctxs[k]->device) return SR_E_INVALID;  // RCCL: one rank per device
+    std::vector<int> devs(n);
+    for (int k = 0; k < n; ++k) {
+        sr_comm_release(ctxs[k]);
+        devs[k] = ctxs[k]->device;
+        HIPCHK(ctxs[k], hipSetDevice(devs[k]));
+        rc = comm_events(ctxs[k]);
+        if (rc != SR_OK) return rc;
+    }
+    if (n > 1) {
+        Rccl* R = rccl();
+        if (!R) return SR_E_COMM;
+        std::vector<ncclComm_t> comms(n, nullptr);
+        NCCLCHK(ctxs[0], R->CommInitAll(comms.data(), n, devs.data()));
+        for (int k = 0; k < n; ++k) ctxs[k]->comm = comms[k];
+    }
+    for (int k = 0; k < n; ++k) { ctxs[k]->comm_rank = k; ctxs[k]->comm_nranks = n; }
+    return SR_OK;
+}
+
+void sr_comm_destroy(sr_ctx* c) {
+    if (c) (void)hipSetDevice(c->device);
+    sr_comm_release(c);
+}
+
+int sr_comm_rank(sr_ctx* c, int* rank, int* nranks) {
+    if (!c) return SR_E_INVALID;
+    if (rank) *rank = c->comm_rank;
+    if (nranks) *nranks = c->comm_nranks;
+    return SR_OK;
+}
+
+int sr_last_comm_error(sr_ctx* c) { return c ? c->last_nccl : 0; }
+
+int sr_last_comm_ms(sr_ctx* c, double* comm_ms) {
+    if (!c || !comm_ms) return SR_E_INVALID;
+    *comm_ms = c->comm_ms;
+    return SR_OK;
+}
+
+int sr_upscale_sharded_f32_dev(sr_ctx* c, const float* d_band, int h_band, int w, float* d_out, void* stream) {
+    return run_sharded(c, d_band, false, 3, h_band, w, d_out, (hipStream_t)stream);
+}
+
+int sr_upscale_sharded_rgba8_dev(sr_ctx* c, const uint8_t* d_band, int in_channels, int h_band, int w, uint8_t* d_out,
+                                 void* stream) {
+    return run_sharded(c, d_band, true, in_channels, h_band, w, d_out, (hipStream_t)stream);
+}
+
+int sr_upscale_sharded_f32_all(sr_ctx* const* ctxs, int n, const float* const* d_bands, const int* h_bands, int w,
+                               float* const* d_outs) {
+    return run_sharded_all(ctxs, n, (const void* const*)d_bands, h_bands, false, 3, w, (void* const*)d_outs);
+}
+
+int sr_upscale_sharded_rgba8_all(sr_ctx* const* ctxs, int n, const uint8_t* const* d_bands, int in_channels,
+                                 const int* h_bands, int w, uint8_t* const* d_outs) {
+    return run_sharded_all(ctxs, n, (const void* const*)d_bands, h_bands, true, in_channels, w, (void* const*)d_outs);
+}
+
+}  // extern "C"

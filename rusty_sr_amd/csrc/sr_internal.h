@@ -1,0 +1,66 @@
+// sr_internal.h -- the context behind include/srhip.h's opaque sr_ctx, shared by sr_api.cpp (engine) and
+// sr_comm.cpp (RCCL communicator + sharded entry points).  Not installed, not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/srhip.h"
+
+struct sr_ctx {
+    int device = 0;
+    int cus = 0, clock_mhz = 0;
+    char name[128] = {0};
+    hipStream_t stream = nullptr;
+    float* d_params = nullptr;  // all packed parameters, one allocation
+    size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
+    int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
+    int graph = SR_GRAPH_SR_NET;
+    int factor = SR_FACTOR;
+    float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3 (zero-bordered, see sr_kernels.h)
+    size_t feat_cap_px = 0;       // allocated padded pixels per map
+    int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
+    int pitch = 0; long img_stride = 0;
+    int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
+    // host-pointer entry points: two in / out slots so that chunk i+1 uploads and chunk i-1
+    // downloads while chunk i computes (run_host)
+    void* d_in[2] = {nullptr, nullptr};  size_t in_cap[2] = {0, 0};
+    void* d_out[2] = {nullptr, nullptr}; size_t out_cap[2] = {0, 0};
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    std::vector<hipEvent_t> pool;  // per-chunk timing / ordering events of run_host, grown on demand
+    int pipeline = 1;              // 0: one upload, one pass, one download
+    int last_chunks = 0;
+    hipEvent_t ev[8] = {nullptr};
+    bool profiling = false;
+    double total_ms = 0, stage_ms[5] = {0}, h2d_ms = 0, d2h_ms = 0;
+    int last_h = 0, last_w = 0;
+    int last_hip = 0;
+    // experiment switches, read once at sr_create (none changes results): SRHIP_TH, SRHIP_PIPE, SRHIP_BW
+    int env_th[5] = {0, 0, 0, 0, 0};  // 0: automatic
+    bool env_pipe = true;
+    int env_bw = -1;                  // tile-order column-block width in tiles (-1: automatic)
+    unsigned long long params_hash = 0;  // FNV-1a of the parameter vector: contexts of one sharded call must agree
+    // ---- multi-GPU (sr_comm.cpp): one RCCL communicator per context, neighbour halo exchange
+    void* comm = nullptr;             // ncclComm_t
+    int comm_rank = 0, comm_nranks = 1;
+    void* d_ext = nullptr; size_t ext_cap = 0;  // band + halo rows, the exchange lands here
+    hipEvent_t ev_comm[2] = {nullptr, nullptr};
+    double comm_ms = 0;
+    int last_nccl = 0;
+};
+
+#define HIPCHK(ctx, expr)                         \
+    do {                                          \
+        hipError_t e__ = (expr);                  \
+        if (e__ != hipSuccess) {                  \
+            (ctx)->last_hip = (int)e__;           \
+            return e__ == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP; \
+        }                                         \
+    } while (0)
+
+
+// The whole conv stack on device buffers (sr_api.cpp): rows [halo_top, H - halo_bot) of each image are produced.
+int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
+                 void* d_out, bool out_u8, hipStream_t s);
+int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes);
+void sr_comm_release(sr_ctx* c);  // sr_comm.cpp: destroy the communicator and its buffers (called by sr_destroy)

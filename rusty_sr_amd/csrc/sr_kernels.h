@@ -47,7 +47,21 @@ struct StageArgs {
     int n_img;            // images in the batch (tiles = n_img * tiles_x * tiles_y)
     TileDiv div_tpi, div_tx;  // tile id -> (image, tile row, tile column) without a hardware divide
     int* queue;           // persistent form: 8 per-XCD tile-queue heads, zeroed before the launch
+    // Tile order inside an image: column blocks of `bw` tile columns, each walked row by row (bw = 0: plain
+    // row-major).  Consecutive tile ids -- what one XCD's workgroups hold at a time -- then cover a few rows of one
+    // block instead of a slice of one long tile row, so the halo rows of vertically adjacent tiles are still in
+    // that XCD's L2 when they are needed again (at 3840 px a tile row of one 32-channel map is 3.9 MB, the L2 4 MB).
+    int bw, nfull;                     // block width in tiles; number of full-width blocks (tiles_x / bw)
+    TileDiv div_blk, div_bw, div_rem;  // divisors: bw * tiles_y, bw, tiles_x % bw (the last, narrower block)
 };
+inline void set_tile_order(StageArgs& a, int bw) {
+    if (bw <= 0 || bw >= a.tiles_x) { a.bw = 0; a.nfull = 0; a.div_blk = a.div_bw = a.div_rem = TileDiv{1u, 0u}; return; }
+    a.bw = bw; a.nfull = a.tiles_x / bw;
+    a.div_blk = make_tile_div((uint32_t)(bw * a.tiles_y));
+    a.div_bw = make_tile_div((uint32_t)bw);
+    const int rem = a.tiles_x % bw;
+    a.div_rem = make_tile_div((uint32_t)(rem > 0 ? rem : 1));
+}
 
 // Feature maps live in HBM with a zero border so tile staging never tests bounds:
 // rows [-kFeatPad, H + kFeatPadBottom), columns [-kFeatPad, pitch - kFeatPad); kernels only

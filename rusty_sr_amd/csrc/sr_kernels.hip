@@ -42,6 +42,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <set>
 #include <type_traits>
 #include <utility>
 
@@ -134,6 +136,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 __device__ __forceinline__ int tile_div(int t, TileDiv d) {  // see make_tile_div
     return (int)((__umulhi((uint32_t)t, d.m) + (uint32_t)t) >> d.s);
+}
+
+// Tile id within the launch -> (image, tile column, tile row): see StageArgs::bw.  Scalar ALU only.
+__device__ __forceinline__ void tile_coords(const StageArgs& a, int t, int& n, int& tx, int& ty) {
+    const int tpi = a.tiles_x * a.tiles_y;
+    n = tile_div(t, a.div_tpi);
+    const int r = t - n * tpi;
+    if (a.bw == 0) {
+        ty = tile_div(r, a.div_tx);
+        tx = r - ty * a.tiles_x;
+    } else {
+        int b = tile_div(r, a.div_blk);
+        if (b > a.nfull) b = a.nfull;
+        const int rr = r - b * a.bw * a.tiles_y;
+        const bool full = b < a.nfull;
+        const int w = full ? a.bw : a.tiles_x - a.nfull * a.bw;
+        ty = full ? tile_div(rr, a.div_bw) : tile_div(rr, a.div_rem);
+        tx = b * a.bw + (rr - ty * w);
+    }
 }
 
 __device__ __forceinline__ float load_img(const void* img, int img_ch, bool u8, size_t px, int c) {
@@ -840,8 +861,8 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
     // request everything the first phase of tile `t` needs: weight chunks 0..3 and the first source tile
     int n = 0, x0 = 0, y0 = 0;
     auto request_tile = [&](int t) {
-        n = tile_div(t, a.div_tpi);
-        const int r = t - n * tiles_per_img, ty = tile_div(r, a.div_tx), tx = r - ty * a.tiles_x;
+        int tx, ty;
+        tile_coords(a, t, n, tx, ty);
         x0 = tx * kTW; y0 = a.y_begin + ty * TH;
 #pragma unroll
         for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
@@ -1156,8 +1177,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
 
     auto coords = [&](int t, int& n, int& x0, int& y0) {
-        n = tile_div(t, a.div_tpi);
-        const int r = t - n * tiles_per_img, ty = tile_div(r, a.div_tx), tx = r - ty * a.tiles_x;
+        int tx, ty;
+        tile_coords(a, t, n, tx, ty);
         x0 = tx * kTW; y0 = a.y_begin + ty * TH;
     };
 
@@ -1354,13 +1375,25 @@ hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool 
     return th == 8 ? launch_conv0_t<8, 1>(a, nblk, img_u8, s) : launch_conv0_t<4, 1>(a, nblk, img_u8, s);
 }
 
+// The > 64 KB dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is a property of a (kernel, device)
+// pair: every stage kernel instantiation has the same C++ type, and a process may drive several GPUs from several
+// host threads (sr_upscale_*_multi, sr_upscale_sharded_*_all), so the "already configured" set is keyed on both
+// and guarded by a mutex.
 template <typename K>
 static hipError_t launch_with_lds(K kern, const StageArgs& a, int nblk, size_t lds, hipStream_t s, int nthreads = kThreads) {
-    static bool configured = false;  // one instance per kernel template instantiation
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> configured;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const auto key = std::make_pair((const void*)kern, dev);
+        if (!configured.count(key)) {
+            e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            configured.insert(key);
+        }
     }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthreads), lds, s, a);
     return hipGetLastError();

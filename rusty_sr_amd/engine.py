@@ -178,6 +178,48 @@ class Engine:
                                                      self._stream_ptr(stream)), self._ctx)
         return out
 
+    # ---- sharded image: RCCL communicator inside libsrhip (include/srhip.h sr_comm_*) ----------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 opaque bytes from rank 0 (ncclGetUniqueId) that every rank passes to comm_init_rank."""
+        buf = (C.c_uint8 * _lib.SR_COMM_ID_BYTES)()
+        _lib.check(_lib.lib().sr_comm_unique_id(buf, _lib.SR_COMM_ID_BYTES))
+        return bytes(buf)
+
+    def comm_init_rank(self, uid: bytes, rank: int, nranks: int):
+        """Join the band communicator as `rank` of `nranks` (collective; one process per GPU)."""
+        buf = (C.c_uint8 * _lib.SR_COMM_ID_BYTES).from_buffer_copy(uid) if nranks > 1 else None
+        _lib.check(self._L.sr_comm_init_rank(self._ctx, buf, _lib.SR_COMM_ID_BYTES if nranks > 1 else 0, rank, nranks), self._ctx)
+
+    def comm_rank(self):
+        r, n = C.c_int(), C.c_int()
+        _lib.check(self._L.sr_comm_rank(self._ctx, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def last_comm_ms(self) -> float:
+        v = C.c_double()
+        _lib.check(self._L.sr_last_comm_ms(self._ctx, C.byref(v)))
+        return v.value
+
+    def upscale_sharded_dev(self, band, out=None, stream=None):
+        """This rank's band (rows, W, 3 f32 | 3-4 u8) of an image sharded in rank order: halo exchange over the
+        context's RCCL communicator + band pass, asynchronous on the stream -> (3 rows, 3 W, 3 f32 | 4 u8)."""
+        import torch
+        assert band.is_cuda and band.is_contiguous() and band.dim() == 3
+        hb, w, c = band.shape
+        u8 = band.dtype == torch.uint8
+        assert u8 or (band.dtype == torch.float32 and c == 3)
+        if out is None:
+            out = torch.empty((self.factor * hb, self.factor * w, 4 if u8 else 3), dtype=band.dtype, device=band.device)
+        if u8:
+            st = self._L.sr_upscale_sharded_rgba8_dev(self._ctx, C.c_void_p(band.data_ptr()), c, hb, w, C.c_void_p(out.data_ptr()),
+                                                      self._stream_ptr(stream))
+        else:
+            st = self._L.sr_upscale_sharded_f32_dev(self._ctx, C.c_void_p(band.data_ptr()), hb, w, C.c_void_p(out.data_ptr()),
+                                                    self._stream_ptr(stream))
+        _lib.check(st, self._ctx)
+        return out
+
     # ---- introspection ------------------------------------------------------
     def read_feature(self, which: int, h: int, w: int) -> np.ndarray:
         """Post-activation node data of the last call: 0..3 = f, l1, l2, l3."""
@@ -189,6 +231,10 @@ class Engine:
         """Host-pointer entry points: chunked upload / compute / download overlap (default on);
         results do not depend on it."""
         _lib.check(self._L.sr_set_pipeline(self._ctx, 1 if on else 0))
+
+    def set_experiment(self, key: str, value: str = ""):
+        """sr_set_experiment: "th" / "pipe" / "bw" A/B switches (results do not depend on them)."""
+        _lib.check(self._L.sr_set_experiment(self._ctx, key.encode(), value.encode()))
 
     def set_profiling(self, on: bool):
         _lib.check(self._L.sr_set_profiling(self._ctx, int(on)))
@@ -229,6 +275,61 @@ def upscale_multi(engines, px: np.ndarray, out: np.ndarray = None) -> np.ndarray
         fp = C.POINTER(C.c_float)
         _lib.check(L.sr_upscale_f32_multi(arr, len(engines), px.ctypes.data_as(fp), h, w, out.ctypes.data_as(fp)))
     return out
+
+
+def upscale_batch_multi(engines, px: np.ndarray, out: np.ndarray = None) -> np.ndarray:
+    """A batch dealt over several engines from this process (sr_upscale_*_batch_multi): image i -> engines[i mod N].
+    px (n,H,W,3|4) u8 -> (n,3H,3W,4) u8 RGBA, or (n,H,W,3) f32 -> (n,3H,3W,3) f32; identical to one engine's result."""
+    L = _lib.lib()
+    arr = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
+    f = engines[0].factor
+    if px.dtype == np.uint8:
+        px = np.ascontiguousarray(px)
+        n, h, w, c = px.shape
+        if out is None:
+            out = np.empty((n, f * h, f * w, 4), dtype=np.uint8)
+        u8p = C.POINTER(C.c_uint8)
+        _lib.check(L.sr_upscale_rgba8_batch_multi(arr, len(engines), px.ctypes.data_as(u8p), c, n, h, w, out.ctypes.data_as(u8p)))
+    else:
+        px = np.ascontiguousarray(px, dtype=np.float32)
+        n, h, w, c = px.shape
+        if c != 3:
+            raise ValueError("expected 3 channels")
+        if out is None:
+            out = np.empty((n, f * h, f * w, 3), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        _lib.check(L.sr_upscale_f32_batch_multi(arr, len(engines), px.ctypes.data_as(fp), n, h, w, out.ctypes.data_as(fp)))
+    return out
+
+
+def comm_init_all(engines):
+    """One process, one engine per device: ncclCommInitAll inside libsrhip; engine k becomes rank k."""
+    arr = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
+    _lib.check(_lib.lib().sr_comm_init_all(arr, len(engines)), engines[0]._ctx)
+
+
+def upscale_sharded_all(engines, bands, outs=None):
+    """Bands (torch tensors, band k on engine k's device, rank order) of ONE image -> their output rows, through
+    sr_upscale_sharded_*_all (grouped RCCL halo exchange + band passes, synchronous)."""
+    import torch
+    n = len(engines)
+    f = engines[0].factor
+    u8 = bands[0].dtype == torch.uint8
+    w, c = bands[0].shape[1], bands[0].shape[2]
+    if outs is None:
+        outs = [torch.empty((f * b.shape[0], f * w, 4 if u8 else 3), dtype=b.dtype, device=b.device) for b in bands]
+    ctxs = (C.c_void_p * n)(*[e._ctx for e in engines])
+    bp = (C.c_void_p * n)(*[b.data_ptr() for b in bands])
+    op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    hb = (C.c_int * n)(*[b.shape[0] for b in bands])
+    L = _lib.lib()
+    for b in bands:
+        torch.cuda.synchronize(b.device)  # the library runs on the contexts' own streams
+    if u8:
+        _lib.check(L.sr_upscale_sharded_rgba8_all(ctxs, n, bp, c, hb, w, op), engines[0]._ctx)
+    else:
+        _lib.check(L.sr_upscale_sharded_f32_all(ctxs, n, bp, hb, w, op), engines[0]._ctx)
+    return outs
 
 
 class PinnedBuffer:

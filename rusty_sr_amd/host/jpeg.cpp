@@ -155,8 +155,12 @@ bool decode_jpeg_memory(const uint8_t* d, size_t len, Image& out, std::string& e
         else if (m == 0xee && n >= 12 && !memcmp(s, "Adobe", 5)) adobe_transform = s[11];
         else if (m == 0xda) {  // SOS: decode the single interleaved scan of a baseline file
             if (!have_sof) { err = "JPEG scan before frame header"; return false; }
+            if (n < 1) { err = "bad JPEG scan header"; return false; }
             const int ns = s[0];
             if (ns != ncomp || n < 1 + (size_t)2 * ns + 3) { err = "multi-scan baseline JPEG is not supported"; return false; }
+            // T.81 A.2.2: a scan with ONE component is not interleaved -- one 8x8 data unit per MCU in raster order over
+            // ceil(W/8) x ceil(H/8), whatever sampling factors the frame header declares for it
+            if (ncomp == 1) comp[0].h = comp[0].v = 1;
             for (int i = 0; i < ns; ++i) {
                 int ci = -1;
                 for (int j = 0; j < ncomp; ++j) if (comp[j].id == s[1 + 2 * i]) ci = j;

@@ -300,6 +300,7 @@ static bool encode_band(const uint8_t* rgba, int w, int y0, int y1, bool last, i
         }
     }
     raw_len = raw.size();
+    if (raw.size() > 0xfffffff0u) return false;  // zlib's uInt counters: never truncate silently
     adler = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
     z_stream zs;
     memset(&zs, 0, sizeof zs);
@@ -356,7 +357,13 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
     ihdr[4] = Hh >> 24; ihdr[5] = Hh >> 16; ihdr[6] = Hh >> 8; ihdr[7] = Hh;
     ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;  // 8-bit RGBA like the reference's outputs
     chunk("IHDR", ihdr, 13);
-    chunk("IDAT", comp.data(), clen);
+    // a PNG chunk length is at most 2^31 - 1: a large stream goes out as several IDAT chunks (the decoder
+    // concatenates them, PNG spec 11.2.4)
+    const size_t kMaxIdat = (size_t)1 << 30;
+    for (size_t off = 0; off < clen || off == 0; off += kMaxIdat) {
+        chunk("IDAT", comp.data() + off, std::min(kMaxIdat, (size_t)clen - off));
+        if (clen == 0) break;
+    }
     chunk("IEND", nullptr, 0);
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot create file"; return false; }

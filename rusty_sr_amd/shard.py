@@ -101,3 +101,42 @@ def upscale_sharded(band: torch.Tensor, rank: int, world: int,
     xchg.band.copy_(band)
     ext = xchg.exchange()
     return compute(ext, xchg.top, xchg.bot)
+
+
+def init_band_comm(engine, rank: int, world: int, group=None) -> None:
+    """Give `engine` (this rank's Engine) its RCCL band communicator INSIDE libsrhip (sr_comm_init_rank): rank 0
+    draws the 128-byte id (ncclGetUniqueId), torch.distributed only carries those bytes to the other ranks.  After
+    this, Engine.upscale_sharded_dev exchanges halos without touching torch.distributed at all -- the same calls a
+    Rust / C++ host makes."""
+    uid = [engine.comm_unique_id() if rank == 0 and world > 1 else b""]
+    if world > 1:
+        dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init_rank(uid[0], rank, world)
+
+
+def upscale_batch_round_robin(images, rank: int, world: int, compute: Callable, group=None, gather: bool = False):
+    """Throughput mode (BASELINE configs[4], reference main.rs:164-171 once per file): image i is processed by rank
+    i mod world, parameters replicated, NO communication on the data path.  `images` is the whole batch (indexable
+    by image: numpy (n,H,W,C) or a list -- a rank only touches its own entries); `compute(stack)` maps this rank's
+    (m,H,W,C) stack to its (m,3H,3W,C') outputs (Engine.upscale_rgba8 / upscale_f32 on a GPU).
+    Returns (indices, outputs); with gather=True every rank's outputs are collected on rank 0 (all_gather_object:
+    test / verification helper, not part of the timed path) and rank 0 gets the batch in image order."""
+    import numpy as np
+    idx = round_robin(len(images), rank, world)
+    mine = np.stack([np.asarray(images[i]) for i in idx]) if idx else None
+    outs = compute(mine) if idx else None
+    if not gather:
+        return idx, outs
+    if world == 1:
+        return idx, outs
+    parts = [None] * world
+    dist.all_gather_object(parts, (idx, None if outs is None else np.asarray(outs)), group=group)
+    if rank != 0:
+        return idx, outs
+    n = len(images)
+    first = next(o for _, o in parts if o is not None)
+    full = np.empty((n,) + first.shape[1:], dtype=first.dtype)
+    for ids, o in parts:
+        for j, i in enumerate(ids):
+            full[i] = o[j]
+    return list(range(n)), full

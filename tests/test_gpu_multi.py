@@ -1,0 +1,259 @@
+"""GPU tests of the multi-GPU / sharded side of the C ABI and of BASELINE.json's named configurations at their full
+sizes: config B (1920x1080) whole frame against the oracle, config C (3840x2160 as 8 row bands, 270 rows + 7-row
+halos), config D (64 x 512x512 dealt round-robin).  The test box has ONE GPU: several contexts then share it (same
+code path, same host threads, no RCCL -- RCCL admits one rank per device); everything that needs distinct devices
+runs whenever torch.cuda.device_count() > 1 (the driver's multi-GPU node)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import synth_u8
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+TIGHT = 2e-5
+
+
+def _ndev():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.fixture(scope="module", params=["f32", "split_f16"])
+def eng(params, request):
+    import rusty_sr_amd as r
+    e = r.Engine(params["imagenet"], device=0, precision=request.param)
+    yield e
+    e.close()
+
+
+# ---------------------------------------------------------------- config B: the whole 1080p frame, not crops
+def test_config_b_whole_frame_against_the_oracle(eng, params):
+    """1920x1080 -> 5760x3240, EVERY output sample against the CPU oracle (f32, pre-quantisation) and the fused u8
+    path against the oracle's quantiser.  The oracle needs a few seconds for this frame on the GPU box's host."""
+    px = synth_u8(2, 1, 1080, 1920)
+    x = oracle.img_to_data(px)
+    want = oracle.forward(params["imagenet"], x)
+    got = eng.upscale_f32(x)
+    assert got.shape == want.shape == (1, 3240, 5760, 3)
+    err = np.abs(got - want)
+    assert err.max() < TIGHT, err.max()
+    got8 = eng.upscale_rgba8(px)
+    want8 = oracle.data_to_rgba8(want)
+    d = got8[..., :3].astype(np.int16) - want8[..., :3].astype(np.int16)
+    assert (got8[..., 3] == 255).all() and np.abs(d).max() <= 1
+    bad = d != 0
+    assert bad.mean() < 1e-4
+    frac = 255.0 * want.astype(np.float64) + 0.5
+    if bad.any():
+        assert np.abs(frac - np.round(frac))[bad].max() < 255 * TOL  # only at rounding knife-edges
+
+
+def test_split_mode_is_as_close_to_exact_arithmetic_as_the_f32_cpu_path(params):
+    """|split_f16 - f64 truth| <= 2 |oracle f32 - f64 truth| on a set of 1080p crops: the fast mode may be quoted
+    beside the exact mode without a precision asterisk.  (Crops carry the 7-px halo; the comparison is on the
+    interior, where crop == frame.)"""
+    import rusty_sr_amd as r
+    px = synth_u8(2, 1, 1080, 1920)[0]
+    engs = {p: r.Engine(params["imagenet"], device=0, precision=p) for p in ("f32", "split_f16")}
+    try:
+        full = {p: e.upscale_f32(oracle.img_to_data(px)) for p, e in engs.items()}
+        worst = {"f32": 0.0, "split_f16": 0.0, "cpu": 0.0}
+        for (y, x) in ((0, 0), (100, 700), (500, 1200), (1080 - 142, 1920 - 142), (640, 0), (300, 1500)):
+            crop = oracle.img_to_data(px[y:y + 142, x:x + 142])
+            truth = oracle.forward(params["imagenet"], crop, f64=True)[0][21:-21, 21:-21].astype(np.float64)
+            cpu = oracle.forward(params["imagenet"], crop)[0][21:-21, 21:-21]
+            worst["cpu"] = max(worst["cpu"], float(np.abs(cpu - truth).max()))
+            for p in engs:
+                got = full[p][0][3 * (y + 7):3 * (y + 135), 3 * (x + 7):3 * (x + 135)]
+                worst[p] = max(worst[p], float(np.abs(got - truth).max()))
+        assert worst["split_f16"] <= 2 * worst["cpu"] + 1e-7, worst
+        assert worst["f32"] <= 2 * worst["cpu"] + 1e-7, worst
+        assert worst["split_f16"] < TIGHT and worst["f32"] < TIGHT
+    finally:
+        for e in engs.values():
+            e.close()
+
+
+# ---------------------------------------------------------------- config C: 3840x2160 as 8 row bands
+def test_config_c_every_band_of_the_8_way_split(eng):
+    """BASELINE configs[3]: each of the eight 270-row bands of the 3840x2160 image, extended by the 7 halo rows its
+    neighbours would send, reproduces the undivided rows bit for bit (band 0 / 7 touch the true image edges)."""
+    import torch
+    from rusty_sr_amd.shard import split_rows
+    H, W = 2160, 3840
+    px = torch.from_numpy(synth_u8(3, 1, H, W)[0]).cuda()
+    full = eng.upscale_rgba8_dev(px[None])[0]
+    torch.cuda.synchronize()
+    for a, b in split_rows(H, 8):
+        assert b - a == 270
+        top, bot = (0 if a == 0 else 7), (0 if b == H else 7)
+        out = eng.upscale_band_rgba8_dev(px[a - top:b + bot].contiguous(), top, bot)
+        torch.cuda.synchronize()
+        assert torch.equal(out, full[3 * a:3 * b]), (a, b)
+
+
+def test_config_c_through_eight_contexts(params, eng):
+    """3840x2160 through sr_upscale_rgba8_multi with 8 contexts (the one-process form of config C; on this box all on
+    one GPU, on a multi-GPU node one per device): equal to the single-context call."""
+    import rusty_sr_amd as r
+    import torch
+    nd = _ndev()
+    engs = [r.Engine(params["imagenet"], device=k % nd, precision=eng.precision) for k in range(8)]
+    try:
+        px = synth_u8(3, 1, 2160, 3840)[0]
+        want = eng.upscale_rgba8(px)
+        got = r.upscale_multi(engs, px)
+        np.testing.assert_array_equal(got, want)
+    finally:
+        for e in engs:
+            e.close()
+
+
+# ---------------------------------------------------------------- config D: 64 x 512x512
+def test_config_d_batch_of_64(eng):
+    """BASELINE configs[4] at its full size on one GPU: the 64-image batch through sr_upscale_rgba8 (chunked host
+    pipeline) equals 64 single-image calls."""
+    px = synth_u8(4, 64, 512, 512)
+    got = eng.upscale_rgba8(px)
+    assert got.shape == (64, 1536, 1536, 4)
+    for i in range(64):
+        np.testing.assert_array_equal(got[i], eng.upscale_rgba8(px[i]), err_msg=f"image {i}")
+
+
+@pytest.mark.parametrize("k", [2, 3, 8])
+def test_config_d_dealt_round_robin_over_contexts(params, eng, k):
+    """sr_upscale_*_batch_multi: image i -> context i mod k, one host thread per context; equal to one context's batch,
+    image for image (u8 and f32, ragged: 13 images over k contexts)."""
+    import rusty_sr_amd as r
+    nd = _ndev()
+    engs = [r.Engine(params["imagenet"], device=j % nd, precision=eng.precision) for j in range(k)]
+    try:
+        px = synth_u8(44, 13, 96, 160)
+        np.testing.assert_array_equal(r.upscale_batch_multi(engs, px), eng.upscale_rgba8(px))
+        x = oracle.img_to_data(px[:5])
+        np.testing.assert_array_equal(r.upscale_batch_multi(engs, x), eng.upscale_f32(x))
+        if k == 8:  # the named size: 64 x 512x512 over 8 contexts
+            px = synth_u8(4, 64, 512, 512)
+            np.testing.assert_array_equal(r.upscale_batch_multi(engs, px), eng.upscale_rgba8(px))
+    finally:
+        for e in engs:
+            e.close()
+
+
+def test_round_robin_driver_on_the_gpu(eng, params):
+    """shard.upscale_batch_round_robin with the GPU engine as the per-rank compute: the shares of ranks 0..2 of a
+    7-image batch, stitched together, are the single-rank batch."""
+    from rusty_sr_amd.shard import upscale_batch_round_robin
+    px = synth_u8(45, 7, 64, 100)
+    want = eng.upscale_rgba8(px)
+    got = np.empty_like(want)
+    for rank in range(3):
+        idx, outs = upscale_batch_round_robin(px, rank, 3, eng.upscale_rgba8)
+        got[idx] = outs
+    np.testing.assert_array_equal(got, want)
+
+
+# ---------------------------------------------------------------- the context-set rules of the multi calls
+def test_cooperating_contexts_must_match(params):
+    import rusty_sr_amd as r
+    a = r.Engine(params["imagenet"], device=0)
+    b = r.Engine(params["imagenet"], device=0, precision="split_f16")
+    c = r.Engine(params["anime"], device=0)
+    d = r.Engine(params["imagenet"], device=0)
+    px = synth_u8(1, 2, 40, 40)
+    try:
+        for bad in ([a, a], [a, b], [a, c]):  # the same context twice / another arithmetic mode / other parameters
+            with pytest.raises(r.SrError):
+                r.upscale_multi(bad, px[0])
+            with pytest.raises(r.SrError):
+                r.upscale_batch_multi(bad, px)
+        np.testing.assert_array_equal(r.upscale_multi([a, d], px[0]), a.upscale_rgba8(px[0]))
+    finally:
+        for e in (a, b, c, d):
+            e.close()
+
+
+# ---------------------------------------------------------------- the RCCL communicator inside libsrhip
+def test_comm_single_rank_and_argument_rules(eng, params):
+    """sr_comm_*: a 1-rank communicator needs no RCCL object and makes sr_upscale_sharded_*_dev the plain call;
+    the id is 128 bytes from ncclGetUniqueId; two contexts of one device cannot form a communicator (RCCL admits
+    one rank per device)."""
+    import torch
+    import rusty_sr_amd as r
+    from rusty_sr_amd import _lib
+    L = _lib.lib()
+    assert L.sr_comm_available() == 1
+    uid = r.Engine.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    assert eng.comm_rank() == (0, 1)
+    eng.comm_init_rank(b"", 0, 1)
+    px = torch.from_numpy(synth_u8(9, 1, 50, 70)[0]).cuda()
+    out = eng.upscale_sharded_dev(px)
+    want = eng.upscale_rgba8_dev(px[None])[0]
+    x = torch.from_numpy(oracle.img_to_data(px.cpu().numpy())).cuda()
+    out32 = eng.upscale_sharded_dev(x)
+    want32 = eng.upscale_f32_dev(x[None])[0]
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(out32, want32)
+    with pytest.raises(r.SrError):
+        eng.comm_init_rank(uid, 2, 2)   # rank out of range
+    other = r.Engine(params["imagenet"], device=0, precision=eng.precision)
+    try:
+        with pytest.raises(r.SrError):
+            r.comm_init_all([eng, other])  # same device twice
+        r.comm_init_all([other])
+        outs = r.upscale_sharded_all([other], [px])
+        assert torch.equal(outs[0], want)
+    finally:
+        other.close()
+
+
+@pytest.mark.skipif("_ndev() < 2")
+def test_contexts_on_other_devices(params):
+    """device != 0: the > 64 KB dynamic-LDS attribute is per (kernel, device); a context on every device of the node
+    must run every stage kernel (both forms, both modes) and agree with device 0."""
+    import rusty_sr_amd as r
+    px = synth_u8(8, 1, 300, 1100)[0]   # pipe form
+    small = synth_u8(8, 1, 40, 70)[0]   # first form
+    for prec in ("f32", "split_f16"):
+        ref = r.Engine(params["imagenet"], device=0, precision=prec)
+        want, want_s = ref.upscale_rgba8(px), ref.upscale_rgba8(small)
+        for dev in range(1, _ndev()):
+            e = r.Engine(params["imagenet"], device=dev, precision=prec)
+            np.testing.assert_array_equal(e.upscale_rgba8(px), want, err_msg=f"device {dev}")
+            np.testing.assert_array_equal(e.upscale_rgba8(small), want_s, err_msg=f"device {dev}")
+            e.close()
+        ref.close()
+
+
+@pytest.mark.skipif("_ndev() < 2")
+def test_sharded_over_all_devices_with_rccl(params):
+    """The real thing (runs on a multi-GPU node only): one context per device, ncclCommInitAll inside libsrhip, one
+    3840-wide image in row bands resident on their devices, grouped ncclSend / ncclRecv halo exchange over xGMI,
+    band passes -- bit-identical to the single-GPU call; and the host-memory forms across real devices."""
+    import torch
+    import rusty_sr_amd as r
+    from rusty_sr_amd.shard import split_rows
+    n = _ndev()
+    H, W = 135 * n, 3840
+    px = synth_u8(3, 1, H, W)[0]
+    for prec in ("f32", "split_f16"):
+        engs = [r.Engine(params["imagenet"], device=k, precision=prec) for k in range(n)]
+        try:
+            want = engs[0].upscale_rgba8(px)
+            r.comm_init_all(engs)
+            bands = [torch.from_numpy(px[a:b]).to(f"cuda:{k}") for k, (a, b) in enumerate(split_rows(H, n))]
+            for _ in range(2):
+                outs = r.upscale_sharded_all(engs, bands)
+            got = np.concatenate([o.cpu().numpy() for o in outs])
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(r.upscale_multi(engs, px), want)
+            batch = synth_u8(4, 2 * n + 1, 128, 160)
+            np.testing.assert_array_equal(r.upscale_batch_multi(engs, batch), engs[0].upscale_rgba8(batch))
+        finally:
+            for e in engs:
+                e.close()

@@ -311,33 +311,41 @@ def test_host_pipeline_batch_chunks(engines, params):
     assert np.abs(got[20] - oracle.forward(params["imagenet"], x[20:21])[0]).max() < TOL
 
 
-def test_pipe_form_equals_first_form_bit_for_bit(engines, params, monkeypatch):
+def test_pipe_form_equals_first_form_bit_for_bit(engines, params):
     """The two forms of the stage kernels (conv_stage_pipe_kernel: half tiles double-buffered, persistent;
     conv_stage_kernel: whole tile resident) share step order and weight chunks, so they must agree bit for
-    bit -- on ragged shapes, on batches, with few tiles per workgroup, and for both tile heights of the first
-    form.  SRHIP_TH / SRHIP_PIPE are the library's experiment switches (read at every call)."""
+    bit -- on ragged shapes, on batches, with few tiles per workgroup, for both tile heights of the first
+    form, and for any tile order (column-block width).  sr_set_experiment is the library's A/B switch."""
     eng = engines["imagenet"]
     rng = np.random.default_rng(5)
     shapes = [(1, 8, 32), (1, 9, 33), (2, 40, 70), (1, 64, 1024), (3, 37, 129), (1, 130, 700), (1, 300, 515), (1, 2000, 40), (1, 16, 3000)]
-    for (n, h, w) in shapes:
-        px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
-        x = oracle.img_to_data(px)
-        monkeypatch.setenv("SRHIP_TH", "8")
-        monkeypatch.setenv("SRHIP_PIPE", "all")
-        pipe32, pipe8 = eng.upscale_f32(x), eng.upscale_rgba8(px)
-        feats = [eng.read_feature(k, h, w) for k in range(4)]
-        monkeypatch.setenv("SRHIP_PIPE", "none")
-        first32 = eng.upscale_f32(x)
-        np.testing.assert_array_equal(pipe32, first32, err_msg=str((n, h, w)))
-        for k in range(4):
-            np.testing.assert_array_equal(feats[k], eng.read_feature(k, h, w), err_msg=f"feature {k} {(n, h, w)}")
-        np.testing.assert_array_equal(pipe8, eng.upscale_rgba8(px))
-        monkeypatch.setenv("SRHIP_TH", "4")
-        np.testing.assert_array_equal(eng.upscale_f32(x), first32, err_msg="tile height 4 vs 8")
-        monkeypatch.delenv("SRHIP_TH")
-        monkeypatch.delenv("SRHIP_PIPE")
-        if n * h * w <= 40 * 70 * 2:
-            assert np.abs(pipe32 - oracle.forward(params["imagenet"], x)).max() < TIGHT
+    try:
+        for (n, h, w) in shapes:
+            px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+            x = oracle.img_to_data(px)
+            eng.set_experiment("th", "8")
+            eng.set_experiment("pipe", "all")
+            pipe32, pipe8 = eng.upscale_f32(x), eng.upscale_rgba8(px)
+            feats = [eng.read_feature(k, h, w) for k in range(4)]
+            for bw in ("0", "3", "16"):
+                eng.set_experiment("bw", bw)
+                np.testing.assert_array_equal(eng.upscale_f32(x), pipe32, err_msg=f"tile order bw={bw} {(n, h, w)}")
+            eng.set_experiment("bw", "")
+            eng.set_experiment("pipe", "none")
+            first32 = eng.upscale_f32(x)
+            np.testing.assert_array_equal(pipe32, first32, err_msg=str((n, h, w)))
+            for k in range(4):
+                np.testing.assert_array_equal(feats[k], eng.read_feature(k, h, w), err_msg=f"feature {k} {(n, h, w)}")
+            np.testing.assert_array_equal(pipe8, eng.upscale_rgba8(px))
+            eng.set_experiment("th", "4")
+            np.testing.assert_array_equal(eng.upscale_f32(x), first32, err_msg="tile height 4 vs 8")
+            eng.set_experiment("th", "")
+            eng.set_experiment("pipe", "all")
+            if n * h * w <= 40 * 70 * 2:
+                assert np.abs(pipe32 - oracle.forward(params["imagenet"], x)).max() < TIGHT
+    finally:
+        for key in ("th", "pipe", "bw"):
+            eng.set_experiment(key, "" if key != "pipe" else "all")
 
 
 def test_bilinear_and_downsample_graphs(params):

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from conftest import ROOT, synth_u8
-from rusty_sr_amd.shard import BandExchange, round_robin, split_rows, upscale_sharded
+from rusty_sr_amd.shard import BandExchange, round_robin, split_rows, upscale_batch_round_robin, upscale_sharded
 
 
 def test_split_rows_and_round_robin():
@@ -81,3 +81,68 @@ def test_sharded_equals_unsharded_gloo(tmp_path, params, world, h):
     got = torch.cat([torch.load(os.path.join(tmp_path, f"out{r}.pt")) for r in range(world)]).numpy()
     want = oracle.forward(params["imagenet"], oracle.img_to_data(synth_u8(21, 1, h, w)))[0]
     np.testing.assert_array_equal(got, want)  # bit-identical, SURVEY.md 8(e)
+
+
+# ---- config D (BASELINE configs[4]): a batch dealt one image per rank round-robin, no communication ----------------
+def _worker_batch(rank, world, port, n, h, w, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with open(os.path.join(ROOT, "rusty_sr_amd", "res", "imagenet.rsr"), "rb") as f:
+            params = oracle.rsr_decode(f.read())
+        batch = oracle.img_to_data(synth_u8(4, n, h, w))  # seed 4 = SURVEY.md 8(d) config D
+        calls = []
+        def compute(stack):
+            calls.append(stack.shape[0])
+            return oracle.forward(params, stack)
+        idx, outs = upscale_batch_round_robin(batch, rank, world, compute)
+        assert idx == list(range(rank, n, world)) and calls == [len(idx)] and outs.shape[0] == len(idx)
+        idx2, full = upscale_batch_round_robin(batch, rank, world, compute, gather=True)
+        if rank == 0:
+            np.save(os.path.join(tmp, "full.npy"), full)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 5), (3, 7)])
+def test_batch_round_robin_equals_single_rank_gloo(tmp_path, params, world, n):
+    h, w = 12, 20
+    mp.spawn(_worker_batch, args=(world, _free_port(), n, h, w, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, "full.npy"))
+    want = oracle.forward(params["imagenet"], oracle.img_to_data(synth_u8(4, n, h, w)))
+    np.testing.assert_array_equal(got, want)  # the dealt batch IS the single-rank batch, image for image
+
+
+def test_batch_round_robin_more_ranks_than_images():
+    idx, outs = upscale_batch_round_robin(np.zeros((2, 4, 4, 3), np.float32), 3, 8, lambda s: s)
+    assert idx == [] and outs is None
+
+
+# ---- config C's actual geometry: 3840x2160 over 8 ranks = 270-row bands with 7-row halos (width cut down) ------------
+def _worker_c(rank, world, port, h, w, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with open(os.path.join(ROOT, "rusty_sr_amd", "res", "imagenet.rsr"), "rb") as f:
+            params = oracle.rsr_decode(f.read())
+        x = torch.from_numpy(oracle.img_to_data(synth_u8(3, 1, h, w)[0]))  # seed 3 = config C
+        a, b = split_rows(h, world)[rank]
+        out = upscale_sharded(x[a:b], rank, world, _oracle_band(params))
+        torch.save(out, os.path.join(tmp, f"out{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config_c_band_geometry_gloo(tmp_path, params):
+    """Ranks 3 and 4 of the 8-way split of 2160 rows (two interior 270-row bands side by side), as a 2-rank job on
+    the 554 rows they can see: each band's output equals the same rows of the undivided image."""
+    world, w = 2, 16
+    bands = split_rows(2160, 8)
+    assert bands[3] == (810, 1080) and bands[4] == (1080, 1350)
+    h = 540
+    mp.spawn(_worker_c, args=(world, _free_port(), h, w, str(tmp_path)), nprocs=world, join=True)
+    got = torch.cat([torch.load(os.path.join(tmp_path, f"out{r}.pt")) for r in range(world)]).numpy()
+    want = oracle.forward(params["imagenet"], oracle.img_to_data(synth_u8(3, 1, h, w)))[0]
+    np.testing.assert_array_equal(got, want)
