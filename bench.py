@@ -11,14 +11,22 @@ One "step" = one pass of the whole conv stack over one image resident in HBM
 (u8 RGB in -> u8 RGBA out by default, i.e. img_to_data + graph.forward +
 data_to_img fused; --io f32 times the f32-in / f32-out form).
 
-Workload at N=1: 1920x1080 RGB (BASELINE.json configs[2], the configuration
+Workload of `value` at N=1: 1920x1080 RGB (BASELINE.json configs[2], the configuration
 north_star quotes its target on), x3 upscale with the bundled imagenet.rsr.
 BASELINE.json says "4x"; the reference is hard-wired to factor 3
 (main.rs:31) and its weights only fit factor 3, so every number here is x3.
+The other named configurations ride along as keyed entries of the same JSON line:
+  config_A  256x256                       (N=1)
+  config_C  3840x2160: at N=1 the whole image on one GPU; at N>1 STRONG scaling -- N row bands
+            (2160/N rows each), 7-row halo exchange inside the timed region, per-rank roofline fraction
+  config_D  64 x 512x512: image i on rank i mod N, no communication; device-resident and host-pipelined
+            (H2D / kernels / D2H overlapped) rates
 
-N>1 (weak scaling): the image grows to 1920 x (1080*N); rank r owns row band r,
+`value` at N>1 (weak scaling): the image grows to 1920 x (1080*N); rank r owns row band r,
 exchanges 7-row halos with its neighbours over RCCL each step (inside the timed
 region) and writes its own output rows.  value = all output pixels / max-rank time.
+The exchange is libsrhip's own RCCL communicator (sr_comm_init_rank / sr_upscale_sharded_*_dev: what a
+Rust host calls); torch.distributed only carries the 128-byte id, the barrier and the max-over-ranks.
 """
 import argparse
 import json
@@ -44,18 +52,20 @@ FLOP_PER_PX = 2 * sum(MAC_PER_PX.values())  # 260352
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA (not the 2:1-sparse headline)
 PEAK_HBM_GBPS = 8000.0
+MARGIN = (5, 3, 2, 1, 0)  # extra rows stage s computes either side of a band (what later stages read)
 
 
-def synth_u8(seed, h, w):
-    """SURVEY.md 8(d): seeded u8 noise, 5x5 box-smoothed (edge clamped, sum // 25)."""
+def synth_u8(seed, h, w, n=None):
+    """SURVEY.md 8(d): seeded u8 noise, 5x5 box-smoothed (edge clamped, sum // 25).  n: a batch (n,h,w,3)."""
     rng = np.random.default_rng(seed)
-    a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8).astype(np.int32)
-    p = np.pad(a, ((2, 2), (2, 2), (0, 0)), mode="edge")
+    a = rng.integers(0, 256, ((n or 1), h, w, 3), dtype=np.uint8).astype(np.int32)
+    p = np.pad(a, ((0, 0), (2, 2), (2, 2), (0, 0)), mode="edge")
     s = np.zeros_like(a)
     for dy in range(5):
         for dx in range(5):
-            s += p[dy:dy + h, dx:dx + w, :]
-    return (s // 25).astype(np.uint8)
+            s += p[:, dy:dy + h, dx:dx + w, :]
+    s = (s // 25).astype(np.uint8)
+    return s if n else s[0]
 
 
 STAGE_SHAPE = {1: (1, 5), 2: (2, 5), 3: (3, 5), 4: (3, 3)}  # stage -> (sources, first kernel size)
@@ -78,30 +88,53 @@ def kernel_matches(name, stage, precision):
     return False
 
 
-def pmc_traffic(stage, H, W, precision="f32"):
-    """HBM bytes per launch of the stage kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_latest.json = scripts/profile.sh of this same command; FETCH_SIZE x2
-    gfx950 correction + WRITE_SIZE, collected in separate passes).  Only valid for the
-    workload it was measured on (1920x1080); null otherwise."""
+def _profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def pmc_entry(stage, H, W, precision):
+    """The committed rocprofv3 record of one stage kernel on the headline workload (profiles/pmc_latest.json =
+    scripts/profile.sh of this same command: kernel-trace durations incl. the median, and the PMC passes --
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, collected in separate runs).  Only valid for 1920x1080."""
     if (H, W) != (1080, 1920):
         return None
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        names = [n for n in d if kernel_matches(n, stage, precision) and "hbm_read_bytes" in d[n]]
-        names.sort(key=lambda n: 0 if "pipe" in n else 1)  # the form the engine runs at this size
-        if names:
-            v = d[names[0]]
-            return {"hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v.get("hbm_write_bytes", 0)),
-                    "algorithmic_bytes_per_launch": int(H * W * 128 * (min(stage, 3) + 1)),
-                    "source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
-    except Exception:
-        pass
-    return None
+    d = _profile_json("pmc_latest.json")
+    if not d:
+        return None
+    names = [n for n in d if kernel_matches(n, stage, precision)]
+    names.sort(key=lambda n: 0 if "pipe" in n else 1)  # the form the engine runs at this size
+    return d[names[0]] if names else None
 
 
-def cpu_baseline(params, px_u8, budget_s=12.0):
-    """Time the CPU oracle (a port of the reference semantics; the Rust reference
-    itself cannot be built here) on a bounded strip of the same workload."""
+def pmc_traffic(stage, H, W, precision="f32"):
+    v = pmc_entry(stage, H, W, precision)
+    if not v or "hbm_read_bytes" not in v:
+        return None
+    return {"hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v.get("hbm_write_bytes", 0)),
+            "algorithmic_bytes_per_launch": int(H * W * 128 * (min(stage, 3) + 1)),
+            "source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+
+
+def stage_tflops(stage, rows, W, ms):
+    return 2 * MAC_PER_PX[stage] * rows * W / (ms / 1e3) / 1e12
+
+
+def roofline_of(stage_ms, rows, W, precision):
+    """Roofline block of the dominant stage kernel from per-stage HIP-event times (ms) of one call."""
+    k = int(np.argmax(stage_ms))
+    ach = stage_tflops(k, rows[k], W, stage_ms[k])
+    peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS
+    return k, ach, peak
+
+
+def cpu_baseline(params, px_u8, budget_s=10.0):
+    """The reference's CPU path cannot be built here (Rust, un-vendored crates): two ports of it are timed on this
+    host instead, on a bounded sample of the same workload -- (a) the C oracle (a correctness oracle: fixed summation
+    order, no FMA; all threads and one thread), (b) the same graph on torch-CPU / oneDNN with all cores
+    (oracle/torch_ref.py; checked against (a) in tests/test_cpu_baseline.py).  `value` is the FASTER of the two."""
     import oracle
     h, w, _ = px_u8.shape
     cores = os.cpu_count() or 1
@@ -115,12 +148,14 @@ def cpu_baseline(params, px_u8, budget_s=12.0):
     t0 = time.perf_counter()
     oracle.forward(params, x[:rows], native=True)
     dt = time.perf_counter() - t0
-    mp = rows * w * 9 / 1e6
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    single = None
+    legs = {"c_oracle": {"value": round(rows * w * 9 / 1e6 / dt, 3), "unit": "output MP/s", "cores": cores,
+                         "sample": f"top {rows} rows of the {w}x{h} workload image, f32 in/out, second of two passes, OpenMP on {cores} "
+                                   f"threads (oracle/sr_oracle.c, gcc -O3 -march=native -ffp-contract=off); "
+                                   f"GFLOP/s={rows * w * FLOP_PER_PX / dt / 1e9:.1f}"}}
     try:  # also one thread (closest to what alumina 0.1.1 does for n = 1), on a ~4 s sample
         import ctypes
         gomp = ctypes.CDLL("libgomp.so.1")
@@ -133,16 +168,39 @@ def cpu_baseline(params, px_u8, budget_s=12.0):
             t0 = time.perf_counter()
             oracle.forward(params, x[:r1], native=True)
             d1 = time.perf_counter() - t0
-            single = {"value": round(r1 * w * 9 / 1e6 / d1, 4), "unit": "output MP/s", "cores": 1,
-                      "sample": f"top {r1} rows, one OpenMP thread; GFLOP/s={r1 * w * FLOP_PER_PX / d1 / 1e9:.2f}"}
+            legs["c_oracle_1thread"] = {"value": round(r1 * w * 9 / 1e6 / d1, 4), "unit": "output MP/s", "cores": 1,
+                                        "sample": f"top {r1} rows, one OpenMP thread; GFLOP/s={r1 * w * FLOP_PER_PX / d1 / 1e9:.2f}"}
         finally:
             gomp.omp_set_num_threads(cores)
     except Exception:
         pass
-    return {"value": round(mp / dt, 3), "unit": "output MP/s", "cores": cores, "kind": "port", "single_thread": single,
-            "sample": f"top {rows} rows of the {w}x{h} workload image, f32 in/out, second of two passes, OpenMP on {cores} threads "
-                      f"(oracle/sr_oracle.c, gcc -O3 -march=native); GFLOP/s={rows * w * FLOP_PER_PX / dt / 1e9:.1f}",
-            "cpu": model}
+    try:  # the tuned-library leg: torch-CPU conv2d (oneDNN), every core, whole frame
+        import torch
+        from oracle.torch_ref import TorchNet
+        net = TorchNet(params)
+        nthr = torch.get_num_threads()
+        net.forward(x[None, :128])
+        t0 = time.perf_counter()
+        net.forward(x[None, :256])
+        t256 = time.perf_counter() - t0
+        rows_t = int(min(h, max(256, 256 * budget_s / max(t256, 1e-6) / 3)))
+        net.forward(x[None, :rows_t])
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            net.forward(x[None, :rows_t])
+            best = min(best, time.perf_counter() - t0)
+        legs["torch_cpu"] = {"value": round(rows_t * w * 9 / 1e6 / best, 3), "unit": "output MP/s", "cores": nthr,
+                             "sample": f"top {rows_t} rows, torch {torch.__version__} CPU conv2d (oneDNN, channels_last), {nthr} threads, "
+                                       f"best of 2 after warm-up; GFLOP/s={rows_t * w * FLOP_PER_PX / best / 1e9:.1f}"}
+    except Exception as ex:
+        legs["torch_cpu"] = {"error": str(ex)[:200]}
+    best_leg = max((k for k in ("c_oracle", "torch_cpu") if "value" in legs[k]), key=lambda k: legs[k]["value"])
+    return {"value": legs[best_leg]["value"], "unit": "output MP/s", "cores": legs[best_leg]["cores"], "kind": "port",
+            "leg": best_leg, "sample": legs[best_leg]["sample"], "legs": legs, "cpu": model,
+            "single_thread": legs.get("c_oracle_1thread"),
+            "scaling_c_oracle": (round(legs["c_oracle"]["value"] / legs["c_oracle_1thread"]["value"], 1)
+                                 if "c_oracle_1thread" in legs else None)}
 
 
 def main():
@@ -161,12 +219,13 @@ def main():
                          "modes); at N=1 it is measured in the same run and reported as `other_precision`.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config_A / config_C / config_D entries")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import rusty_sr_amd as r
-    from rusty_sr_amd.shard import BandExchange
+    from rusty_sr_amd.shard import BandExchange, init_band_comm, round_robin, split_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,7 +237,8 @@ def main():
     # Rehearsal on a box with fewer GPUs than ranks (not a measurement): SRHIP_SHARE_GPU=1 folds the ranks
     # onto the devices present and SRHIP_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks per device.
     backend = os.environ.get("SRHIP_DIST_BACKEND", "nccl")
-    if os.environ.get("SRHIP_SHARE_GPU") == "1":
+    shared = os.environ.get("SRHIP_SHARE_GPU") == "1"
+    if shared:
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -190,46 +250,105 @@ def main():
             dist.init_process_group(backend)
 
     H, W = args.height, args.width
+    u8 = args.io == "rgba8"
+    dt_in = torch.uint8 if u8 else torch.float32
     params = r.rsr.builtin(args.weights)
     eng = r.Engine(params, device=local, precision=args.precision)
-    px = synth_u8(2 + rank, H, W)  # seed 2 = SURVEY.md 8(d) config B; other ranks' bands differ
-    xchg = BandExchange(H, W, 3, torch.uint8 if args.io == "rgba8" else torch.float32, dev, rank, world)
-    if args.io == "rgba8":
-        xchg.band.copy_(torch.from_numpy(px).to(dev))
-        out = torch.empty((3 * H, 3 * W, 4), dtype=torch.uint8, device=dev)
-        run = lambda ext: eng.upscale_band_rgba8_dev(ext, xchg.top, xchg.bot, out=out)
-    else:
-        xchg.band.copy_(torch.from_numpy(px).to(dev).float() / 255.0)
-        out = torch.empty((3 * H, 3 * W, 3), dtype=torch.float32, device=dev)
-        run = lambda ext: eng.upscale_band_f32_dev(ext, xchg.top, xchg.bot, out=out)
 
-    def step():
-        run(xchg.exchange())
-
-    # set-up, not steps: the first calls allocate the workspace (4 feature maps), zero its borders,
-    # upload the gather table and bring the clocks up
-    for _ in range(3):
-        step()  # includes the halo exchange, so RCCL's lazy P2P connection set-up also happens here
-    torch.cuda.synchronize()
+    # ---- how halos travel: libsrhip's own RCCL communicator (the product path), or torch.distributed P2P
+    # (rehearsals on a shared GPU / gloo, and the fallback should RCCL inside the library fail to come up)
+    exchange = "none"
+    if world > 1:
+        exchange = "torch.distributed P2P (BandExchange)"
+        if backend == "nccl" and not shared and os.environ.get("SRHIP_EXCHANGE", "lib") == "lib":
+            try:
+                init_band_comm(eng, rank, world)
+                exchange = "libsrhip RCCL communicator (sr_upscale_sharded_*_dev: grouped ncclSend/ncclRecv)"
+            except Exception as ex:  # noqa: BLE001 -- report and fall back rather than lose the run
+                exchange += f" [libsrhip communicator failed: {str(ex)[:120]}]"
+        flags = [exchange.startswith("libsrhip")]
+        allf = [None] * world
+        dist.all_gather_object(allf, flags[0])
+        if not all(allf):  # every rank must take the same path
+            if exchange.startswith("libsrhip"):
+                eng.comm_init_rank(b"", 0, 1)
+                exchange = "torch.distributed P2P (BandExchange) [another rank fell back]"
+    use_lib = exchange.startswith("libsrhip")
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
+    def timed(step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize fences; max over ranks; ms per step."""
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / steps * 1e3
+
+    class Band:
+        """This rank's row band of an image sharded over the ranks, resident in HBM, and its step function."""
+
+        def __init__(self, px_band):
+            hb, w = px_band.shape[:2]
+            self.hb, self.w = hb, w
+            src = torch.from_numpy(px_band).to(dev)
+            if not u8:
+                src = torch.from_numpy(r.img_to_data(px_band)).to(dev)
+            self.out = torch.empty((3 * hb, 3 * w, 4 if u8 else 3), dtype=dt_in, device=dev)
+            self.top = 7 if rank > 0 else 0
+            self.bot = 7 if rank < world - 1 else 0
+            if use_lib or world == 1:
+                self.band = src.contiguous()
+                self.xchg = None
+            else:
+                self.xchg = BandExchange(hb, w, 3, dt_in, dev, rank, world)
+                self.xchg.band.copy_(src)
+
+        def step(self):
+            if self.xchg is None:
+                if world == 1:
+                    (eng.upscale_rgba8_dev if u8 else eng.upscale_f32_dev)(self.band[None], out=self.out[None])
+                else:
+                    eng.upscale_sharded_dev(self.band, out=self.out)
+            else:
+                ext = self.xchg.exchange()
+                (eng.upscale_band_rgba8_dev if u8 else eng.upscale_band_f32_dev)(ext, self.top, self.bot, out=self.out)
+
+        def stage_ms(self, reps):
+            """Per-stage kernel times (HIP events on the launch stream, inside libsrhip); median over reps."""
+            eng.set_profiling(True)
+            acc, comm = [], []
+            for _ in range(reps):
+                self.step()
+                torch.cuda.synchronize()
+                acc.append(eng.last_timing()["stage_ms"])
+                comm.append(eng.last_comm_ms() if use_lib and world > 1 else 0.0)
+            eng.set_profiling(False)
+            return np.median(np.array(acc), axis=0), float(np.median(comm))
+
+        def rows(self):
+            return [min(self.hb + self.top + self.bot, self.hb + (min(m, self.top) + min(m, self.bot))) for m in MARGIN]
+
+    # ------------------------------------------------------------------ the `value` workload (weak scaling)
+    px = synth_u8(2 + rank, H, W)  # seed 2 = SURVEY.md 8(d) config B; other ranks' bands differ
+    main_band = Band(px)
+    # set-up, not steps: the first calls allocate the workspace (4 feature maps), zero its borders
+    # and bring the clocks up; with N > 1 RCCL's lazy P2P connection set-up also happens here
+    for _ in range(3):
+        main_band.step()
+    torch.cuda.synchronize()
+    ms_per_step = timed(main_band.step, args.steps, args.warmup)
     out_mp_total = world * (3 * H) * (3 * W) / 1e6
     value = out_mp_total / (ms_per_step / 1e3)
 
@@ -239,72 +358,80 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         **({"rehearsal": f"backend={backend}, ranks folded onto {torch.cuda.device_count()} device(s): not a measurement"}
-           if world > 1 and (backend != "nccl" or os.environ.get("SRHIP_SHARE_GPU") == "1") else {}),
+           if world > 1 and (backend != "nccl" or shared) else {}),
         "dtype": "f32" if args.precision == "f32" else "f16x3 split (hi/lo half pairs, f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"{W}x{H} RGB x3 upscale per GPU, {args.weights}.rsr, {args.io} in/out resident in HBM"
                                + (f"; {world} row bands of one {W}x{H * world} image, 7-row RCCL halo exchange per step"
                                   if world > 1 else ""),
                    "io": args.io, "image": [H * world, W], "factor": 3, "parallelism": f"rowband{world}",
-                   "precision": args.precision},
+                   "precision": args.precision, **({"exchange": exchange} if world > 1 else {})},
         "tflops": round(world * H * W * FLOP_PER_PX / (ms_per_step / 1e3) / 1e12, 2),
     }
 
-    if rank == 0 and not args.no_roofline:
+    stage_ms = None
+    if not args.no_roofline:
         # dominant kernel = stage 3 (l3 node: conv3 5x5 + conv6 3x3 + conv8 3x3, K = 1376);
         # per-launch duration from HIP events recorded on the launch stream around each stage.
-        eng.set_profiling(True)
-        acc = np.zeros(5)
-        reps = max(3, min(args.steps, 10))
-        for _ in range(reps):
-            run(xchg.ext)
-            torch.cuda.synchronize()
-            acc += np.array(eng.last_timing()["stage_ms"])
-        eng.set_profiling(False)
-        stage_ms = acc / reps
-        rows = [min(H + xchg.top + xchg.bot, H + 2 * m) if world > 1 else H for m in (5, 3, 2, 1, 0)]
-        k = int(np.argmax(stage_ms))
-        flops = 2 * MAC_PER_PX[k] * rows[k] * W
-        ach = flops / (stage_ms[k] / 1e3) / 1e12
-        if args.precision == "f32":
-            peak, issued = PEAK_F32_MFMA_TFLOPS, ach
-            note = "v_mfma_f32_32x32x2_f32; algorithmic FLOPs = issued FLOPs"
-        else:
-            peak, issued = PEAK_F16_MFMA_TFLOPS, 3 * ach
-            note = ("v_mfma_f32_32x32x16_f16, 3 products per algorithmic product: achieved counts ALGORITHMIC FLOPs "
-                    f"against the f16 dense peak (issued rate {issued:.1f} TFLOP/s); the ceiling of this scheme is peak/3")
-        result["roofline"] = {"bound": "mfma", "kernel": f"stage {k} (conv_stage_pipe_kernel<{STAGE_SHAPE[k][0]}, {STAGE_SHAPE[k][1]}, ...>)" if k else "conv0_kernel", "achieved": round(ach, 2),
-                              "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                              "traffic": pmc_traffic(k, H, W, args.precision),
-                              "avg_launch_ms": round(float(stage_ms[k]), 4), "note": note}
-        result["stages"] = [{"stage": s, "ms": round(float(stage_ms[s]), 4),
-                             "tflops": round(2 * MAC_PER_PX[s] * rows[s] * W / (stage_ms[s] / 1e3) / 1e12, 2)}
-                            for s in range(5)]
-        io_bytes = H * W * (3 + 36 if args.io == "rgba8" else 12 + 108)
-        result["hbm"] = {"algorithmic_GBps": round(io_bytes / (ms_per_step / 1e3) / 1e9, 2), "peak_GBps": PEAK_HBM_GBPS,
-                         "note": "compulsory image I/O only; the path is MFMA-bound (2170 FLOP/B)"}
-        result["device"] = eng.device_info()
+        stage_ms, comm_ms = main_band.stage_ms(max(3, min(args.steps, 10)))
+        rows = main_band.rows() if world > 1 else [H] * 5
+        k, ach, peak = roofline_of(stage_ms, rows, W, args.precision)
+        if rank == 0:
+            if args.precision == "f32":
+                note = "v_mfma_f32_32x32x2_f32; algorithmic FLOPs = issued FLOPs"
+            else:
+                note = ("v_mfma_f32_32x32x16_f16, 3 products per algorithmic product: achieved counts ALGORITHMIC FLOPs "
+                        f"against the f16 dense peak (issued rate {3 * ach:.1f} TFLOP/s); the ceiling of this scheme is peak/3")
+            pe = pmc_entry(k, H, W, args.precision) if world == 1 else None
+            result["roofline"] = {
+                "bound": "mfma",
+                "kernel": f"stage {k} (conv_stage_pipe_kernel<{STAGE_SHAPE[k][0]}, {STAGE_SHAPE[k][1]}, ...>)" if k else "conv0_kernel",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": pmc_traffic(k, H, W, args.precision) if world == 1 else None,
+                "avg_launch_ms": round(float(stage_ms[k]), 4),
+                "source": "hip_events (median over launches, on the launch stream, this run)",
+                "rocprof": ({"median_ms": pe.get("median_us") and round(pe["median_us"] / 1e3, 4),
+                             "avg_ms": pe.get("avg_us") and round(pe["avg_us"] / 1e3, 4),
+                             "frac_at_median": pe.get("median_us") and round(stage_tflops(k, H, W, pe["median_us"] / 1e3) / peak, 4),
+                             "mfma_util_pmc": pe.get("mfma_util") and round(pe["mfma_util"], 4),
+                             "source": "profiles/pmc_latest.json (rocprofv3 --kernel-trace of this command, committed)"}
+                            if pe else None),
+                "note": note}
+            result["stages"] = [{"stage": s, "ms": round(float(stage_ms[s]), 4), "tflops": round(stage_tflops(s, rows[s], W, stage_ms[s]), 2)}
+                                for s in range(5)]
+            if world > 1:
+                result["comm_ms"] = round(comm_ms, 4)
+            io_bytes = H * W * (3 + 36 if u8 else 12 + 108)
+            hbm = {"algorithmic_GBps": round(io_bytes / (ms_per_step / 1e3) / 1e9, 2), "peak_GBps": PEAK_HBM_GBPS,
+                   "note": "algorithmic = compulsory image I/O only; the path is MFMA-bound (2170 FLOP/B)"}
+            if world == 1:
+                ents = [pmc_entry(s, H, W, args.precision) for s in range(5)]
+                if all(e and "hbm_read_bytes" in e for e in ents):
+                    tot = sum(e["hbm_read_bytes"] + e.get("hbm_write_bytes", 0) for e in ents)
+                    hbm.update({"counter_bytes_per_call": int(tot), "counter_GBps": round(tot / (ms_per_step / 1e3) / 1e9, 1),
+                                "counter_frac_of_peak": round(tot / (ms_per_step / 1e3) / 1e9 / PEAK_HBM_GBPS, 4),
+                                "counter_source": "profiles/pmc_latest.json: FETCH_SIZE x2 + WRITE_SIZE summed over the five stage kernels"})
+            result["hbm"] = hbm
+            result["device"] = eng.device_info()
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # the other arithmetic mode on the same resident image, same number of steps
         other = "f32" if args.precision == "split_f16" else "split_f16"
         eng.set_precision(other)
         for _ in range(args.warmup):
-            step()
+            main_band.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            main_band.step()
         torch.cuda.synchronize()
         oms = (time.perf_counter() - t0) / args.steps * 1e3
-        eng.set_profiling(True)
-        run(xchg.ext); torch.cuda.synchronize()
-        ost = eng.last_timing()["stage_ms"]
-        eng.set_profiling(False)
+        ost, _ = main_band.stage_ms(3)
         eng.set_precision(args.precision)
         peak_o = PEAK_F32_MFMA_TFLOPS if other == "f32" else PEAK_F16_MFMA_TFLOPS
-        ach_o = 2 * MAC_PER_PX[3] * H * W / (ost[3] / 1e3) / 1e12
+        ach_o = stage_tflops(3, H, W, ost[3])
         result["other_precision"] = {"precision": other, "value": round((3 * H) * (3 * W) / 1e6 / (oms / 1e3), 2),
                                      "unit": "output MP/s", "ms_per_step": round(oms, 4),
+                                     "stage_ms": [round(float(v), 4) for v in ost],
                                      "stage3_tflops": round(ach_o, 2), "stage3_frac_of_peak": round(ach_o / peak_o, 4),
                                      "peak": peak_o}
 
@@ -317,8 +444,8 @@ def main():
             extra = {}
             for prec in ("f32", "split_f16"):
                 e4 = r.Engine(p4, device=local, factor=4, precision=prec)
-                xin = xchg.band.contiguous()[None]
-                fn = e4.upscale_rgba8_dev if args.io == "rgba8" else e4.upscale_f32_dev
+                xin = main_band.band.contiguous()[None]
+                fn = e4.upscale_rgba8_dev if u8 else e4.upscale_f32_dev
                 o4 = fn(xin)
                 for _ in range(3):
                     fn(xin, out=o4)
@@ -336,6 +463,135 @@ def main():
                                                   "reference); parity for this factor is against the CPU restatement only")
         except Exception as ex:  # never let the extra break the contract line
             result["x4_synthetic_weights"] = {"error": str(ex)}
+
+    # ------------------------------------------------------------------ the other named configurations
+    del main_band
+    torch.cuda.empty_cache()
+    peak_here = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
+    ksteps = max(3, min(args.steps, 10))
+    if not args.no_configs:
+        try:
+            # config C: one 3840x2160 image.  N = 1: the whole image; N > 1: strong scaling, band r on rank r.
+            HC, WC = 2160, 3840
+            a, b = split_rows(HC, world)[rank]
+            band = Band(synth_u8(3, HC, WC)[a:b])  # seed 3 = SURVEY.md 8(d) config C (every rank builds the image, keeps its rows)
+            for _ in range(2):
+                band.step()
+            torch.cuda.synchronize()
+            ms_c = timed(band.step, ksteps, 1)
+            st_c, comm_c = band.stage_ms(3)
+            rows_c = band.rows() if world > 1 else [HC] * 5
+            kc, ach_c, _ = roofline_of(st_c, rows_c, WC, args.precision)
+            mine = {"rank": rank, "rows": b - a, "stage_ms": [round(float(v), 4) for v in st_c], "comm_ms": round(comm_c, 4),
+                    "roofline_frac": round(ach_c / peak_here, 4), "dominant_stage": kc}
+            per_rank = [mine]
+            if world > 1:
+                per_rank = [None] * world
+                dist.all_gather_object(per_rank, mine)
+            if rank == 0:
+                result["config_C"] = {
+                    "workload": f"3840x2160 RGB x3, {args.io}, resident in HBM" + (f", {world} row bands of {HC // world} rows + 7-row halos "
+                                f"(strong scaling; exchange: {exchange})" if world > 1 else ", one GPU"),
+                    "value": round(9 * HC * WC / 1e6 / (ms_c / 1e3), 2), "unit": "output MP/s", "ms_per_step": round(ms_c, 4),
+                    "scaling": "strong", "steps": ksteps, "recompute_overhead": round(sum(p["rows"] + 14 for p in per_rank) / HC - 1, 4) if world > 1 else 0.0,
+                    "roofline_frac_per_rank": [p["roofline_frac"] for p in per_rank], "per_rank": per_rank}
+            del band
+            torch.cuda.empty_cache()
+        except Exception as ex:  # noqa: BLE001
+            if rank == 0:
+                result["config_C"] = {"error": str(ex)[:300]}
+
+        try:
+            # config D: 64 x 512x512, image i -> rank i mod N (shard.round_robin), weights replicated, no communication
+            ND, HD, WD = 64, 512, 512
+            idx = round_robin(ND, rank, world)
+            batch = synth_u8(4, HD, WD, n=ND)[idx]  # seed 4 = SURVEY.md 8(d) config D
+            xin = torch.from_numpy(batch).to(dev) if u8 else torch.from_numpy(r.img_to_data(batch)).to(dev)
+            outd = torch.empty((len(idx), 3 * HD, 3 * WD, 4 if u8 else 3), dtype=dt_in, device=dev)
+            fn = eng.upscale_rgba8_dev if u8 else eng.upscale_f32_dev
+            step_d = (lambda: fn(xin, out=outd)) if idx else (lambda: None)
+            for _ in range(2):
+                step_d()
+            torch.cuda.synchronize()
+            ms_d = timed(step_d, ksteps, 1)
+            entry = {"workload": f"64 x 512x512 RGB x3, image i on rank i mod {world}, {args.io}",
+                     "value": round(ND * 9 * HD * WD / 1e6 / (ms_d / 1e3), 2), "unit": "output MP/s", "ms_per_step": round(ms_d, 4),
+                     "scaling": "strong", "steps": ksteps, "images_per_rank": len(idx), "data_path_collectives": 0,
+                     "tflops": round(ND * HD * WD * FLOP_PER_PX / (ms_d / 1e3) / 1e12, 2)}
+            del outd
+            # ... and from / to host memory: upload, kernels and download overlapped in chunks of 4 images (sr_upscale_rgba8)
+            if u8 and idx:
+                from rusty_sr_amd.engine import host_alloc
+                pin_in, pin_out = host_alloc(batch.shape), host_alloc((len(idx), 3 * HD, 3 * WD, 4))
+                pin_in.array[...] = batch
+                step_h = lambda: eng.upscale_rgba8(pin_in.array, out=pin_out.array)
+                step_h()
+                ms_h = timed(step_h, max(2, ksteps // 2), 1)
+                t = eng.last_timing()
+                entry["host_pipelined"] = {"value": round(ND * 9 * HD * WD / 1e6 / (ms_h / 1e3), 2), "unit": "output MP/s",
+                                           "ms_per_step": round(ms_h, 4), "kernel_ms": round(t["total_ms"], 4),
+                                           "h2d_ms": round(t["h2d_ms"], 4), "d2h_ms": round(t["d2h_ms"], 4),
+                                           "note": "page-locked host buffers, PCIe-inclusive: never `value`"}
+                pin_in.close(); pin_out.close()
+            elif u8 and world > 1:
+                timed(lambda: None, max(2, ksteps // 2), 1)  # keep the collective sequence of the timing helper in step
+            if rank == 0:
+                result["config_D"] = entry
+            del xin
+            torch.cuda.empty_cache()
+        except Exception as ex:  # noqa: BLE001
+            if rank == 0:
+                result["config_D"] = {"error": str(ex)[:300]}
+
+        if world == 1:
+            try:
+                # config A: 256x256, one GPU (4-row tiles, first form of the stage kernels: one round of workgroups)
+                pa = torch.from_numpy(synth_u8(1, 256, 256)).to(dev)[None]  # seed 1 = config A
+                xa = pa if u8 else torch.from_numpy(r.img_to_data(pa.cpu().numpy())).to(dev)
+                fn = eng.upscale_rgba8_dev if u8 else eng.upscale_f32_dev
+                oa = fn(xa)
+                for _ in range(5):
+                    fn(xa, out=oa)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    fn(xa, out=oa)
+                torch.cuda.synchronize()
+                ms_a = (time.perf_counter() - t0) / 50 * 1e3
+                eng.set_profiling(True)
+                sa = []
+                for _ in range(5):
+                    fn(xa, out=oa); torch.cuda.synchronize(); sa.append(eng.last_timing()["stage_ms"])
+                eng.set_profiling(False)
+                sa = np.median(np.array(sa), axis=0)
+                ka, ach_a, _ = roofline_of(sa, [256] * 5, 256, args.precision)
+                result["config_A"] = {"workload": f"256x256 RGB x3, {args.io}, one GPU", "value": round(9 * 65536 / 1e6 / (ms_a / 1e3), 2),
+                                      "unit": "output MP/s", "ms_per_step": round(ms_a, 4), "stage_ms": [round(float(v), 4) for v in sa],
+                                      "roofline_frac": round(ach_a / peak_here, 4), "whole_call_frac": round(65536 * FLOP_PER_PX / (ms_a / 1e3) / 1e12 / peak_here, 4)}
+            except Exception as ex:  # noqa: BLE001
+                result["config_A"] = {"error": str(ex)[:300]}
+
+            try:
+                # what the drop-in user runs: host pointers in and out (sr_upscale_rgba8), 1080p, page-locked buffers
+                if u8:
+                    from rusty_sr_amd.engine import host_alloc
+                    pin_in, pin_out = host_alloc((H, W, 3)), host_alloc((3 * H, 3 * W, 4))
+                    pin_in.array[...] = px
+                    call = lambda: eng.upscale_rgba8(pin_in.array, out=pin_out.array)
+                    for _ in range(3):
+                        call()
+                    t0 = time.perf_counter()
+                    for _ in range(ksteps):
+                        call()
+                    ms_h = (time.perf_counter() - t0) / ksteps * 1e3
+                    t = eng.last_timing()
+                    result["host_call"] = {"workload": f"{W}x{H} u8 RGB in host memory -> RGBA8 in host memory (sr_upscale_rgba8), page-locked",
+                                           "t_e2e_device_ms": round(ms_h, 4), "value": round(9 * H * W / 1e6 / (ms_h / 1e3), 2), "unit": "output MP/s",
+                                           "t_kernel_ms": round(t["total_ms"], 4), "h2d_ms": round(t["h2d_ms"], 4), "d2h_ms": round(t["d2h_ms"], 4),
+                                           "note": "PCIe-inclusive (6.2 MB up, 74.6 MB down): never `value`"}
+                    pin_in.close(); pin_out.close()
+            except Exception as ex:  # noqa: BLE001
+                result["host_call"] = {"error": str(ex)[:300]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(params, px)

@@ -35,10 +35,22 @@ SEGMENTS = {
 _lib = None
 
 
+def _cpu_tag():
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            lines = [l for l in f if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        lines = []
+    return hashlib.sha1("".join(lines).encode()).hexdigest()[:10]
+
+
 def build(native=False, force=False):
     """Compile the oracle with gcc.  native=True builds a -march=native copy
     (used for the cpu_baseline timing on the GPU box's host CPU)."""
-    name = "libsr_oracle_native.so" if native else "libsr_oracle.so"
+    # the -march=native copy is only valid on the CPU it was built on: key its name on the host's CPU model so a copy
+    # built in one container is never loaded on another machine (the GPU box rebuilds its own on first use)
+    name = f"libsr_oracle_native_{_cpu_tag()}.so" if native else "libsr_oracle.so"
     out = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "sr_oracle.c")
     if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):

@@ -48,7 +48,8 @@ struct ParamLayout {
 };
 
 constexpr int kChunk = 1024;  // floats per tap chunk (32 cin x 32 cout)
-constexpr int kAutoBlockWidth = 0;  // default tile order of the stage kernels (StageArgs::bw); SRHIP_BW / sr_set_experiment("bw") override
+constexpr int kAutoBlockWidth = 16;  // default tile order of the stage kernels (StageArgs::bw): 16-tile (512 px) column blocks;
+                                     // measured 1080p / 4K, both modes (scripts/bw_exp.py): 0-3 % faster than row-major, 8..32 alike
 
 // w = hi + lo/2048 with hi, lo halves (see split_half in sr_kernels.hip)
 void split_half_host(float v, _Float16& hi, _Float16& lo) {

@@ -17,6 +17,19 @@ print("== kernel-trace --stats (per launch) ==")
 for name, calls, us, pct in sorted(rows, key=lambda r: -r[3]):
     print(f"{name:70s} calls={calls:4d} avg={us:10.1f} us  {pct:5.1f}%")
 
+# per-dispatch durations -> median / min per kernel (the --stats table only has the average, which a few slow
+# launches -- clock ramp, first touch -- pull up)
+import statistics
+durs = defaultdict(list)
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "conv" in r.get("Kernel_Name", ""):
+            durs[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("\n== kernel-trace, per-dispatch durations ==")
+for k in sorted(durs, key=lambda k: -sum(durs[k])):
+    v = durs[k]
+    print(f"{k:70s} n={len(v):4d} median={statistics.median(v):10.1f} us  min={min(v):10.1f}  max={max(v):10.1f}")
+
 agg = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -44,6 +57,11 @@ js = {}
 for name, calls, us, pct in rows:
     js.setdefault(name, {})["avg_us"] = us
     js[name]["calls"] = calls
+for k, v in durs.items():
+    d = js.setdefault(k, {})
+    d["median_us"] = statistics.median(v)
+    d["min_us"] = min(v)
+    d["max_us"] = max(v)
 for k in agg:
     c = {cn: sum(v) / len(v) for cn, v in agg[k].items()}
     d = js.setdefault(k, {})

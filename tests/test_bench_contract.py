@@ -32,8 +32,15 @@ def test_bench_single_gpu_contract():
     assert abs(d["value"] - 9 * 360 * 640 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["source"].startswith("hip_events")
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["leg"] in cb["legs"] and cb["value"] == max(cb["legs"][k]["value"] for k in ("c_oracle", "torch_cpu") if "value" in cb["legs"][k])
+    # the other named configurations ride along as keyed entries
+    for key in ("config_A", "config_C", "config_D", "host_call"):
+        assert key in d and "error" not in d[key], (key, d.get(key))
+    assert d["config_C"]["scaling"] == "strong" and len(d["config_C"]["roofline_frac_per_rank"]) == 1
+    assert d["config_D"]["images_per_rank"] == 64 and d["config_D"]["data_path_collectives"] == 0 and "host_pipelined" in d["config_D"]
 
 
 def test_bench_two_rank_rehearsal():
@@ -47,3 +54,9 @@ def test_bench_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "rowband2" and "rehearsal" in d
     assert d["config"]["image"] == [720, 640]
     assert abs(d["value"] - 2 * 9 * 360 * 640 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
+    c, dd = d["config_C"], d["config_D"]
+    assert "error" not in c and "error" not in dd, (c, dd)
+    assert c["scaling"] == "strong" and len(c["roofline_frac_per_rank"]) == 2 and [p["rows"] for p in c["per_rank"]] == [1080, 1080]
+    assert abs(c["value"] - 9 * 2160 * 3840 / 1e6 / (c["ms_per_step"] / 1e3)) / c["value"] < 1e-3
+    assert dd["images_per_rank"] == 32 and dd["data_path_collectives"] == 0
+    assert abs(dd["value"] - 64 * 9 * 512 * 512 / 1e6 / (dd["ms_per_step"] / 1e3)) / dd["value"] < 1e-3

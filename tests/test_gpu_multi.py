@@ -68,7 +68,7 @@ def test_split_mode_is_as_close_to_exact_arithmetic_as_the_f32_cpu_path(params):
             cpu = oracle.forward(params["imagenet"], crop)[0][21:-21, 21:-21]
             worst["cpu"] = max(worst["cpu"], float(np.abs(cpu - truth).max()))
             for p in engs:
-                got = full[p][0][3 * (y + 7):3 * (y + 135), 3 * (x + 7):3 * (x + 135)]
+                got = full[p][3 * (y + 7):3 * (y + 135), 3 * (x + 7):3 * (x + 135)]
                 worst[p] = max(worst[p], float(np.abs(got - truth).max()))
         assert worst["split_f16"] <= 2 * worst["cpu"] + 1e-7, worst
         assert worst["f32"] <= 2 * worst["cpu"] + 1e-7, worst
