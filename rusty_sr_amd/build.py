@@ -75,6 +75,27 @@ def build_host(force=False, verbose=False):
     return CLI
 
 
+FUZZ = os.path.join(HERE, "bin", "srcodec_asan")
+
+
+def build_sanitized(force=False, verbose=False):
+    """g++ -fsanitize=address,undefined -> rusty_sr_amd/bin/srcodec_asan: the hand-written PNG / JPEG / PNM / BMP
+    decoders under AddressSanitizer + UBSan, driven by tests/test_decoder_robustness.py with truncated and
+    bit-flipped files."""
+    srcs = [os.path.join(HOST, f) for f in ("fuzz_main.cpp", "png.cpp", "jpeg.cpp")]
+    deps = srcs + [os.path.join(HOST, "png.hpp")]
+    if not force and os.path.exists(FUZZ) and all(os.path.getmtime(d) <= os.path.getmtime(FUZZ) for d in deps):
+        return FUZZ
+    os.makedirs(os.path.dirname(FUZZ), exist_ok=True)
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-fno-omit-frame-pointer", *srcs, "-lz", "-o", FUZZ]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return FUZZ
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
     print(build_host(force=True, verbose=True))
+    print(build_sanitized(force=True, verbose=True))

@@ -146,6 +146,9 @@ bool decode_jpeg_memory(const uint8_t* d, size_t len, Image& out, std::string& e
             if (n < 6 || s[0] != 8) { err = "only 8-bit JPEG is supported"; return false; }
             H = s[1] << 8 | s[2]; W = s[3] << 8 | s[4]; ncomp = s[5];
             if (W <= 0 || H <= 0 || (ncomp != 1 && ncomp != 3) || n < 6 + (size_t)3 * ncomp) { err = "unsupported JPEG frame"; return false; }
+            // an 8x8 block costs at least 2 bits of entropy-coded data per component: a frame header that promises more
+            // pixels than the file could possibly hold is refused before its planes are allocated (also caps at 2^28 px)
+            if ((uint64_t)W * (uint64_t)H > ((uint64_t)1 << 28) || (uint64_t)W * (uint64_t)H / 256 > (uint64_t)len + 64) { err = "JPEG dimensions do not fit the file"; return false; }
             for (int i = 0; i < ncomp; ++i) { comp[i].id = s[6 + 3 * i]; comp[i].h = s[7 + 3 * i] >> 4; comp[i].v = s[7 + 3 * i] & 15; comp[i].tq = s[8 + 3 * i] & 3;
                 if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4) { err = "bad JPEG sampling factors"; return false; } }
             have_sof = true;

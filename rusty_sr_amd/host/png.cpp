@@ -7,10 +7,15 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <climits>
+#include <exception>
 #include <thread>
 
 namespace srpng {
 namespace {
+// Largest image any decoder here will allocate for: 2^28 px = 1 GiB of RGBA8 (16384 x 16384).  The reference's
+// `image` crate has comparable built-in limits; without one a 30-byte header can ask for terabytes.
+constexpr uint64_t kMaxPixels = (uint64_t)1 << 28;
 
 uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | p[1] << 16 | p[2] << 8 | p[3]; }
 void put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
@@ -111,10 +116,12 @@ bool decode_memory(const uint8_t* p, size_t len, Image& out, std::string& err) {
         pos += 12 + (size_t)n;
     }
     if (!have_hdr || H.w <= 0 || H.h <= 0 || idat.empty()) { err = "PNG has no image data"; return false; }
+    if ((uint64_t)H.w * (uint64_t)H.h > kMaxPixels) { err = "PNG dimensions too large"; return false; }
     const bool depth_ok = H.depth == 8 || H.depth == 16 || ((H.ctype == 0 || H.ctype == 3) && (H.depth == 1 || H.depth == 2 || H.depth == 4));
     if (!depth_ok || (H.ctype != 0 && H.ctype != 2 && H.ctype != 3 && H.ctype != 4 && H.ctype != 6) || (H.ctype == 3 && H.depth == 16)) {
         err = "unsupported PNG colour type / bit depth"; return false;
     }
+    if (H.ctype == 3 && (plte.empty() || plte.size() % 3 != 0 || plte.size() > 768)) { err = "PNG palette missing or malformed"; return false; }
     const int bits_pp = channels_of(H.ctype) * H.depth, bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
     auto stride_of = [&](int w) { return ((size_t)w * bits_pp + 7) / 8; };
     // pass geometry: non-interlaced = one pass; Adam7 = seven
@@ -127,6 +134,9 @@ bool decode_memory(const uint8_t* p, size_t len, Image& out, std::string& err) {
         ph[k] = H.interlace ? (H.h - ys[k] + dys[k] - 1) / dys[k] : H.h;
         if (pw[k] > 0 && ph[k] > 0) raw_len += (size_t)ph[k] * (stride_of(pw[k]) + 1);
     }
+    // deflate cannot expand more than ~1032:1: a header that promises more than the IDAT data can hold is refused
+    // BEFORE anything of that size is allocated
+    if (raw_len / 1032 > idat.size() + 16) { err = "PNG inflate failed"; return false; }
     std::vector<uint8_t> raw(raw_len);
     uLongf got = (uLongf)raw_len;
     const int zr = uncompress(raw.data(), &got, idat.data(), (uLong)idat.size());
@@ -180,6 +190,13 @@ static bool decode_pnm(const uint8_t* d, size_t len, Image& out, std::string& er
     long w = 0, h = 0, maxv = 1;
     if (!next_int(w) || !next_int(h) || (!bitmap && !next_int(maxv))) { err = "bad PNM header"; return false; }
     if (w <= 0 || h <= 0 || w > (1 << 20) || h > (1 << 20) || maxv <= 0 || maxv > 65535) { err = "bad PNM header"; return false; }
+    if ((uint64_t)w * (uint64_t)h > kMaxPixels) { err = "PNM dimensions too large"; return false; }
+    {   // the samples must be there before the output is allocated: plain files need >= 1 byte per sample (P1) or 2
+        const uint64_t samples = (uint64_t)w * h * ch, left = len - std::min(pos, len);
+        const uint64_t need = plain ? (bitmap ? samples : samples * 2 - 1) : bitmap ? ((uint64_t)(w + 7) / 8) * h
+                                                                                   : samples * (maxv > 255 ? 2 : 1);
+        if (need > left) { err = "truncated PNM"; return false; }
+    }
     out.w = (int)w; out.h = (int)h;
     out.rgba.assign((size_t)w * h * 4, 255);
     auto put = [&](size_t p, int c, long v) {
@@ -225,10 +242,12 @@ static bool decode_bmp(const uint8_t* d, size_t len, Image& out, std::string& er
     const uint32_t off = le32(10), hdr = le32(14), comp = le32(30);
     const int32_t w = (int32_t)le32(18), hs = (int32_t)le32(22);
     const int bpp = d[28] | d[29] << 8;
+    if (hs == INT32_MIN) { err = "unsupported BMP (only uncompressed 1/4/8/24/32-bit)"; return false; }
     const int h = hs < 0 ? -hs : hs;
     const bool pal = bpp == 1 || bpp == 4 || bpp == 8;
     if (hdr < 40 || w <= 0 || h <= 0 || w > (1 << 20) || h > (1 << 20) || !(pal || bpp == 24 || bpp == 32) ||
         (comp != 0 && !(comp == 3 && bpp == 32))) { err = "unsupported BMP (only uncompressed 1/4/8/24/32-bit)"; return false; }
+    if ((uint64_t)w * (uint64_t)h > kMaxPixels) { err = "BMP dimensions too large"; return false; }
     const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
     uint32_t ncol = pal ? le32(46) : 0;
     if (pal && (ncol == 0 || ncol > (1u << bpp))) ncol = 1u << bpp;
@@ -252,9 +271,21 @@ static bool decode_bmp(const uint8_t* d, size_t len, Image& out, std::string& er
     return true;
 }
 
+static bool decode_any_memory(const std::vector<uint8_t>& buf, Image& out, std::string& err);
+
 bool decode_image_file(const std::string& path, Image& out, std::string& err) {
     std::vector<uint8_t> buf;
     if (!read_all(path, buf, err)) return false;
+    try {  // backstop: whatever a hostile header makes a container ask for, the caller gets an error, not a terminate()
+        return decode_any_memory(buf, out, err);
+    } catch (const std::exception& e) {
+        err = std::string("image too large or corrupt (") + e.what() + ")";
+        out = Image();
+        return false;
+    }
+}
+
+static bool decode_any_memory(const std::vector<uint8_t>& buf, Image& out, std::string& err) {
     if (buf.size() >= 8 && buf[0] == 0x89 && buf[1] == 'P') return decode_memory(buf.data(), buf.size(), out, err);
     if (buf.size() >= 4 && buf[0] == 0xff && buf[1] == 0xd8) return decode_jpeg_memory(buf.data(), buf.size(), out, err);
     if (buf.size() >= 7 && buf[0] == 'P' && buf[1] >= '1' && buf[1] <= '6' && isspace(buf[2])) return decode_pnm(buf.data(), buf.size(), out, err);

@@ -1,0 +1,174 @@
+"""The hand-written decoders of the host CLI (rusty_sr_amd/host/png.cpp, jpeg.cpp: the stand-ins for `image::open`,
+reference main.rs:164) parse untrusted files.  They are built under AddressSanitizer + UBSan
+(rusty_sr_amd/bin/srcodec_asan) and fed truncated, bit-flipped and chunk-mangled variants of the seven reference PNGs
+and of JPEG / PNM / BMP files: every file must end in "ok WxH" or a clean "error: ..." line -- the counterpart of the
+reference's `.expect("Error opening input image file.")` -- never in a sanitizer report, crash, hang or huge
+allocation."""
+import io
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope="module")
+def harness():
+    from rusty_sr_amd.build import build_sanitized
+    return build_sanitized()
+
+
+def _run(harness, paths, timeout=300):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=1:max_allocation_size_mb=2048",
+               UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([harness, *map(str, paths)], capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, f"sanitizer / crash (rc {r.returncode}):\n{r.stderr[-3000:]}"
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(paths)
+    assert all(l.startswith("ok ") or l.startswith("error: ") for l in lines), lines
+    return lines
+
+
+def _seed_files(tmp):
+    """name -> bytes: the reference PNGs plus generated files of every container the CLI accepts."""
+    from PIL import Image
+    seeds = {}
+    for name in sorted(os.listdir(GOLDEN)):
+        if name.endswith(".png"):
+            seeds[name] = open(os.path.join(GOLDEN, name), "rb").read()
+    rng = np.random.default_rng(7)
+    img = Image.fromarray(rng.integers(0, 256, (37, 53, 3), dtype=np.uint8))
+    for tag, kw in (("q90_444.jpg", dict(quality=90, subsampling=0)), ("q60_420.jpg", dict(quality=60, subsampling=2)),
+                    ("q75_422_rst.jpg", dict(quality=75, subsampling=1)), ("prog.jpg", dict(quality=80, progressive=True))):
+        b = io.BytesIO(); img.save(b, "JPEG", **kw); seeds[tag] = b.getvalue()
+    b = io.BytesIO(); img.convert("L").save(b, "JPEG", quality=85); seeds["grey.jpg"] = b.getvalue()
+    for mode, tag in (("P", "pal.png"), ("LA", "la.png"), ("I;16", "g16.png"), ("1", "bw.png")):
+        b = io.BytesIO()
+        (img.convert("L").convert(mode) if mode != "I;16" else Image.fromarray(rng.integers(0, 65536, (9, 11), dtype=np.uint16))).save(b, "PNG")
+        seeds[tag] = b.getvalue()
+    b = io.BytesIO(); img.save(b, "PNG", interlace=1); seeds["adam7.png"] = b.getvalue()
+    b = io.BytesIO(); img.save(b, "PPM"); seeds["rgb.ppm"] = b.getvalue()
+    b = io.BytesIO(); img.save(b, "BMP"); seeds["rgb.bmp"] = b.getvalue()
+    return seeds
+
+
+def test_intact_files_decode(harness, tmp_path):
+    seeds = _seed_files(tmp_path)
+    paths = []
+    for name, data in seeds.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        paths.append(p)
+    lines = dict(zip(seeds, _run(harness, paths)))
+    for name, line in lines.items():
+        if name == "prog.jpg":
+            assert line.startswith("error: progressive JPEG"), line  # refused by name, not mis-decoded
+        else:
+            assert line.startswith("ok "), (name, line)
+
+
+def test_truncated_and_bit_flipped_files_fail_cleanly(harness, tmp_path):
+    seeds = _seed_files(tmp_path)
+    rng = np.random.default_rng(11)
+    paths = []
+    for name, data in seeds.items():
+        stem, ext = os.path.splitext(name)
+        cuts = sorted({0, 1, 7, 8, 20, 33, 40, len(data) // 3, len(data) // 2, len(data) - 9, len(data) - 1} |
+                      {int(c) for c in rng.integers(0, len(data), 6)})
+        for c in cuts:
+            if 0 <= c < len(data):
+                p = tmp_path / f"{stem}_cut{c}{ext}"; p.write_bytes(data[:c]); paths.append(p)
+        for k in range(40):  # random bit flips, biased towards the headers
+            b = bytearray(data)
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(0, min(len(b), 200))) if k % 2 == 0 else int(rng.integers(0, len(b)))
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+            p = tmp_path / f"{stem}_flip{k}{ext}"; p.write_bytes(bytes(b)); paths.append(p)
+        for k in range(6):  # a run of random bytes somewhere in the middle
+            b = bytearray(data)
+            pos = int(rng.integers(0, max(1, len(b) - 16)))
+            b[pos:pos + 16] = rng.integers(0, 256, 16, dtype=np.uint8).tobytes()
+            p = tmp_path / f"{stem}_junk{k}{ext}"; p.write_bytes(bytes(b)); paths.append(p)
+    assert len(paths) > 800
+    for i in range(0, len(paths), 200):
+        _run(harness, paths[i:i + 200])
+
+
+def _png_chunk(t, d):
+    return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+
+
+def test_hostile_png_headers(harness, tmp_path):
+    """Well-formed chunks with hostile contents: absurd dimensions (must not allocate terabytes), zero sizes, bad
+    bit depth / colour type combinations, IDAT shorter or longer than the header promises, palette index out of
+    range, missing IEND, chunk length running past the end of the file."""
+    sig = b"\x89PNG\r\n\x1a\n"
+    def ihdr(w, h, depth=8, ct=6, il=0):
+        return _png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ct, 0, 0, il))
+    raw = lambda w, h, bpp: zlib.compress(b"".join(b"\x00" + bytes(w * bpp) for _ in range(h)))
+    cases = {
+        "huge": sig + ihdr(0x7fffffff, 0x7fffffff) + _png_chunk(b"IDAT", raw(1, 1, 4)) + _png_chunk(b"IEND", b""),
+        "wide": sig + ihdr(0x40000000, 1) + _png_chunk(b"IDAT", raw(1, 1, 4)) + _png_chunk(b"IEND", b""),
+        "zero_w": sig + ihdr(0, 5) + _png_chunk(b"IDAT", raw(1, 1, 4)) + _png_chunk(b"IEND", b""),
+        "depth3": sig + ihdr(4, 4, depth=3) + _png_chunk(b"IDAT", raw(4, 4, 4)) + _png_chunk(b"IEND", b""),
+        "ct5": sig + ihdr(4, 4, ct=5) + _png_chunk(b"IDAT", raw(4, 4, 4)) + _png_chunk(b"IEND", b""),
+        "rgb16_as_pal": sig + ihdr(4, 4, depth=16, ct=3) + _png_chunk(b"IDAT", raw(4, 4, 4)) + _png_chunk(b"IEND", b""),
+        "short_idat": sig + ihdr(16, 16) + _png_chunk(b"IDAT", raw(16, 3, 4)) + _png_chunk(b"IEND", b""),
+        "long_idat": sig + ihdr(2, 2) + _png_chunk(b"IDAT", raw(64, 64, 4)) + _png_chunk(b"IEND", b""),
+        "bad_filter": sig + ihdr(2, 2) + _png_chunk(b"IDAT", zlib.compress(b"\x09" + bytes(8) + b"\x07" + bytes(8))) + _png_chunk(b"IEND", b""),
+        "pal_oob": sig + ihdr(4, 1, ct=3) + _png_chunk(b"PLTE", bytes(6)) + _png_chunk(b"IDAT", zlib.compress(b"\x00\x00\x01\x02\xff")) + _png_chunk(b"IEND", b""),
+        "no_plte": sig + ihdr(4, 1, ct=3) + _png_chunk(b"IDAT", zlib.compress(b"\x00\x00\x01\x02\x03")) + _png_chunk(b"IEND", b""),
+        "no_iend": sig + ihdr(2, 2) + _png_chunk(b"IDAT", raw(2, 2, 4)),
+        "len_past_eof": sig + ihdr(2, 2) + struct.pack(">I", 0x7ffffff0) + b"IDAT" + b"abc",
+        "len_negative": sig + ihdr(2, 2) + struct.pack(">I", 0xfffffff0) + b"IDAT" + b"abc",
+        "adam7_tiny": sig + ihdr(1, 1, il=1) + _png_chunk(b"IDAT", raw(1, 1, 4)) + _png_chunk(b"IEND", b""),
+        "adam7_short": sig + ihdr(9, 9, il=1) + _png_chunk(b"IDAT", raw(2, 2, 4)) + _png_chunk(b"IEND", b""),
+        "not_zlib": sig + ihdr(2, 2) + _png_chunk(b"IDAT", b"this is not a deflate stream") + _png_chunk(b"IEND", b""),
+        "two_ihdr": sig + ihdr(2, 2) + ihdr(1000, 1000) + _png_chunk(b"IDAT", raw(2, 2, 4)) + _png_chunk(b"IEND", b""),
+    }
+    paths = []
+    for name, data in cases.items():
+        p = tmp_path / f"{name}.png"; p.write_bytes(data); paths.append(p)
+    lines = dict(zip(cases, _run(harness, paths)))
+    for name in ("huge", "wide", "zero_w", "depth3", "ct5", "rgb16_as_pal", "short_idat", "bad_filter", "no_plte", "len_past_eof",
+                 "len_negative", "not_zlib", "adam7_short"):
+        assert lines[name].startswith("error: "), (name, lines[name])
+
+
+def test_hostile_jpeg_and_pnm_and_bmp_headers(harness, tmp_path):
+    cases = {
+        "sof_huge.jpg": b"\xff\xd8\xff\xc0\x00\x11\x08\xff\xff\xff\xff\x03\x01\x11\x00\x02\x11\x01\x03\x11\x01\xff\xda\x00\x02",
+        "sos_first.jpg": b"\xff\xd8\xff\xda\x00\x0c\x03\x01\x00\x02\x11\x03\x11\x00\x3f\x00" + bytes(20),
+        "sos_len0.jpg": b"\xff\xd8\xff\xc0\x00\x0b\x08\x00\x08\x00\x08\x01\x01\x11\x00\xff\xda\x00\x02",
+        "seg_past_eof.jpg": b"\xff\xd8\xff\xe0\xff\xff" + bytes(10),
+        "dqt_short.jpg": b"\xff\xd8\xff\xdb\x00\x05\x00\x01\x02\xff\xd9",
+        "dht_overflow.jpg": b"\xff\xd8\xff\xc4\x00\x14\x00" + bytes([255] * 16) + b"\x00\xff\xd9",
+        "only_soi.jpg": b"\xff\xd8",
+        "p6_huge.ppm": b"P6\n2000000000 2000000000\n255\n" + bytes(12),
+        "p6_neg.ppm": b"P6\n-5 4\n255\n" + bytes(60),
+        "p6_short.ppm": b"P6\n16 16\n255\n" + bytes(30),
+        "p5_maxval0.pgm": b"P5\n2 2\n0\n" + bytes(4),
+        "p6_nodims.ppm": b"P6\n",
+        "bmp_huge.bmp": b"BM" + struct.pack("<IHHI", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 0x7fffffff, 0x7fffffff, 1, 24, 0, 0, 0, 0, 0, 0) + bytes(16),
+        "bmp_off_past.bmp": b"BM" + struct.pack("<IHHI", 70, 0, 0, 0x7ffffff0) + struct.pack("<IiiHHIIiiII", 40, 2, 2, 1, 24, 0, 0, 0, 0, 0, 0) + bytes(16),
+        "bmp_neg_w.bmp": b"BM" + struct.pack("<IHHI", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, -2, 2, 1, 24, 0, 0, 0, 0, 0, 0) + bytes(16),
+        "bmp_short.bmp": b"BM" + struct.pack("<IHHI", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 16, 16, 1, 24, 0, 0, 0, 0, 0, 0) + bytes(16),
+        "bmp_min_h.bmp": b"BM" + struct.pack("<IHHI", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 2, -2147483648, 1, 24, 0, 0, 0, 0, 0, 0) + bytes(16),
+        "empty.png": b"",
+    }
+    paths = []
+    for name, data in cases.items():
+        p = tmp_path / name; p.write_bytes(data); paths.append(p)
+    lines = dict(zip(cases, _run(harness, paths)))
+    for name, line in lines.items():
+        assert line.startswith("error: "), (name, line)
+
+
+def test_encoder_round_trip_under_sanitizers(harness, tmp_path):
+    for w, h in ((1, 1), (37, 21), (513, 300), (4096, 33)):
+        r = subprocess.run([harness, "--roundtrip", str(w), str(h), str(tmp_path / "rt.png")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.startswith("ok "), (w, h, r.stdout, r.stderr[-2000:])
