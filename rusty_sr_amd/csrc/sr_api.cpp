@@ -106,6 +106,33 @@ void pack_steps(std::vector<float>& dst, const float* w, int ks, int ntn, bool s
             }
 }
 
+// Weight stream of the split-half COLUMN form of the stage kernels (conv_stage_col_kernel): one 2 KB chunk per tap of one
+// 16-channel half -- [hi | lo] x [h 2][lane 32][8 halves], channel = 16 half + 8 h + e -- taps in kernel-COLUMN order
+// (kx outer, ky inner: a step of that kernel is one kernel column), half 0 of a source before its half 1.
+void pack_cols(std::vector<float>& dst, const float* w, int ks, int (*lane_channel)(int, int), int f) {
+    for (int half = 0; half < 2; ++half)
+        for (int kx = 0; kx < ks; ++kx)
+            for (int ky = 0; ky < ks; ++ky) {
+                const size_t base = dst.size();
+                dst.resize(base + 512, 0.0f);
+                _Float16* hp = (_Float16*)(dst.data() + base);
+                for (int j = 0; j < 32; ++j) {
+                    const int o = lane_channel(f, j);
+                    if (o < 0) continue;
+                    const float* src = w + ((size_t)o * ks * ks + ky * ks + kx) * 32 + 16 * half;
+                    for (int c = 0; c < 16; ++c) {
+                        _Float16 hi, lo;
+                        split_half_host(src[c], hi, lo);
+                        const int h = c / 8, e = c % 8;
+                        hp[(h * 32 + j) * 8 + e] = hi;
+                        hp[512 + (h * 32 + j) * 8 + e] = lo;
+                    }
+                }
+            }
+}
+int lane_ident(int, int j) { return j; }
+int lane_expand(int f, int j) { return expand_channel(f, 0, j); }
+
 // conv0 [32][5][5][3]: K packed per kernel row -- slot k = 3 kx + c (15 used of 16) -- as
 // [ky 5][jj 4][h 2][o 32][e 2] with k = 2 (2 jj + e) + h  (conv0_kernel: B[k][o] for MFMA j = 2 jj + e).
 void pack_conv0(std::vector<float>& dst, const float* w) {
@@ -224,7 +251,7 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[3][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}};
+    static const char* const kSwitch[5][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"dbg", "SRHIP_DBG"}, {"cols", "SRHIP_COLS"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
     {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
@@ -278,6 +305,20 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
             exp3(params + L.conv7); exp3(params + L.conv9); exp3(params + L.conv10);
             pack_lin(w, factor);  // f32 in both modes: the residual is the signal, it stays on the exact path
             off[4] = push(w);
+        }
+        if (expand_tiles(factor) == 1) {  // column-form chunks of the split-half mode (one N-tile only: factor 2, 3)
+            w.clear(); pack_cols(w, params + L.conv1, 5, lane_ident, factor);
+            c->off_wc[1] = push(w);
+            w.clear(); pack_cols(w, params + L.conv2, 5, lane_ident, factor); pack_cols(w, params + L.conv5, 3, lane_ident, factor);
+            c->off_wc[2] = push(w);
+            w.clear(); pack_cols(w, params + L.conv3, 5, lane_ident, factor); pack_cols(w, params + L.conv6, 3, lane_ident, factor);
+            pack_cols(w, params + L.conv8, 3, lane_ident, factor);
+            c->off_wc[3] = push(w);
+            w.clear(); pack_cols(w, params + L.conv7, 3, lane_expand, factor); pack_cols(w, params + L.conv9, 3, lane_expand, factor);
+            pack_cols(w, params + L.conv10, 3, lane_expand, factor);
+            pack_lin(w, factor);
+            c->off_wc[4] = push(w);
+            c->have_cols = true;
         }
         const size_t boff[4] = {L.f_bias, L.l_bias[0], L.l_bias[1], L.l_bias[2]};
         const size_t aoff[4] = {L.f_activ, L.l_activ[0], L.l_activ[1], L.l_activ[2]};
@@ -345,6 +386,10 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
         }
     } else if (!strcmp(key, "pipe")) { // "none": first form of the stage kernels everywhere
         c->env_pipe = strcmp(v, "none") != 0;
+    } else if (!strcmp(key, "cols")) {  // "0": split-half mode runs the step form of the pipe kernel instead of the column form
+        c->env_cols = strcmp(v, "0") != 0;
+    } else if (!strcmp(key, "dbg")) {  // timing experiments that BREAK the results (StageArgs::dbg); never set outside scripts/
+        c->env_dbg = atoi(v);
     } else if (!strcmp(key, "bw")) {   // tile-order column-block width in tiles; "" / negative: automatic, 0: plain row-major
         c->env_bw = *v ? atoi(v) : -1;
     } else {
@@ -497,14 +542,17 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
                 case 3: a.src[0] = f; a.src[1] = l1; a.src[2] = l2; a.dst = l3; break;
                 case 4: a.src[0] = l1; a.src[1] = l2; a.src[2] = l3; a.img = d_img; a.out = d_out; break;
             }
-            a.wpack = P + (c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
+            const bool use_pipe = pipe && th == 8;
+            // split-half mode, pipe form, one N-tile: the column form of the kernel with its own chunk order
+            const bool use_cols = use_pipe && c->precision == SR_PRECISION_SPLIT_F16 && c->have_cols && c->env_cols;
+            a.wpack = P + (use_cols ? c->off_wc[st] : c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
             a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
             a.H = H; a.W = W; a.img_ch = img_ch;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.n_img = n; a.queue = c->d_queue + st * 8;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
             set_tile_order(a, c->env_bw >= 0 ? c->env_bw : kAutoBlockWidth);
-            const bool use_pipe = pipe && th == 8;
+            a.dbg = c->env_dbg;
             // persistent kernels (the pipe form; the first form in split-half mode) get one workgroup per resident
             // slot -- 2 per CU with 8-row tiles, 3 with 4-row tiles -- and pull tiles from the queue
             int grid = nblk;
@@ -512,7 +560,9 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
                 const int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);
                 if (grid > resident) grid = resident;
             }
-            if (use_pipe) {
+            if (use_cols) {
+                HIPCHK(c, sr_launch_stage_cols(st, c->factor, a, grid, img_u8, out_u8, s));
+            } else if (use_pipe) {
                 HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, grid, img_u8, out_u8, s));
             } else {
                 HIPCHK(c, sr_launch_stage(st, c->factor, a, th, c->precision, grid, img_u8, out_u8, s));

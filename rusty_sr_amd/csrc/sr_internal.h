@@ -14,6 +14,8 @@ struct sr_ctx {
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
     size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
+    size_t off_wc[5] = {0};  // split-half column-form chunks (pack_cols)
+    bool have_cols = false, env_cols = true;
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;
@@ -39,6 +41,7 @@ struct sr_ctx {
     int env_th[5] = {0, 0, 0, 0, 0};  // 0: automatic
     bool env_pipe = true;
     int env_bw = -1;                  // tile-order column-block width in tiles (-1: automatic)
+    int env_dbg = 0;                  // StageArgs::dbg timing experiments (results invalid when non-zero)
     unsigned long long params_hash = 0;  // FNV-1a of the parameter vector: contexts of one sharded call must agree
     // ---- multi-GPU (sr_comm.cpp): one RCCL communicator per context, neighbour halo exchange
     void* comm = nullptr;             // ncclComm_t

@@ -51,6 +51,9 @@ struct StageArgs {
     // row-major).  Consecutive tile ids -- what one XCD's workgroups hold at a time -- then cover a few rows of one
     // block instead of a slice of one long tile row, so the halo rows of vertically adjacent tiles are still in
     // that XCD's L2 when they are needed again (at 3840 px a tile row of one 32-channel map is 3.9 MB, the L2 4 MB).
+    int dbg;              // TIMING EXPERIMENTS ONLY (sr_set_experiment "dbg"; results are then wrong by design): bit 0 = gathers read
+                          // one contiguous KB per instruction instead of 64 pixel lines, bit 1 = no half-tile gathers at all,
+                          // bit 2 = no epilogue stores
     int bw, nfull;                     // block width in tiles; number of full-width blocks (tiles_x / bw)
     TileDiv div_blk, div_bw, div_rem;  // divisors: bw * tiles_y, bw, tiles_x % bw (the last, narrower block)
 };
@@ -85,3 +88,7 @@ hipError_t sr_launch_stage(int stage, int factor, const StageArgs& a, int th, in
 // wpack must be in the pipe chunk order (sr_api.cpp pack_*_pipe); grid = co-resident workgroups.
 hipError_t sr_launch_stage_pipe(int stage, int factor, const StageArgs& a, int prec, int grid, bool img_u8, bool out_u8,
                                 hipStream_t s);
+// Column form of the split-half stage kernels (conv_stage_col_kernel): one kernel COLUMN of one 16-channel half per barrier
+// (30 / 18 MFMAs per wave), operands of the next column read from LDS under the MFMAs of this one, weights through a ring of
+// ten 2 KB tap slots (waves 0-1 request them, waves 2-3 request the half-tile gathers).  wpack: sr_api.cpp pack_cols.
+hipError_t sr_launch_stage_cols(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s);

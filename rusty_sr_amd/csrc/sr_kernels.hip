@@ -89,6 +89,9 @@ constexpr int kThreads = 256;
 #ifndef SR_SPLIT_WAVES
 #define SR_SPLIT_WAVES 4
 #endif
+#ifndef SR_SPLIT_INTERLEAVE
+#define SR_SPLIT_INTERLEAVE 1  // split-half step loop: operand reads / DMA requests interleaved 1:1 with the MFMAs (0: all in front)
+#endif
 constexpr int kTW = 32;            // tile width = one MFMA M-tile of pixels
 constexpr int kChunkFloats = 1024; // one tap: 32 cin x 32 cout
 constexpr int kRingSlots = 5;      // 4 KB weight chunks: one being read, up to four in flight
@@ -600,14 +603,80 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
             }
         }
     };
+    // One operand of step p, item k = ts * (2 + 2 T) + j: j = 0 / 1 the hi / lo weight fragment of tap slot ts, j = 2 + 2 m / 3 + 2 m
+    // the hi / lo pixels of tile row m -- a register copy when the row is already held (see above), an LDS read otherwise.
+    constexpr int NI = 2 * (2 + 2 * T), NM = 2 * 3 * T;  // operand items / MFMAs of a full step
+    auto load_item = [&](Ops& o, const Ops& prev, int pp, int p, int sl, int k) {
+        const int ts = k / (2 + 2 * T), j = k % (2 + 2 * T), t = 2 * p + ts;
+        if (t >= NT) return;
+        const char* wb = ring + sl * 4096 + wlane;
+        if (j == 0) { o.bh[ts] = *(const f16x8*)(wb + ts * 1024); return; }
+        if (j == 1) { o.bl[ts] = *(const f16x8*)(wb + 2048 + ts * 1024); return; }
+        const int m = (j - 2) >> 1;
+        const bool lo = (j - 2) & 1;
+        const int id = row_id(p, ts, m);
+#pragma unroll
+        for (int ts2 = 0; ts2 < 2; ++ts2)
+#pragma unroll
+            for (int m2 = 0; m2 < T; ++m2)
+                if ((ts2 * T + m2) < (ts * T + m) && row_id(p, ts2, m2) == id) {
+                    if (lo) o.al[ts][m] = o.al[ts2][m2]; else o.ah[ts][m] = o.ah[ts2][m2];
+                    return;
+                }
+#pragma unroll
+        for (int ts2 = 0; ts2 < 2; ++ts2)
+#pragma unroll
+            for (int m2 = 0; m2 < T; ++m2)
+                if (pp >= 0 && row_id(pp, ts2, m2) == id) {
+                    if (lo) o.al[ts][m] = prev.al[ts2][m2]; else o.ah[ts][m] = prev.ah[ts2][m2];
+                    return;
+                }
+        const int kx = t / KS, ky = t - kx * KS;
+        const char* ab = abase + ((ky + m) * TWH + kx) * 16;
+        if (lo) o.al[ts][m] = *(const f16x8*)(ab + LO * PS); else o.ah[ts][m] = *(const f16x8*)ab;
+    };
     Ops cur, nxt;
     load(cur, cur, -1, 0, sm.slot());
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int nt = 0; nt < NTN; ++nt) {
-        sm.begin_step();
         const bool last = p == NP - 1 && nt == NTN - 1;
+#if SR_SPLIT_INTERLEAVE
+        // Two waves share a SIMD's matrix pipe.  With all of a step's operand reads and DMA requests in front of its
+        // 12 MFMAs the two fall into lockstep (both read, then both multiply) and the pipe idles through every read
+        // phase.  So each wave keeps the pipe busy on its own: one operand read of the NEXT step (or one DMA request)
+        // in the shadow of each 32-cycle MFMA of this one, pinned in that order.
+        const int pn = nt + 1 < NTN ? p : p + 1;
+        const int sln = sm.slot() == kRingSlots - 1 ? 0 : sm.slot() + 1;
+        int q = 0;  // MFMAs issued so far in this step
+        auto after_mfma = [&]() {
+            if (q == 0) sm.begin_step();
+#pragma unroll
+            for (int k = 0; k < NI; ++k)
+                if (!last && k >= q * NI / NM && k < (q + 1) * NI / NM) load_item(nxt, cur, p, pn, sln, k);
+            if (nt == 0 && q == NM / 2 - 1) sm.piece(2 * p);
+            if (nt == 0 && q == NM - 2) sm.piece(2 * p + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            ++q;
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts) {
+            if (2 * p + ts < NT) {
+#pragma unroll
+                for (int m = 0; m < T; ++m) { accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bh[ts], accm[nt * T + m], 0, 0, 0); after_mfma(); }
+#pragma unroll
+                for (int m = 0; m < T; ++m) { accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bl[ts], accx[nt * T + m], 0, 0, 0); after_mfma(); }
+#pragma unroll
+                for (int m = 0; m < T; ++m) { accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[ts][m], cur.bh[ts], accx[nt * T + m], 0, 0, 0); after_mfma(); }
+            } else {  // the lone last tap of an odd kernel: the second tap slot is empty, its items still have to be issued
+#pragma unroll
+                for (int m = 0; m < 3 * T; ++m) after_mfma();
+            }
+        }
+#else
+        sm.begin_step();
         // (with two N-tiles the same taps run again on the next chunk: everything is found in `cur`)
         if (!last) load(nxt, cur, p, nt + 1 < NTN ? p : p + 1, sm.slot() == kRingSlots - 1 ? 0 : sm.slot() + 1);
         if (nt == 0) { sm.piece(2 * p); sm.piece(2 * p + 1); }  // two gather instructions per step
@@ -624,6 +693,7 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#endif
         sm.template end_step<1>(last);
         cur = nxt;
       }
@@ -990,6 +1060,13 @@ struct HalfTile {
 #pragma unroll
         for (int g = G0; g < G1 && g < G::NG; ++g) lds_dma16<0>(origin, off[g], dst + g * 1024);
     }
+    // the same for an explicit LDS plane of the split-half map (0, 1: hi halves of channel groups 2 khalf, 2 khalf + 1; 2, 3: lo)
+    __device__ __forceinline__ void stage_plane(int g, int plane, uint32_t buf, const float* __restrict__ src, int khalf, long img_stride,
+                                                int pitch, int n, int y0, int x0) const {
+        const int chunk = plane < 2 ? 2 * khalf + plane : 4 + 2 * khalf + (plane - 2);
+        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) + chunk * 16);
+        lds_dma16<0>(origin, off[g], __builtin_amdgcn_readfirstlane(buf + plane * G::PLANE + g * 1024));
+    }
     // one gather instruction of that request: pixel group g (64 tile pixels) of this wave's plane
     template <int PREC>
     __device__ __forceinline__ void stage_one(int g, uint32_t buf, const float* __restrict__ src, int khalf, long img_stride,
@@ -1131,7 +1208,7 @@ struct PipeStream {
     __device__ __forceinline__ void begin_step() { step_request(st, ring, a.wpack, wave, lane); }
     // gather instruction number g of the half tile being requested (compile-time after unrolling)
     __device__ __forceinline__ void piece(int g) {
-        if (g < HalfTile<KSN>::G::NG && rq.active) {
+        if (g < HalfTile<KSN>::G::NG && rq.active && !(a.dbg & 2)) {
             htn.template stage_one<PREC>(g, rq.buf, rq.src, rq.khalf, a.img_stride, a.pitch, rq.n, rq.y0, rq.x0, wave);
             st.tile_seq = ++st.issued;
         }
@@ -1175,6 +1252,14 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     H3 h3;
     h0.init(a.pitch, lane);
     if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
+    if (a.dbg & 1) {  // timing experiment: what would contiguous gathers cost?
+#pragma unroll
+        for (int g = 0; g < H0::G::NG; ++g) h0.off[g] = (uint32_t)(g * 64 + lane) * 16u;
+        if constexpr (NSRC >= 2) {
+#pragma unroll
+            for (int g = 0; g < H3::G::NG; ++g) h3.off[g] = (uint32_t)(g * 64 + lane) * 16u;
+        }
+    }
 
     auto coords = [&](int t, int& n, int& x0, int& y0) {
         int tx, ty;
@@ -1263,6 +1348,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             asm volatile("" ::: "memory");
         }
         TL(5); TL(6); TL(8);
+        if (!(a.dbg & 4))  // timing experiment (bit 2): no epilogue at all
         stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
         TL(7);
         if (!st.have_next) break;
@@ -1270,6 +1356,281 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
     TL_END();
+}
+
+// ---------------------------------------------------------------------------
+// Stage kernel, COLUMN form (split-half mode, 8-row tiles, one N-tile).  Same tiles, same half tiles, same double
+// buffering and persistent queue as the pipe form; what changes is the unit of work between two workgroup barriers.
+// Measured on the step form (rocprofv3 SQ counters, 1080p): a wave spent 33 % of its cycles parked at s_waitcnt /
+// s_barrier and the f16 matrix pipe was 52-57 % busy -- with the half-tile gathers and the epilogue removed still only
+// 58-66 %: twelve 32-cycle MFMAs between two synchronisation points cannot cover the synchronisation itself.  Here
+//  * a step is one kernel COLUMN of one 16-channel half: 5 (3) taps x 2 rows x 3 products = 30 (18) MFMAs per wave and
+//    barrier, and the 6 (4) tile rows a column touches are read once for all its taps;
+//  * the operands of column c+1 (rows of the same half tile, weight fragments of whatever comes next -- also across half
+//    and tile boundaries) are read from LDS into the registers column c frees, one ds_read_b128 in the shadow of each MFMA,
+//    so nothing is waited for at the barrier;
+//  * weights travel as 2 KB tap chunks ([hi | lo], sr_api.cpp pack_cols) through a ring of ten slots: at the start of
+//    column c the taps of column c+2 are requested into the slots column c has just vacated;
+//  * DMA roles are split by wave: waves 0-1 request weights only (L2 hits, needed one column later), waves 2-3 the
+//    half-tile gathers only (HBM latency, needed at the end of the half).  Loads retire in order on a wave's VM counter,
+//    so a wave that issued both had its per-step weight wait held up by gathers that were not due for a dozen steps.
+// Tap order (kernel-column-major), product order and half order equal the step form's, so results are bit-identical.
+// ---------------------------------------------------------------------------
+constexpr int kColSlots = 10;
+constexpr int kColRingBytes = kColSlots * 2048;
+
+template <int NSRC, int KS0>
+struct ColPlan {  // compile-time schedule of a tile: halves j (wrapping into the next tile), columns c
+    static constexpr int NH = 2 * NSRC;
+    static constexpr int ks(int j) { return (j % NH) < 2 ? KS0 : 3; }
+    static constexpr int tap0(int j) { int t = 0; for (int k = 0; k < j; ++k) t += ks(k) * ks(k); return t; }
+    static constexpr int ntaps() { return tap0(NH); }
+    static constexpr int ncols() { int c = 0; for (int j = 0; j < NH; ++j) c += ks(j); return c; }
+    static constexpr int col_half(int c) { int j = 0; while (c >= ks(j)) { c -= ks(j); ++j; } return j; }
+    static constexpr int col_kx(int c) { int j = 0; while (c >= ks(j)) { c -= ks(j); ++j; } return c; }
+    static constexpr int col_ks(int c) { return ks(col_half(c)); }
+    static constexpr int col_tap0(int c) { return tap0(col_half(c)) + col_kx(c) * col_ks(c); }
+};
+
+// Operand reads of the NEXT column, in issue order.  kind 0: tile row `idx` (hi / lo pixels), kind 1: weight fragment of tap
+// `idx`; `earliest` = number of this column's MFMAs that must have been issued first (the registers the read lands in are
+// those of an operand that dies there; the first six use spare registers and go out at once).
+struct ColItem { int kind, idx, lo, earliest; };
+__host__ __device__ constexpr ColItem col_item(int KS, int KSN, bool same_half, int k) {
+    int n = 0;
+    if (same_half) {
+        for (int r = KS; r >= KS - 1; --r)
+            for (int lo = 0; lo < 2; ++lo) { if (n == k) return {0, r, lo, 0}; ++n; }
+    }
+    for (int lo = 0; lo < 2; ++lo) { if (n == k) return {1, KSN - 1, lo, 0}; ++n; }
+    const int m = (KS > KSN ? KS : KSN) - 1;
+    for (int ky = 0; ky < m; ++ky) {
+        const int e = 6 * ((ky < KS - 1 ? ky : KS - 2) + 1);
+        if (ky < KSN - 1) for (int lo = 0; lo < 2; ++lo) { if (n == k) return {1, ky, lo, e}; ++n; }
+        if (same_half && ky < KS - 1) for (int lo = 0; lo < 2; ++lo) { if (n == k) return {0, ky, lo, e}; ++n; }
+    }
+    return {2, 0, 0, 0};
+}
+__host__ __device__ constexpr int col_item_count(int KS, int KSN, bool same_half) { return (same_half ? 2 * (KS + 1) : 0) + 2 * KSN; }
+// items [first, first + count) go out after MFMA number q (0-based) of the column: at most `cap` per MFMA, none before its time
+__host__ __device__ constexpr int col_items_before(int KS, int KSN, bool same_half, int q, int cap) {
+    const int total = col_item_count(KS, KSN, same_half);
+    int done = 0;
+    for (int s = 0; s < q; ++s) {
+        int c = 0;
+        while (c < cap && done < total && col_item(KS, KSN, same_half, done).earliest <= s + 1) { ++done; ++c; }
+    }
+    return done;
+}
+
+template <typename F, int... C>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, C...>) { (f(std::integral_constant<int, C>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int FACTOR = 3>
+__global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
+    constexpr int TH = 8, T = 2;
+    using P = ColPlan<NSRC, KS0>;
+    using H0 = HalfTile<KS0>;
+    using H3 = HalfTile<3>;
+    constexpr int HB = H0::BYTES;
+    constexpr int NH = P::NH, NCOLS = P::ncols(), NTAPS = P::ntaps();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem + 2 * HB;
+    volatile int* s_next = (volatile int*)(ring + kColRingBytes);
+    float* s_wlin = (float*)(ring + kColRingBytes + 16);
+    const uint32_t lds0 = lds_addr(smem), ring_lds = lds_addr(ring);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const bool weight_wave = wave < 2;  // waves 0, 1: weight DMA (hi / lo KB of every tap); waves 2, 3: gathers (planes 0-1 / 2-3)
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int ntiles = tiles_per_img * a.n_img;
+    const int xcd = blockIdx.x & 7;
+    float bias[1] = {a.bias[i]};
+    const float beta = FINAL ? 0.f : a.beta[i];
+    H0 h0;
+    H3 h3;
+    h0.init(a.pitch, lane);
+    if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
+
+    auto coords = [&](int t, int& n, int& x0, int& y0) {
+        int tx, ty;
+        tile_coords(a, t, n, tx, ty);
+        x0 = tx * kTW; y0 = a.y_begin + ty * TH;
+    };
+    if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
+    if constexpr (FINAL) {
+        const float* wlin = a.wpack + (size_t)NTAPS * 512;
+        for (int k = tid; k < 9 * 128; k += 256) s_wlin[k] = wlin[k];
+    }
+    __syncthreads();
+    int cur_tile = __builtin_amdgcn_readfirstlane(*s_next);
+    if (cur_tile < 0) return;
+    int n, x0, y0;
+    coords(cur_tile, n, x0, y0);
+    LinPrefetch<IMG_U8> linpx;
+
+    // ring slot of tap g of the current tile (g >= NTAPS: a tap of the next tile): slots are handed out round-robin over the
+    // whole launch, rbase = (taps of all earlier tiles) mod kColSlots
+    int rbase = 0;
+    auto slot_lds = [&](int g) -> uint32_t {
+        int sl = rbase + g % kColSlots;
+        if (sl >= kColSlots) sl -= kColSlots;
+        return ring_lds + (uint32_t)sl * 2048u;
+    };
+    auto request_tap = [&](int g) {  // this wave's KB (hi or lo) of tap g
+        const char* src = (const char*)a.wpack + (size_t)(g % NTAPS) * 2048 + wave * 1024;
+        lds_dma16<0>(uniform_ptr(src), (uint32_t)(lane * 16), __builtin_amdgcn_readfirstlane(slot_lds(g) + wave * 1024));
+    };
+    // first tile only: half 0 (every wave moves its plane) and the weights of the first two columns
+    h0.template stage<1>(lds0, a.src[0], 0, a.img_stride, a.pitch, n, y0, x0, wave);
+    if (weight_wave) static_for<P::col_ks(0) + P::col_ks(1)>([&](auto gc) { request_tap(decltype(gc)::value); });
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const int wlane = (h * 32 + i) * 16;
+    const char* ring_lane = ring + wlane;
+    // operand registers of two columns (parity of the column number): weight fragments of up to 5 taps, pixels of up to 6 rows
+    f16x8 bh[2][5], bl[2][5], ah[2][6], al[2][6];
+    // fragment of tap g (tile-relative) -> b?[par][t]; par, t, lo are compile-time at every call site (after inlining the
+    // array indices are constants, so the operand arrays live in registers)
+    auto read_b = [&](int par, int t, int g, bool lo) __attribute__((always_inline)) {
+        const char* p = ring_lane + (slot_lds(g) - ring_lds) + (lo ? 1024 : 0);
+        if (lo) bl[par][t] = *(const f16x8*)p; else bh[par][t] = *(const f16x8*)p;
+    };
+    static_for<KS0>([&](auto tc) { constexpr int t = decltype(tc)::value; read_b(0, t, t, false); read_b(0, t, t, true); });
+    // (every later column finds its fragments prefetched by the column before it; these reads must have returned in EVERY wave
+    // before column 0's first weight request may overwrite the slots they came from)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    while (true) {
+        f32x16 acc[T], accx[T];
+#pragma unroll
+        for (int m = 0; m < T; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[m][r] = 0.f; accx[m][r] = 0.f; }
+        int pulled = 0;
+        if (tid == 0) pulled = atomicAdd(&a.queue[xcd], 1);  // the answer is looked at by the end of half 0
+        int nn = 0, nx0 = 0, ny0 = 0, next = -1;
+        bool have_next = false;
+
+        static_for<NCOLS>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int j = P::col_half(c), kx = P::col_kx(c), KS = P::col_ks(c), par = c & 1;
+            constexpr int KSN = P::col_ks(c + 1), KS2 = P::col_ks(c + 2);
+            constexpr bool same_half = kx + 1 < KS;          // the next column reads the same half tile
+            constexpr bool last_of_half = !same_half;
+            using GJ = TileGeom<8, KS>;
+            constexpr int TWH = GJ::TWH, PS = GJ::PLANE;
+            const char* hb = smem + (j & 1) * HB;
+            const char* abase = hb + h * PS + ((wave * T) * TWH + i) * 16;
+            if constexpr (kx == 0) {
+                if constexpr (j == 1) {  // the mailbox was published before the barrier that ended half 0
+                    next = __builtin_amdgcn_readfirstlane(*s_next);
+                    have_next = next >= 0;
+                    if (have_next) coords(next, nn, nx0, ny0);
+                }
+                if constexpr (FINAL && j == NH - 1) {
+                    StepStream dummy{};
+                    linpx.issue(a, n, y0, x0, tid, dummy);
+                }
+                // the half tile landed with the barrier that ended the previous column: its first column's rows
+                static_for<KS + 1>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    ah[par][r] = *(const f16x8*)(abase + (r * TWH) * 16);
+                    al[par][r] = *(const f16x8*)(abase + (r * TWH) * 16 + 2 * PS);
+                });
+            }
+            // what this column requests on the side
+            constexpr int jr = j + 1;                           // the half whose gathers go out during half j ...
+            constexpr int KSR = P::ks(jr);                      // (jr == NH: half 0 of the next tile)
+            constexpr int NGR = HalfTile<KSR>::G::NG;
+            constexpr int issue_cols = KS - 1;                  // ... spread over all but the last column of half j
+            constexpr int PPC = (2 * NGR + issue_cols - 1) / issue_cols;
+            const bool gather_on = !(a.dbg & 2) && (jr < NH || have_next);
+            const bool weights_on = c + 2 < NCOLS || have_next;
+            const uint32_t other = lds0 + ((j + 1) & 1) * HB;
+            constexpr int NITEMS = col_item_count(KS, KSN, same_half);
+            constexpr int CAP = NITEMS > 6 * KS - 2 ? 2 : 1;
+
+            // after MFMA number q of the column: this wave's DMA request number q (they need the lead), then the operand reads
+            // of the next column that are due -- all indices compile-time constants (registers, not scratch)
+            auto aux = [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                if (weight_wave) {
+                    if constexpr (q < KS2) { if (weights_on) request_tap(P::col_tap0(c + 2) + q); }
+                } else if constexpr (kx < issue_cols && q < PPC && kx * PPC + q < 2 * NGR) {
+                    if (gather_on) {
+                        constexpr int e = kx * PPC + q;  // piece number within this wave's 2 * NGR
+                        const int plane = 2 * (wave - 2) + e / NGR;
+                        constexpr int g = e % NGR;
+                        const float* src = a.src[(jr % NH) >> 1];
+                        const int tn = jr < NH ? n : nn, ty0 = jr < NH ? y0 : ny0, tx0 = jr < NH ? x0 : nx0;
+                        if constexpr (KSR == KS0) h0.stage_plane(g, plane, other, src, jr & 1, a.img_stride, a.pitch, tn, ty0, tx0);
+                        else h3.stage_plane(g, plane, other, src, jr & 1, a.img_stride, a.pitch, tn, ty0, tx0);
+                    }
+                }
+                constexpr int first = col_items_before(KS, KSN, same_half, q, CAP), last = col_items_before(KS, KSN, same_half, q + 1, CAP);
+                static_for<last - first>([&](auto kc) {
+                    constexpr int k = first + decltype(kc)::value;
+                    constexpr ColItem it = col_item(KS, KSN, same_half, k);
+                    if constexpr (it.kind == 0) {
+                        const char* p = abase + (it.idx * TWH + kx + 1) * 16 + (it.lo ? 2 * PS : 0);
+                        if constexpr (it.lo) al[par ^ 1][it.idx] = *(const f16x8*)p; else ah[par ^ 1][it.idx] = *(const f16x8*)p;
+                    } else {
+                        read_b(par ^ 1, it.idx, P::col_tap0(c + 1) + it.idx, it.lo);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<KS>([&](auto kyc) {
+                constexpr int ky = decltype(kyc)::value;
+                static_for<T>([&](auto mc) { constexpr int m = decltype(mc)::value;
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[par][ky + m], bh[par][ky], acc[m], 0, 0, 0); aux(std::integral_constant<int, 6 * ky + m>{}); });
+                static_for<T>([&](auto mc) { constexpr int m = decltype(mc)::value;
+                    accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[par][ky + m], bl[par][ky], accx[m], 0, 0, 0); aux(std::integral_constant<int, 6 * ky + 2 + m>{}); });
+                static_for<T>([&](auto mc) { constexpr int m = decltype(mc)::value;
+                    accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[par][ky + m], bh[par][ky], accx[m], 0, 0, 0); aux(std::integral_constant<int, 6 * ky + 4 + m>{}); });
+            });
+            static_assert(col_items_before(KS, KSN, same_half, 6 * KS, CAP) == NITEMS, "every operand of the next column is requested");
+            // end of the column: the weights of column c+2 (requested at its start) have landed; at the end of a half also
+            // the next half tile; every LDS read of this column has returned before anybody overwrites what it read
+            if constexpr (j == 0 && last_of_half) { if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, pulled); }
+            if (weight_wave || last_of_half) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        });
+
+        if constexpr (FINAL) {
+            // bilinear residual: the image tile goes into the buffer the last half has just left (buffer 1)
+            float* s_x = (float*)(smem + HB);
+            StepStream dummy{};
+            linpx.seq = 0;
+            linpx.store(s_x, tid, dummy);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            lin_mfma<TH, T, 1>(acc, s_x, s_wlin, wave, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
+            asm volatile("" ::: "memory");
+        }
+        if (!(a.dbg & 4))
+        stage_epilogue<TH, T, 1, FINAL, OUT_U8, 1, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
+        if (!have_next) break;
+        n = nn; x0 = nx0; y0 = ny0;
+        rbase += NTAPS % kColSlots;
+        if (rbase >= kColSlots) rbase -= kColSlots;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
 }
 
 // ---------------------------------------------------------------------------
@@ -1445,6 +1806,27 @@ static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a,
     }
     return hipErrorInvalidValue;
 }
+// Column form (split-half mode, 8-row tiles, factor <= 3): LDS = two half tiles + tap ring + mailbox (+ bilinear weights).
+hipError_t sr_launch_stage_cols(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s) {
+    constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kColRingBytes + 16;
+    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kColRingBytes + 16 + 9 * 128 * sizeof(float);
+    switch (stage) {
+        case 1: return launch_with_lds(conv_stage_col_kernel<1, 5, false, false, false>, a, grid, lds5, s);
+        case 2: return launch_with_lds(conv_stage_col_kernel<2, 5, false, false, false>, a, grid, lds5, s);
+        case 3: return launch_with_lds(conv_stage_col_kernel<3, 5, false, false, false>, a, grid, lds5, s);
+        case 4:
+#define SR_FINAL(F)                                                                                                          \
+            if (img_u8 && out_u8) return launch_with_lds(conv_stage_col_kernel<3, 3, true, true, true, F>, a, grid, lds3, s); \
+            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_col_kernel<3, 3, true, false, false, F>, a, grid, lds3, s); \
+            return hipErrorInvalidValue;
+            if (factor == 3) { SR_FINAL(3) }
+            if (factor == 2) { SR_FINAL(2) }
+#undef SR_FINAL
+            return hipErrorInvalidValue;
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t sr_launch_stage_pipe(int stage, int factor, const StageArgs& a, int prec, int grid, bool img_u8, bool out_u8, hipStream_t s) {
     return prec == 0 ? launch_stage_pipe_t<0>(stage, factor, a, grid, img_u8, out_u8, s)
                      : launch_stage_pipe_t<1>(stage, factor, a, grid, img_u8, out_u8, s);
