@@ -53,7 +53,7 @@ struct StageArgs {
     // that XCD's L2 when they are needed again (at 3840 px a tile row of one 32-channel map is 3.9 MB, the L2 4 MB).
     int dbg;              // TIMING EXPERIMENTS ONLY (sr_set_experiment "dbg"; results are then wrong by design): bit 0 = gathers read
                           // one contiguous KB per instruction instead of 64 pixel lines, bit 1 = no half-tile gathers at all,
-                          // bit 2 = no epilogue stores
+                          // bit 2 = no epilogue at all, bit 3 = (column form) no weight requests after the first two columns
     int bw, nfull;                     // block width in tiles; number of full-width blocks (tiles_x / bw)
     TileDiv div_blk, div_bw, div_rem;  // divisors: bw * tiles_y, bw, tiles_x % bw (the last, narrower block)
 };

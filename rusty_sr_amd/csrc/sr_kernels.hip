@@ -1369,8 +1369,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
 //  * the operands of column c+1 (rows of the same half tile, weight fragments of whatever comes next -- also across half
 //    and tile boundaries) are read from LDS into the registers column c frees, one ds_read_b128 in the shadow of each MFMA,
 //    so nothing is waited for at the barrier;
-//  * weights travel as 2 KB tap chunks ([hi | lo], sr_api.cpp pack_cols) through a ring of ten slots: at the start of
-//    column c the taps of column c+2 are requested into the slots column c has just vacated;
+//  * weights travel as 2 KB tap chunks ([hi | lo], sr_api.cpp pack_cols) through two banks of five slots: at the start of
+//    column c the taps of column c+2 are requested into the bank column c has just vacated (all slot numbers are
+//    compile-time constants: a first version with a modulo-10 ring spent 25 scalar instructions per MFMA on them);
 //  * DMA roles are split by wave: waves 0-1 request weights only (L2 hits, needed one column later), waves 2-3 the
 //    half-tile gathers only (HBM latency, needed at the end of the half).  Loads retire in order on a wave's VM counter,
 //    so a wave that issued both had its per-step weight wait held up by gathers that were not due for a dozen steps.
@@ -1473,21 +1474,19 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
     coords(cur_tile, n, x0, y0);
     LinPrefetch<IMG_U8> linpx;
 
-    // ring slot of tap g of the current tile (g >= NTAPS: a tap of the next tile): slots are handed out round-robin over the
-    // whole launch, rbase = (taps of all earlier tiles) mod kColSlots
-    int rbase = 0;
-    auto slot_lds = [&](int g) -> uint32_t {
-        int sl = rbase + g % kColSlots;
-        if (sl >= kColSlots) sl -= kColSlots;
-        return ring_lds + (uint32_t)sl * 2048u;
-    };
-    auto request_tap = [&](int g) {  // this wave's KB (hi or lo) of tap g
+    // The ring is two banks of five 2 KB tap slots; column c keeps its taps in bank c & 1 (a tile has an even number of
+    // columns, so the parity runs on across tiles).  While column c executes from registers, bank (c+1) & 1 holds the taps
+    // of column c+1 (being read) and bank c & 1 -- column c's own, already consumed -- receives the taps of column c+2.
+    auto request_tap = [&](int bank, int t, int g) {  // this wave's KB (hi or lo) of tap g (tile-relative; >= NTAPS: next tile's)
         const char* src = (const char*)a.wpack + (size_t)(g % NTAPS) * 2048 + wave * 1024;
-        lds_dma16<0>(uniform_ptr(src), (uint32_t)(lane * 16), __builtin_amdgcn_readfirstlane(slot_lds(g) + wave * 1024));
+        lds_dma16<0>(uniform_ptr(src), (uint32_t)(lane * 16), __builtin_amdgcn_readfirstlane(ring_lds + (5 * bank + t) * 2048 + wave * 1024));
     };
     // first tile only: half 0 (every wave moves its plane) and the weights of the first two columns
     h0.template stage<1>(lds0, a.src[0], 0, a.img_stride, a.pitch, n, y0, x0, wave);
-    if (weight_wave) static_for<P::col_ks(0) + P::col_ks(1)>([&](auto gc) { request_tap(decltype(gc)::value); });
+    if (weight_wave) {
+        static_for<P::col_ks(0)>([&](auto tc) { request_tap(0, decltype(tc)::value, decltype(tc)::value); });
+        static_for<P::col_ks(1)>([&](auto tc) { constexpr int g1 = P::col_tap0(1) + decltype(tc)::value; request_tap(1, decltype(tc)::value, g1); });
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1498,11 +1497,11 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
     f16x8 bh[2][5], bl[2][5], ah[2][6], al[2][6];
     // fragment of tap g (tile-relative) -> b?[par][t]; par, t, lo are compile-time at every call site (after inlining the
     // array indices are constants, so the operand arrays live in registers)
-    auto read_b = [&](int par, int t, int g, bool lo) __attribute__((always_inline)) {
-        const char* p = ring_lane + (slot_lds(g) - ring_lds) + (lo ? 1024 : 0);
+    auto read_b = [&](int par, int t, bool lo) __attribute__((always_inline)) {  // tap t of the column of parity par
+        const char* p = ring_lane + (5 * par + t) * 2048 + (lo ? 1024 : 0);
         if (lo) bl[par][t] = *(const f16x8*)p; else bh[par][t] = *(const f16x8*)p;
     };
-    static_for<KS0>([&](auto tc) { constexpr int t = decltype(tc)::value; read_b(0, t, t, false); read_b(0, t, t, true); });
+    static_for<KS0>([&](auto tc) { constexpr int t = decltype(tc)::value; read_b(0, t, false); read_b(0, t, true); });
     // (every later column finds its fragments prefetched by the column before it; these reads must have returned in EVERY wave
     // before column 0's first weight request may overwrite the slots they came from)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1519,6 +1518,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
         if (tid == 0) pulled = atomicAdd(&a.queue[xcd], 1);  // the answer is looked at by the end of half 0
         int nn = 0, nx0 = 0, ny0 = 0, next = -1;
         bool have_next = false;
+        const char* g_org[2] = {nullptr, nullptr};
+        uint32_t g_dst[2] = {0, 0};
 
         static_for<NCOLS>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
@@ -1551,11 +1552,24 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
             constexpr int jr = j + 1;                           // the half whose gathers go out during half j ...
             constexpr int KSR = P::ks(jr);                      // (jr == NH: half 0 of the next tile)
             constexpr int NGR = HalfTile<KSR>::G::NG;
+            if constexpr (kx == 0) {
+                // a gathering wave moves two LDS planes of that half: their source origins and LDS bases, once per half
+                // (scalar registers; a request is then s_mov m0 + one global_load_lds)
+                const float* gsrc = a.src[(jr % NH) >> 1];
+                const int tn = jr < NH ? n : nn, ty0 = jr < NH ? y0 : ny0, tx0 = jr < NH ? x0 : nx0;
+                const char* tile0 = (const char*)(gsrc + ((size_t)tn * a.img_stride + (long)(ty0 - KSR / 2) * a.pitch + (tx0 - KSR / 2)) * 32);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const int plane = 2 * (wave & 1) + pl;      // waves 2, 3 -> planes 0-1, 2-3
+                    const int chunk = plane < 2 ? 2 * (jr & 1) + plane : 4 + 2 * (jr & 1) + (plane - 2);
+                    g_org[pl] = uniform_ptr(tile0 + chunk * 16);
+                    g_dst[pl] = __builtin_amdgcn_readfirstlane(lds0 + ((j + 1) & 1) * HB + plane * HalfTile<KSR>::G::PLANE);
+                }
+            }
             constexpr int issue_cols = KS - 1;                  // ... spread over all but the last column of half j
             constexpr int PPC = (2 * NGR + issue_cols - 1) / issue_cols;
             const bool gather_on = !(a.dbg & 2) && (jr < NH || have_next);
-            const bool weights_on = c + 2 < NCOLS || have_next;
-            const uint32_t other = lds0 + ((j + 1) & 1) * HB;
+            const bool weights_on = (c + 2 < NCOLS || have_next) && !(a.dbg & 8);
             constexpr int NITEMS = col_item_count(KS, KSN, same_half);
             constexpr int CAP = NITEMS > 6 * KS - 2 ? 2 : 1;
 
@@ -1564,16 +1578,16 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
             auto aux = [&](auto qc) {
                 constexpr int q = decltype(qc)::value;
                 if (weight_wave) {
-                    if constexpr (q < KS2) { if (weights_on) request_tap(P::col_tap0(c + 2) + q); }
+                    if constexpr (q < KS2) {
+                        constexpr int g2 = (P::col_tap0(c + 2) + q) % NTAPS;  // forced compile-time (the plan's loops must not reach the GPU)
+                        if (weights_on) request_tap(par, q, g2);
+                    }
                 } else if constexpr (kx < issue_cols && q < PPC && kx * PPC + q < 2 * NGR) {
                     if (gather_on) {
                         constexpr int e = kx * PPC + q;  // piece number within this wave's 2 * NGR
-                        const int plane = 2 * (wave - 2) + e / NGR;
-                        constexpr int g = e % NGR;
-                        const float* src = a.src[(jr % NH) >> 1];
-                        const int tn = jr < NH ? n : nn, ty0 = jr < NH ? y0 : ny0, tx0 = jr < NH ? x0 : nx0;
-                        if constexpr (KSR == KS0) h0.stage_plane(g, plane, other, src, jr & 1, a.img_stride, a.pitch, tn, ty0, tx0);
-                        else h3.stage_plane(g, plane, other, src, jr & 1, a.img_stride, a.pitch, tn, ty0, tx0);
+                        constexpr int pl = e / NGR, g = e % NGR;
+                        if constexpr (KSR == KS0) lds_dma16<0>(g_org[pl], h0.off[g], g_dst[pl] + g * 1024);
+                        else lds_dma16<0>(g_org[pl], h3.off[g], g_dst[pl] + g * 1024);
                     }
                 }
                 constexpr int first = col_items_before(KS, KSN, same_half, q, CAP), last = col_items_before(KS, KSN, same_half, q + 1, CAP);
@@ -1584,7 +1598,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
                         const char* p = abase + (it.idx * TWH + kx + 1) * 16 + (it.lo ? 2 * PS : 0);
                         if constexpr (it.lo) al[par ^ 1][it.idx] = *(const f16x8*)p; else ah[par ^ 1][it.idx] = *(const f16x8*)p;
                     } else {
-                        read_b(par ^ 1, it.idx, P::col_tap0(c + 1) + it.idx, it.lo);
+                        read_b(par ^ 1, it.idx, it.lo);
                     }
                 });
                 __builtin_amdgcn_sched_barrier(0);
@@ -1605,7 +1619,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
             if constexpr (j == 0 && last_of_half) { if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, pulled); }
             if (weight_wave || last_of_half) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(a.dbg & 16)) __builtin_amdgcn_s_barrier();  // (bit 4: timing experiment without the column barrier)
             asm volatile("" ::: "memory");
         });
 
@@ -1627,8 +1641,6 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
         stage_epilogue<TH, T, 1, FINAL, OUT_U8, 1, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
         if (!have_next) break;
         n = nn; x0 = nx0; y0 = ny0;
-        rbase += NTAPS % kColSlots;
-        if (rbase >= kColSlots) rbase -= kColSlots;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
 }
