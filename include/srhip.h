@@ -214,8 +214,9 @@ int sr_read_feature(sr_ctx* ctx, int which, float* out_host, size_t cap_floats);
 /* Device time of the most recent call, measured with HIP events on the stream
  * the kernels ran on.  stage_ms[5] = conv0, l1, l2, l3, expand stage kernels
  * (enable with sr_set_profiling; off by default -- it inserts events, and the host-pointer
- * entry points then run undivided).  After a pipelined host call total / h2d / d2h are sums
- * over the chunks and sr_read_feature refuses (the maps hold the last chunk only).
+ * entry points then run undivided).  After a pipelined host call total = first kernel start to last
+ * kernel end (chunks overlap on two compute streams), h2d / d2h = sums over the chunks, and
+ * sr_read_feature refuses (the maps hold the last chunks only).
  * h2d / d2h are zero for the *_dev entry points. */
 int sr_set_profiling(sr_ctx* ctx, int enabled);
 int sr_last_timing(sr_ctx* ctx, double* total_ms, double stage_ms[5], double* h2d_ms,

@@ -268,6 +268,7 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         c->cus = prop.multiProcessorCount;
         c->clock_mhz = prop.clockRate / 1000;
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
         for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
@@ -333,7 +334,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
                 }
             c->off_bias[4] = push(eb);
         }
-        HIPCHK(c, hipMalloc((void**)&c->d_queue, 5 * 8 * sizeof(int)));
+        for (auto& w : c->ws) HIPCHK(c, hipMalloc((void**)&w.d_queue, 5 * 8 * sizeof(int)));
+
         HIPCHK(c, hipMalloc((void**)&c->d_params, host.size() * sizeof(float)));
         HIPCHK(c, hipMemcpy(c->d_params, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
         return SR_OK;
@@ -351,9 +353,13 @@ void sr_destroy(sr_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     sr_comm_release(c);
-    for (auto& p : c->d_feat) if (p) (void)hipFree(p);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (auto& w : c->ws) {
+        for (auto& p : w.d_feat) if (p) (void)hipFree(p);
+        if (w.d_queue) (void)hipFree(w.d_queue);
+    }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->d_params) (void)hipFree(c->d_params);
-    if (c->d_queue) (void)hipFree(c->d_queue);
     for (auto& p : c->d_in) if (p) (void)hipFree(p);
     for (auto& p : c->d_out) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -439,25 +445,25 @@ namespace {
 // (Re)allocate the four zero-bordered feature maps for n images of H x W and make
 // sure every border pixel is zero.  Kernels only store inside [0,H) x [0,W), so the
 // borders stay clean until the geometry changes.
-int ensure_features(sr_ctx* c, int n, int H, int W, int tiles_x, hipStream_t s) {
+int ensure_features(sr_ctx* c, sr_ctx::Workspace& w, int n, int H, int W, int tiles_x, hipStream_t s) {
     const int pitch = tiles_x * 32 + 2 * kFeatPad;
     const long rows = (long)H + kFeatPad + kFeatPadBottom;
     const long img_stride = rows * pitch;
     const size_t npx = (size_t)n * img_stride + (size_t)kFeatPad * pitch + 64;  // slack for the row above image 0
-    if (npx > c->feat_cap_px) {
-        for (auto& p : c->d_feat) {
+    if (npx > w.feat_cap_px) {
+        for (auto& p : w.d_feat) {
             if (p) HIPCHK(c, hipFree(p));
             p = nullptr;
         }
-        c->feat_cap_px = 0; c->geo_n = 0;
-        for (auto& p : c->d_feat) HIPCHK(c, hipMalloc((void**)&p, npx * 32 * sizeof(float)));
-        c->feat_cap_px = npx;
+        w.feat_cap_px = 0; w.geo_n = 0;
+        for (auto& p : w.d_feat) HIPCHK(c, hipMalloc((void**)&p, npx * 32 * sizeof(float)));
+        w.feat_cap_px = npx;
     }
-    if (c->geo_n != n || c->geo_h != H || c->geo_w != W) {
-        for (auto& p : c->d_feat) HIPCHK(c, hipMemsetAsync(p, 0, c->feat_cap_px * 32 * sizeof(float), s));
-        c->geo_n = n; c->geo_h = H; c->geo_w = W;
+    if (w.geo_n != n || w.geo_h != H || w.geo_w != W) {
+        for (auto& p : w.d_feat) HIPCHK(c, hipMemsetAsync(p, 0, w.feat_cap_px * 32 * sizeof(float), s));
+        w.geo_n = n; w.geo_h = H; w.geo_w = W;
     }
-    c->pitch = pitch; c->img_stride = img_stride;
+    w.pitch = pitch; w.img_stride = img_stride;
     return SR_OK;
 }
 
@@ -476,8 +482,9 @@ int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
 // of the n images are produced; each earlier stage computes just the extra rows
 // the later ones read (f +-5, l1 +-3, l2 +-2, l3 +-1 around the band).
 int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top,
-                 int halo_bot, void* d_out, bool out_u8, hipStream_t s) {
-    if (!c || !d_img || !d_out) return SR_E_INVALID;
+                 int halo_bot, void* d_out, bool out_u8, hipStream_t s, int slot) {
+    if (!c || !d_img || !d_out || slot < 0 || slot > 1) return SR_E_INVALID;
+    sr_ctx::Workspace& ws = c->ws[slot];
     if (n <= 0 || H <= 0 || W <= 0) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET) {  // bilinear_net / downsample_net: one elementwise kernel
@@ -499,7 +506,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
     const int top = halo_top, bot = H - halo_bot;
     static const int margin[5] = {5, 3, 2, 1, 0};
     const int tiles_x = (W + 31) / 32;
-    int rc = ensure_features(c, n, H, W, tiles_x, s);
+    int rc = ensure_features(c, ws, n, H, W, tiles_x, s);
     if (rc != SR_OK) return rc;
     // tile height: 8 rows when that still gives every CU two workgroups, else 4
     const long tiles8 = (long)n * tiles_x * ((bot - top + 7) / 8);
@@ -510,11 +517,11 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
     const bool prof = c->profiling;
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
     float* feat[4];
-    for (int k = 0; k < 4; ++k) feat[k] = c->d_feat[k] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
+    for (int k = 0; k < 4; ++k) feat[k] = ws.d_feat[k] + ((size_t)kFeatPad * ws.pitch + kFeatPad) * 32;
     // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent), 4-row tiles (small
     // images) the first form; the two are bit-identical.  SRHIP_PIPE=none forces the first form everywhere (A/B runs).
     const bool pipe = c->env_pipe;
-    HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of the persistent kernels
+    HIPCHK(c, hipMemsetAsync(ws.d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of the persistent kernels
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
         int y0 = top - margin[st], y1 = bot + margin[st];
@@ -527,7 +534,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
             Conv0Args a{};
             a.img = d_img; a.wpack = P + c->off_w0; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
             a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
-            a.pitch = c->pitch; a.img_stride = c->img_stride;
+            a.pitch = ws.pitch; a.img_stride = ws.img_stride;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
             a.n_tiles = nblk;
@@ -535,7 +542,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
         } else {
             StageArgs a{};
             float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
-            a.pitch = c->pitch; a.img_stride = c->img_stride;
+            a.pitch = ws.pitch; a.img_stride = ws.img_stride;
             switch (st) {
                 case 1: a.src[0] = f; a.dst = l1; break;
                 case 2: a.src[0] = f; a.src[1] = l1; a.dst = l2; break;
@@ -549,7 +556,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
             a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
             a.H = H; a.W = W; a.img_ch = img_ch;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
-            a.n_img = n; a.queue = c->d_queue + st * 8;
+            a.n_img = n; a.queue = ws.d_queue + st * 8;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
             set_tile_order(a, c->env_bw >= 0 ? c->env_bw : kAutoBlockWidth);
             a.dbg = c->env_dbg;
@@ -708,21 +715,26 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
         }
         return SR_OK;
     };
+    // chunk i computes on stream i % 2 with workspace i % 2: consecutive chunks' stage launches overlap (the tail of one
+    // launch -- its last, partly filled round of workgroups -- runs beside the head of the other stream's next launch;
+    // measured at 1080p, one stream: five bands cost 19 % more kernel time than the undivided pass)
+    auto cstream = [&](int i) { return (slots == 2 && (i & 1)) ? c->stream2 : c->stream; };
     auto issue_front = [&](int i) -> int {  // upload + kernels of chunk i
         const Chunk& k = plan[i];
         const int sl = i % slots;
+        hipStream_t cs = cstream(i);
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->copy_in, ev(i - 2, 3), 0));  // slot's previous reader
         HIPCHK(c, hipEventRecord(ev(i, 0), c->copy_in));
         int rc = copy_images(k, true, sl);
         if (rc != SR_OK) return rc;
         HIPCHK(c, hipEventRecord(ev(i, 1), c->copy_in));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, ev(i, 1), 0));
-        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, ev(i - 2, 4), 0));   // slot's previous download
-        HIPCHK(c, hipEventRecord(ev(i, 2), c->stream));
+        HIPCHK(c, hipStreamWaitEvent(cs, ev(i, 1), 0));
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(cs, ev(i - 2, 4), 0));   // slot's previous download
+        HIPCHK(c, hipEventRecord(ev(i, 2), cs));
         rc = sr_run_stack(c, c->d_in[sl], img_u8, img_ch, k.n, k.h_ext, w, k.halo_top, k.halo_bot, c->d_out[sl],
-                          out_u8, c->stream);
+                          out_u8, cs, sl);
         if (rc != SR_OK) return rc;
-        HIPCHK(c, hipEventRecord(ev(i, 3), c->stream));
+        HIPCHK(c, hipEventRecord(ev(i, 3), cs));
         return SR_OK;
     };
     auto issue_back = [&](int i) -> int {  // download of chunk i
@@ -739,14 +751,16 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     }
     // drain everything before returning, ALSO on failure: copies into / out of the caller's buffers and kernels on
     // the context's stream must not be in flight once the call has returned
-    const hipError_t e1 = hipStreamSynchronize(c->copy_in), e2 = hipStreamSynchronize(c->stream), e3 = hipStreamSynchronize(c->copy_out);
+    const hipError_t e1 = hipStreamSynchronize(c->copy_in), e2 = hipStreamSynchronize(c->stream), e4 = hipStreamSynchronize(c->stream2),
+                     e3 = hipStreamSynchronize(c->copy_out);
     if (rc != SR_OK) return rc;
-    HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
+    HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e4); HIPCHK(c, e3);
     double h2d = 0, ker = 0, d2h = 0;
     for (int i = 0; i < nch; ++i) {
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, ev(i, 0), ev(i, 1))); h2d += ms;
-        HIPCHK(c, hipEventElapsedTime(&ms, ev(i, 2), ev(i, 3))); ker += ms;
+        // chunks overlap on two compute streams: kernel time = first kernel start -> last kernel end
+        HIPCHK(c, hipEventElapsedTime(&ms, ev(0, 2), ev(i, 3))); ker = std::max(ker, (double)ms);
         HIPCHK(c, hipEventElapsedTime(&ms, ev(i, 3), ev(i, 4))); d2h += ms;  // includes waiting for the copy engine
     }
     c->h2d_ms = h2d; c->total_ms = ker; c->d2h_ms = d2h;
@@ -870,11 +884,11 @@ int sr_upscale_rgba8_batch_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* 
 int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
     if (!c || which < 0 || which > 3 || !out_host) return SR_E_INVALID;
     const size_t nf = (size_t)c->last_h * c->last_w * 32;
-    if (nf == 0 || cap_floats < nf || !c->d_feat[which]) return SR_E_INVALID;
+    if (nf == 0 || cap_floats < nf || !c->ws[0].d_feat[which]) return SR_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
-    const float* src = c->d_feat[which] + ((size_t)kFeatPad * c->pitch + kFeatPad) * 32;
-    HIPCHK(c, hipMemcpy2D(out_host, (size_t)c->last_w * 128, src, (size_t)c->pitch * 128, (size_t)c->last_w * 128,
+    const float* src = c->ws[0].d_feat[which] + ((size_t)kFeatPad * c->ws[0].pitch + kFeatPad) * 32;
+    HIPCHK(c, hipMemcpy2D(out_host, (size_t)c->last_w * 128, src, (size_t)c->ws[0].pitch * 128, (size_t)c->last_w * 128,
                           c->last_h, hipMemcpyDeviceToHost));
     if (c->precision == SR_PRECISION_SPLIT_F16) {  // pixel = 32 hi halves + 32 lo halves -> 32 f32, in place
         for (size_t p = 0; p < (size_t)c->last_h * c->last_w; ++p) {

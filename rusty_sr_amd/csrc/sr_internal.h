@@ -19,11 +19,17 @@ struct sr_ctx {
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;
-    float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3 (zero-bordered, see sr_kernels.h)
-    size_t feat_cap_px = 0;       // allocated padded pixels per map
-    int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
-    int pitch = 0; long img_stride = 0;
-    int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
+    // Device workspace of one pass of the conv stack.  Two of them: the host pipeline (run_host) alternates chunks between
+    // two compute streams so that the tail of one chunk's stage launches overlaps the head of the next chunk's; every
+    // other entry point uses ws[0] only (ws[1] is allocated on first use).
+    struct Workspace {
+        float* d_feat[4] = {nullptr, nullptr, nullptr, nullptr};  // f, l1, l2, l3 (zero-bordered, see sr_kernels.h)
+        size_t feat_cap_px = 0;       // allocated padded pixels per map
+        int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
+        int pitch = 0; long img_stride = 0;
+        int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
+    } ws[2];
+    hipStream_t stream2 = nullptr;    // second compute stream of the host pipeline
     // host-pointer entry points: two in / out slots so that chunk i+1 uploads and chunk i-1
     // downloads while chunk i computes (run_host)
     void* d_in[2] = {nullptr, nullptr};  size_t in_cap[2] = {0, 0};
@@ -64,6 +70,6 @@ struct sr_ctx {
 
 // The whole conv stack on device buffers (sr_api.cpp): rows [halo_top, H - halo_bot) of each image are produced.
 int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
-                 void* d_out, bool out_u8, hipStream_t s);
+                 void* d_out, bool out_u8, hipStream_t s, int slot = 0);
 int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes);
 void sr_comm_release(sr_ctx* c);  // sr_comm.cpp: destroy the communicator and its buffers (called by sr_destroy)
