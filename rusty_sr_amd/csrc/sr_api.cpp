@@ -57,11 +57,12 @@ void split_half_host(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((v - (float)hi) * 2048.0f);
 }
 // The expand node's 3 f^2 channels ((dy*f+dx)*3+c, network.rs:39) are laid out in whole RGB
-// triples, 10 per 32-lane N-tile: lane j < 30 of tile nt carries channel 3*(10 nt + j/3) + j%3.
-// Returns that channel, or -1 for an unused lane.
+// triples, 10 per 32-lane N-tile and 5 per 16-lane DPP row (lanes 15 and 31 idle), so that the u8 packing of the
+// last kernel gathers G and B from the two lanes above R with row_shl DPP moves and never crosses a row:
+// lane j of tile nt carries channel 3*(10 nt + 5 (j/16) + (j%16)/3) + (j%16)%3.  Returns that channel, or -1.
 int expand_channel(int f, int nt, int j) {
-    const int tr = nt * 10 + j / 3;
-    return (j < 30 && tr < f * f) ? tr * 3 + j % 3 : -1;
+    const int jj = j % 16, tr = nt * 10 + 5 * (j / 16) + jj / 3;
+    return (jj < 15 && tr < f * f) ? tr * 3 + jj % 3 : -1;
 }
 int expand_tiles(int f) { return (f * f + 9) / 10; }
 

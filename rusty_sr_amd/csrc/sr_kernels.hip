@@ -817,15 +817,16 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
                 for (int r = 0; r < 16; ++r) acc[m][r] = acc[m][r] + accx[m][r] * (1.0f / kLoScale);
         }
         // Expand (network.rs:39): out[f y+dy][f x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
-        // Lane i < 30 of N-tile nt owns colour c = i % 3 of sub-pixel triple tr = 10 nt + i / 3
-        // (dy = tr / f, dx = tr % f); the host packs the weights in that order.
+        // Lane i of N-tile nt (15 of every 16 lanes) owns colour c = (i % 16) % 3 of sub-pixel triple
+        // tr = 10 nt + 5 (i / 16) + (i % 16) / 3 (dy = tr / f, dx = tr % f); the host packs the weights in that order
+        // (sr_api.cpp expand_channel): a triple never straddles a 16-lane DPP row.
         const int OW = a.W * FACTOR;
         const int h_band = a.y_end - a.y_begin;
-        const int tl = i / 3, c = i - 3 * tl;
+        const int jj = i & 15, tl = 5 * (i >> 4) + jj / 3, c = jj % 3;
 #pragma unroll
         for (int nt = 0; nt < NTN; ++nt) {
             const int tr = nt * 10 + tl;
-            const bool valid = i < 30 && tr < FACTOR * FACTOR;
+            const bool valid = jj < 15 && tr < FACTOR * FACTOR;
             const int trc = valid ? tr : 0;
             const int dy = trc / FACTOR, dx = trc - dy * FACTOR;
 #pragma unroll
@@ -845,17 +846,20 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
                         });
                     }
                 } else {
-                    // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255;
-                    // the lane holding c == 0 gathers G and B from its two neighbours
+                    // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255.  Every lane shifts its byte to
+                    // its place in the pixel (8 c bits); the lane holding R then ORs in the two lanes above it with row_shl
+                    // DPP moves -- pure VALU (a __shfl_down is a ds_bpermute: LDS crossbar + an lgkmcnt wait per row)
                     uint32_t* base = (uint32_t*)a.out + opx;
                     const bool writer = valid && c == 0;
+                    const uint32_t sh = 8u * (uint32_t)c;
                     for_each_acc_row([&](int r, int row) {
                         float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(av[r], bias[nt])), 0.5f));
                         q = fminf(fmaxf(q, 0.0f), 255.0f);
-                        const uint32_t qi = (uint32_t)q;
-                        const uint32_t g = __shfl_down(qi, 1), b = __shfl_down(qi, 2);
+                        const uint32_t qs = (uint32_t)q << sh;
+                        const uint32_t g = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qs, 0x101, 0xF, 0xF, true);  // row_shl:1
+                        const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qs, 0x102, 0xF, 0xF, true);  // row_shl:2
                         if (writer && (full_x || x0 + 4 * h + row < a.W))
-                            base[row * FACTOR] = qi | (g << 8) | (b << 16) | 0xff000000u;
+                            base[row * FACTOR] = qs | g | b | 0xff000000u;
                     });
                 }
             }
