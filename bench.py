@@ -130,14 +130,44 @@ def roofline_of(stage_ms, rows, W, precision):
     return k, ach, peak
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU pod usually owns a
+    fraction of its host: the round-2 box reports 256 logical CPUs and a quota of 16).  Oversubscribing the quota with 256
+    OpenMP threads gets the process throttled, so the CPU baseline runs on this many threads and says so."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.999)))
+    return n, quota
+
+
 def cpu_baseline(params, px_u8, budget_s=10.0):
     """The reference's CPU path cannot be built here (Rust, un-vendored crates): two ports of it are timed on this
     host instead, on a bounded sample of the same workload -- (a) the C oracle (a correctness oracle: fixed summation
     order, no FMA; all threads and one thread), (b) the same graph on torch-CPU / oneDNN with all cores
     (oracle/torch_ref.py; checked against (a) in tests/test_cpu_baseline.py).  `value` is the FASTER of the two."""
+    import ctypes
     import oracle
     h, w, _ = px_u8.shape
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cpus()
+    gomp = None
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(cores)
+    except Exception:
+        pass
     x = oracle.img_to_data(px_u8)
     oracle.forward(params, x[:32], native=True)  # warm-up: builds the -march=native copy, spins up OpenMP
     t0 = time.perf_counter()
@@ -154,11 +184,9 @@ def cpu_baseline(params, px_u8, budget_s=10.0):
         model = "unknown"
     legs = {"c_oracle": {"value": round(rows * w * 9 / 1e6 / dt, 3), "unit": "output MP/s", "cores": cores,
                          "sample": f"top {rows} rows of the {w}x{h} workload image, f32 in/out, second of two passes, OpenMP on {cores} "
-                                   f"threads (oracle/sr_oracle.c, gcc -O3 -march=native -ffp-contract=off); "
+                                   f"threads = the CPUs this container may use (oracle/sr_oracle.c, gcc -O3 -march=native -ffp-contract=off); "
                                    f"GFLOP/s={rows * w * FLOP_PER_PX / dt / 1e9:.1f}"}}
     try:  # also one thread (closest to what alumina 0.1.1 does for n = 1), on a ~4 s sample
-        import ctypes
-        gomp = ctypes.CDLL("libgomp.so.1")
         gomp.omp_set_num_threads(1)
         try:
             t0 = time.perf_counter()
@@ -178,6 +206,7 @@ def cpu_baseline(params, px_u8, budget_s=10.0):
         import torch
         from oracle.torch_ref import TorchNet
         net = TorchNet(params)
+        torch.set_num_threads(cores)
         nthr = torch.get_num_threads()
         net.forward(x[None, :128])
         t0 = time.perf_counter()
@@ -198,6 +227,7 @@ def cpu_baseline(params, px_u8, budget_s=10.0):
     best_leg = max((k for k in ("c_oracle", "torch_cpu") if "value" in legs[k]), key=lambda k: legs[k]["value"])
     return {"value": legs[best_leg]["value"], "unit": "output MP/s", "cores": legs[best_leg]["cores"], "kind": "port",
             "leg": best_leg, "sample": legs[best_leg]["sample"], "legs": legs, "cpu": model,
+            "host_logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota,
             "single_thread": legs.get("c_oracle_1thread"),
             "scaling_c_oracle": (round(legs["c_oracle"]["value"] / legs["c_oracle_1thread"]["value"], 1)
                                  if "c_oracle_1thread" in legs else None)}

@@ -252,7 +252,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[5][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"dbg", "SRHIP_DBG"}, {"cols", "SRHIP_COLS"}};
+    static const char* const kSwitch[6][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"dbg", "SRHIP_DBG"}, {"cols", "SRHIP_COLS"},
+                                              {"bands", "SRHIP_BANDS"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
     {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
@@ -393,6 +394,8 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
         }
     } else if (!strcmp(key, "pipe")) { // "none": first form of the stage kernels everywhere
         c->env_pipe = strcmp(v, "none") != 0;
+    } else if (!strcmp(key, "bands")) {  // host pipeline: row bands of one large image ("" / "0": automatic)
+        c->env_bands = *v ? atoi(v) : 0;
     } else if (!strcmp(key, "cols")) {  // "0": split-half mode runs the step form of the pipe kernel instead of the column form
         c->env_cols = strcmp(v, "0") != 0;
     } else if (!strcmp(key, "dbg")) {  // timing experiments that BREAK the results (StageArgs::dbg); never set outside scripts/
@@ -636,8 +639,12 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
     const int span = y_hi - y_lo;
     int bands = 1;
     if (pipe && n == 1 && c->graph == SR_GRAPH_SR_NET && (size_t)span * w >= ((size_t)1 << 19)) {
-        bands = span / 192;  // >= 192 own rows per band keeps the 14 recomputed rows under 7.5 %
+        // measured (scripts/bands_exp.py, page-locked buffers, f32): 1080p 1 / 2 / 4 / 5 / 8 bands = 5.96 / 5.14 / 4.93 / 5.12 / 5.22 ms,
+        // 4K 1 / 4 / 8 / 12 bands = 23.4 / 18.4 / 18.1 / 18.4 ms: few bands expose the last download, many pay 14 recomputed rows
+        // and five more launches each
+        bands = span / 256;
         if (bands > 8) bands = 8;
+        if (c->env_bands > 0) bands = std::min(c->env_bands, span / (2 * SR_HALO));  // sr_set_experiment("bands")
     }
     const size_t img0_in = (size_t)deal.first * in_img, img0_out = (size_t)deal.first * out_img;
     if (bands >= 2) {
