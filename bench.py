@@ -79,6 +79,9 @@ def kernel_matches(name, stage, precision):
     if stage == 0:
         return name.startswith("void conv0_kernel<8, ") and name[name.index("<") + 1:name.rindex(">")].split(", ")[-1] == str(prec)
     nsrc, ks = STAGE_SHAPE[stage]
+    if f"conv_stage_col_kernel<{nsrc}, {ks}, " in name:  # column form: <NSRC, KS0, FINAL, IMG_U8, OUT_U8, FACTOR>, split-half mode only
+        args = name[name.index("<") + 1:name.rindex(">")].split(", ")
+        return prec == 1 and int(args[5]) == 3
     if f"conv_stage_pipe_kernel<{nsrc}, {ks}, " in name:
         args = name[name.index("<") + 1:name.rindex(">")].split(", ")
         return int(args[5]) == prec and int(args[6]) == 3
@@ -105,7 +108,7 @@ def pmc_entry(stage, H, W, precision):
     if not d:
         return None
     names = [n for n in d if kernel_matches(n, stage, precision)]
-    names.sort(key=lambda n: 0 if "pipe" in n else 1)  # the form the engine runs at this size
+    names.sort(key=lambda n: 0 if "_col_" in n else 1 if "pipe" in n else 2)  # the form the engine runs at this size
     return d[names[0]] if names else None
 
 
@@ -414,7 +417,8 @@ def main():
             pe = pmc_entry(k, H, W, args.precision) if world == 1 else None
             result["roofline"] = {
                 "bound": "mfma",
-                "kernel": f"stage {k} (conv_stage_pipe_kernel<{STAGE_SHAPE[k][0]}, {STAGE_SHAPE[k][1]}, ...>)" if k else "conv0_kernel",
+                "kernel": (f"stage {k} (conv_stage_{'pipe' if args.precision == 'f32' else 'col'}_kernel<{STAGE_SHAPE[k][0]}, {STAGE_SHAPE[k][1]}, ...>)"
+                           if k else "conv0_kernel"),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": pmc_traffic(k, H, W, args.precision) if world == 1 else None,
                 "avg_launch_ms": round(float(stage_ms[k]), 4),

@@ -9,9 +9,9 @@ export TMPDIR=/tmp
 TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-BENCH="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline $*"
+BENCH="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline --no-configs $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- \
-    python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_trace.log" 2>&1
+    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-configs "$@" > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/pmc_sq" -o p -- $BENCH > "$OUT/bench_pmc_sq.log" 2>&1
 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_LDS_UNALIGNED_STALL \

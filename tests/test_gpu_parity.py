@@ -239,7 +239,7 @@ def test_full_size_properties_1080p(engines, params, H, W):
     assert torch.equal(out8[..., :3], q) and bool((out8[..., 3] == 255).all())
 
 
-@pytest.mark.parametrize("h,w", [(1080, 1920), (577, 911), (399, 1400), (2000, 270)])
+@pytest.mark.parametrize("h,w", [(1080, 1920), (577, 911), (523, 1100), (2000, 270)])
 def test_host_pipeline_bands_are_bit_identical(engines, h, w):
     """sr_upscale_* on host pointers splits a large image into row bands (upload / kernels /
     download overlap); the result must equal the undivided pass bit for bit, f32 and u8,
