@@ -525,7 +525,6 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
     // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent), 4-row tiles (small
     // images) the first form; the two are bit-identical.  SRHIP_PIPE=none forces the first form everywhere (A/B runs).
     const bool pipe = c->env_pipe;
-    HIPCHK(c, hipMemsetAsync(ws.d_queue, 0, 5 * 8 * sizeof(int), s));  // tile-queue heads of the persistent kernels
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
         int y0 = top - margin[st], y1 = bot + margin[st];
@@ -542,6 +541,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
             a.n_tiles = nblk;
+            a.queue_reset = ws.d_queue;
             HIPCHK(c, sr_launch_conv0(a, th, c->precision, std::min(nblk, 8 * (c->cus > 0 ? c->cus : 256)), img_u8, s));
         } else {
             StageArgs a{};

@@ -29,6 +29,8 @@ struct Conv0Args {
     int tiles_x, tiles_y;
     int n_tiles;          // images * tiles_x * tiles_y; the grid may be smaller (workgroups loop over tiles)
     TileDiv div_tpi, div_tx;
+    int* queue_reset;     // the 5 x 8 tile-queue heads of this call's stage kernels: conv0 is the call's first launch and zeroes
+                          // them (they are first read by stage 1, a later launch of the same stream) -- no memset node per call
 };
 
 struct StageArgs {

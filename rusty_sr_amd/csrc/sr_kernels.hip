@@ -264,6 +264,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     // tile -> XCD mapping does not matter here (measured: no change in kernel time either way)
     for (int k = tid; k < 5 * 8 * 64; k += kThreads) s_w[k] = a.wpack[k];
     if (tid < 16) s_x[NPIX * 3 + tid] = 0.f;
+    if (blockIdx.x == 0 && tid < 40) a.queue_reset[tid] = 0;  // visible to the later launches by stream order
     // img_to_data (main.rs:170) is u8 / 255 with a true division; one table entry per byte value replaces
     // ~10 VALU instructions per sample (the f32 MFMA shares the vector ALU)
     __shared__ float s_lut[256];

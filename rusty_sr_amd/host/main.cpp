@@ -3,8 +3,8 @@
 //
 //   rusty_sr <INPUT_FILE> <OUTPUT_FILE> [-p imagenet|imagenetlinear|anime|bilinear] [-c FILE] [-d]
 //
-// Differences from the reference, all outside the hot path: own codecs (PNG over zlib,
-// baseline JPEG, PPM/PGM, BMP in; PNG out -- the reference's `image` crate knows more formats), the `train` sub-command
+// Differences from the reference, all outside the hot path: own codecs (PNG over zlib, baseline + progressive JPEG,
+// PPM/PGM/PBM, BMP in; PNG, JPEG, BMP, PPM out by extension -- the reference's `image` crate also knows GIF, TIFF, WebP, ICO), the `train` sub-command
 // is not part of this build, and three extra options that cannot collide with the
 // reference's (-p -c -d): --device N, --precision f32|split_f16, --timing.
 #include <cstdio>
@@ -58,13 +58,6 @@ std::vector<float> decode_rsr(const unsigned char* blob, size_t len) {
     std::vector<float> p(n);
     if (sr_rsr_decode(blob, len, p.data(), n, &n) != SR_OK) die("ByteVec conversion failed");
     return p;
-}
-
-bool ends_with_png(const std::string& s) {
-    if (s.size() < 4) return false;
-    std::string e = s.substr(s.size() - 4);
-    for (auto& ch : e) ch = (char)tolower(ch);
-    return e == ".png";
 }
 
 }  // namespace
@@ -158,7 +151,13 @@ int main(int argc, char** argv) {
     srpng::Image in;
     std::string err;
     if (!srpng::decode_image_file(pos[0], in, err)) die("Error opening input image file. (" + err + ")");  // main.rs:164
-    if (!ends_with_png(pos[1])) die("Could not write output file (only .png output is supported by this build)");
+    {   // `.save()` picks the container from the extension (main.rs:175): refuse an unknown one BEFORE spending GPU time
+        const size_t dot = pos[1].find_last_of('.');
+        std::string ext = dot == std::string::npos ? "" : pos[1].substr(dot + 1);
+        for (auto& ch : ext) ch = (char)tolower((unsigned char)ch);
+        if (ext != "png" && ext != "jpg" && ext != "jpeg" && ext != "bmp" && ext != "ppm")
+            die("Could not write output file (this build writes .png, .jpg, .bmp and .ppm)");
+    }
     if (graph == SR_GRAPH_DOWNSAMPLE && (in.w < 3 || in.h < 3)) die("input image is smaller than one 3x3 pooling block");
 
     const int ow = graph == SR_GRAPH_DOWNSAMPLE ? in.w / 3 : in.w * 3, oh = graph == SR_GRAPH_DOWNSAMPLE ? in.h / 3 : in.h * 3;
@@ -179,7 +178,7 @@ int main(int argc, char** argv) {
     }
     printf(" Writing file...");
     fflush(stdout);
-    if (!srpng::encode_file(pos[1], out, ow, oh, err)) die("Could not write output file (" + err + ")");  // main.rs:175
+    if (!srpng::encode_image_file(pos[1], out, ow, oh, err)) die("Could not write output file (" + err + ")");  // main.rs:175
     puts(" Done");
     sr_host_free(pinned);
     for (sr_ctx* c : ctxs) sr_destroy(c);

@@ -404,9 +404,56 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
     return ok;
 }
 
+// `.save(path)` by extension (reference main.rs:175)
+bool encode_image_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err) {
+    std::string ext;
+    const size_t dot = path.find_last_of('.');
+    if (dot != std::string::npos) ext = path.substr(dot + 1);
+    for (auto& ch : ext) ch = (char)tolower((unsigned char)ch);
+    if (ext == "png") return encode_file(path, rgba, w, h, err);
+    if (ext == "jpg" || ext == "jpeg") return encode_jpeg_file(path, rgba, w, h, err);
+    if (ext != "bmp" && ext != "ppm") { err = "unsupported output format '." + ext + "' (this build writes .png, .jpg, .bmp, .ppm)"; return false; }
+    if (w <= 0 || h <= 0 || !rgba) { err = "empty image"; return false; }
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { err = "cannot create file"; return false; }
+    bool ok = true;
+    if (ext == "ppm") {
+        ok = fprintf(f, "P6\n%d %d\n255\n", w, h) > 0;
+        std::vector<uint8_t> row((size_t)w * 3);
+        for (int y = 0; y < h && ok; ++y) {
+            for (int x = 0; x < w; ++x) memcpy(&row[(size_t)x * 3], rgba + ((size_t)y * w + x) * 4, 3);
+            ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+        }
+    } else {  // BMP: BITMAPINFOHEADER, 32 bits per pixel BGRA, bottom-up
+        const uint64_t img = (uint64_t)w * h * 4;
+        if (img + 54 > 0xffffffffull) { fclose(f); err = "image too large for BMP"; return false; }
+        uint8_t hd[54] = {'B', 'M'};
+        auto le32 = [&](int o, uint32_t v) { hd[o] = (uint8_t)v; hd[o + 1] = (uint8_t)(v >> 8); hd[o + 2] = (uint8_t)(v >> 16); hd[o + 3] = (uint8_t)(v >> 24); };
+        le32(2, (uint32_t)(54 + img)); le32(10, 54); le32(14, 40); le32(18, (uint32_t)w); le32(22, (uint32_t)h);
+        hd[26] = 1; hd[28] = 32; le32(34, (uint32_t)img); le32(38, 2835); le32(42, 2835);
+        ok = fwrite(hd, 1, 54, f) == 54;
+        std::vector<uint8_t> row((size_t)w * 4);
+        for (int y = h - 1; y >= 0 && ok; --y) {
+            for (int x = 0; x < w; ++x) {
+                const uint8_t* p = rgba + ((size_t)y * w + x) * 4;
+                uint8_t* o = &row[(size_t)x * 4];
+                o[0] = p[2]; o[1] = p[1]; o[2] = p[0]; o[3] = p[3];
+            }
+            ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+        }
+    }
+    fclose(f);
+    if (!ok) err = "short write";
+    return ok;
+}
+
 }  // namespace srpng
 
 extern "C" {
+int srpng_encode_any_rgba8(const char* path, const uint8_t* rgba, int w, int h) {
+    std::string err;
+    return srpng::encode_image_file(path, rgba, w, h, err) ? 0 : -1;
+}
 int srpng_decode_rgba8(const char* path, int* w, int* h, uint8_t** rgba) {
     srpng::Image img; std::string err;
     if (!srpng::decode_file(path, img, err)) return -1;

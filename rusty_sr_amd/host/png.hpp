@@ -2,7 +2,8 @@
 // Stands in for the `image` crate calls of the reference (image::open main.rs:164,
 // DynamicImage::to_rgba().save main.rs:175).  Decodes non-interlaced and Adam7
 // PNGs of colour types 0/2/3/4/6 at 1..16 bits to RGBA8 (16-bit samples keep their
-// high byte; no gamma / colour management, like the reference); encodes RGBA8.
+// high byte; no gamma / colour management, like the reference); encodes RGBA8.  Plus the other containers the CLI
+// reads (JPEG baseline + progressive, PNM, BMP) and writes (PNG, JPEG, BMP, PPM).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -17,6 +18,10 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
 bool decode_jpeg_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
 // image::open stand-in: picks the decoder from the file's magic bytes (PNG, JPEG, PPM/PGM, BMP)
 bool decode_image_file(const std::string& path, Image& out, std::string& err);
+// `.save(path)` stand-in (reference main.rs:175: the image crate picks the container from the extension):
+// .png (RGBA8), .jpg / .jpeg (baseline, quality 75, alpha dropped), .bmp (32-bit), .ppm (binary P6, alpha dropped)
+bool encode_image_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err);
+bool encode_jpeg_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int quality = 75);
 }  // namespace srpng
 
 extern "C" {
@@ -24,5 +29,6 @@ extern "C" {
 int srpng_decode_rgba8(const char* path, int* w, int* h, uint8_t** rgba);  // caller frees with srpng_free
 int srpng_decode_any_rgba8(const char* path, int* w, int* h, uint8_t** rgba);  // PNG / JPEG / PPM / BMP by magic
 int srpng_encode_rgba8(const char* path, const uint8_t* rgba, int w, int h);
+int srpng_encode_any_rgba8(const char* path, const uint8_t* rgba, int w, int h);  // container by extension: png / jpg / bmp / ppm
 void srpng_free(uint8_t* p);
 }

@@ -109,8 +109,7 @@ def test_png_adam7_interlaced(png, tmp_path):
 
 def test_jpeg_baseline_matches_libjpeg(png, tmp_path):
     """image::open (main.rs:164) also takes JPEG.  Baseline / extended-sequential Huffman files
-    decode to within 3 levels of libjpeg (IDCT rounding; same triangle chroma upsampling);
-    progressive files are refused, never mis-decoded."""
+    and progressive files decode to within 3 levels of libjpeg (IDCT rounding; same triangle chroma upsampling)."""
     from PIL import Image
     src = Image.open(os.path.join(GOLDEN, "butterfly_lr.png")).convert("RGB")
     cases = {
@@ -142,15 +141,56 @@ def test_jpeg_baseline_matches_libjpeg(png, tmp_path):
     if p is not None and b"\xff\xdd" in p.read_bytes():
         got, want = png.decode_any(p), np.array(Image.open(p).convert("RGBA"))
         assert np.abs(got.astype(int) - want.astype(int)).max() <= 3
-    p = tmp_path / "prog.jpg"
-    src.save(p, quality=90, progressive=True)
-    with pytest.raises(ValueError):
-        png.decode_any(p)
+    # progressive files (spectral selection + successive approximation, DC / AC first and refinement scans)
+    for name, kw in (("prog444", dict(quality=90, subsampling=0)), ("prog420", dict(quality=75, subsampling=2)),
+                     ("prog_q30", dict(quality=30, subsampling=1)), ("prog_opt", dict(quality=85, subsampling=2, optimize=True))):
+        p = tmp_path / f"{name}.jpg"
+        src.save(p, progressive=True, **kw)
+        assert b"\xff\xc2" in p.read_bytes()
+        got, want = png.decode_any(p), np.array(Image.open(p).convert("RGBA"))
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert got.shape == want.shape and d.max() <= 3 and d.mean() < 0.15, (name, d.max(), d.mean())
+    for (w, h) in ((1, 1), (9, 23), (83, 119)):
+        p = tmp_path / "prog_odd.jpg"
+        src.crop((0, 0, w, h)).save(p, quality=92, subsampling=2, progressive=True)
+        got, want = png.decode_any(p), np.array(Image.open(p).convert("RGBA"))
+        assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).max() <= 3, (w, h)
+    p = tmp_path / "prog_grey.jpg"
+    src.convert("L").save(p, quality=90, progressive=True)
+    got, want = png.decode_any(p), np.array(Image.open(p).convert("RGBA"))
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 2
     p = tmp_path / "trunc.jpg"
     src.save(p, quality=90)
     p.write_bytes(p.read_bytes()[:400])
     with pytest.raises(ValueError):
         png.decode_any(p)
+
+
+def test_output_containers_by_extension(png, tmp_path):
+    """`.save(OUTPUT_FILE)` picks the container from the extension (main.rs:175): .png exact, .bmp / .ppm exact (alpha kept /
+    dropped), .jpg a baseline JFIF file that libjpeg reads back close to the source; anything else is refused."""
+    from PIL import Image
+    L = C.CDLL(PNGLIB)
+    L.srpng_encode_any_rgba8.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    src = np.array(Image.open(os.path.join(GOLDEN, "butterfly_lr.png")).convert("RGBA"))
+    src[..., 3] = 255
+    for (h, w) in ((171, 256), (1, 1), (9, 17)):
+        a = np.ascontiguousarray(src[:h, :w])
+        enc = lambda name: L.srpng_encode_any_rgba8(str(tmp_path / name).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h)
+        assert enc("o.png") == 0 and enc("o.bmp") == 0 and enc("o.ppm") == 0 and enc("o.jpg") == 0 and enc("O.JPEG") == 0
+        np.testing.assert_array_equal(np.array(Image.open(tmp_path / "o.png").convert("RGBA")), a)
+        np.testing.assert_array_equal(np.array(Image.open(tmp_path / "o.bmp").convert("RGBA"))[..., :3], a[..., :3])
+        np.testing.assert_array_equal(np.array(Image.open(tmp_path / "o.ppm").convert("RGB")), a[..., :3])
+        np.testing.assert_array_equal(png.decode_any(tmp_path / "o.bmp")[..., :3], a[..., :3])  # and our own readers agree
+        np.testing.assert_array_equal(png.decode_any(tmp_path / "o.ppm")[..., :3], a[..., :3])
+        back = np.array(Image.open(tmp_path / "o.jpg").convert("RGB")).astype(int)
+        assert Image.open(tmp_path / "o.jpg").format == "JPEG" and back.shape == (h, w, 3)
+        if h * w > 64:
+            mse = np.mean((back - a[..., :3].astype(int)) ** 2)
+            assert 10 * np.log10(255 ** 2 / mse) > 30.0  # quality 75, 4:4:4
+            own = png.decode_any(tmp_path / "o.jpg")[..., :3].astype(int)  # our decoder on our encoder
+            assert np.abs(own - back).max() <= 3
+        assert enc("o.gif") != 0 and enc("noext") != 0
 
 
 def test_pnm_bmp_and_magic_dispatch(png, tmp_path):
@@ -262,5 +302,14 @@ def test_cli_end_to_end(png, tmp_path, params):
     want = oracle.data_to_rgba8(oracle.downsample(oracle.img_to_data(px))[0])
     d = png.decode(out).astype(int) - want.astype(int)
     assert want.shape == (11, 15, 4) and np.abs(d).max() <= 1 and (d != 0).mean() < 1e-2
+    # OUTPUT_FILE's extension picks the container (main.rs:175): a .jpg and a .bmp of the same upscale
+    r = _run(os.path.join(GOLDEN, "butterfly_lr.png"), str(tmp_path / "o.bmp"))
+    assert r.returncode == 0, r.stderr
+    r2 = _run(os.path.join(GOLDEN, "butterfly_lr.png"), str(out))
+    np.testing.assert_array_equal(png.decode_any(tmp_path / "o.bmp")[..., :3], png.decode(out)[..., :3])
+    r = _run(os.path.join(GOLDEN, "butterfly_lr.png"), str(tmp_path / "o.jpg"))
+    assert r.returncode == 0 and (tmp_path / "o.jpg").read_bytes()[:2] == b"\xff\xd8"
+    r = _run(os.path.join(GOLDEN, "butterfly_lr.png"), str(tmp_path / "o.webp"))
+    assert r.returncode == 1 and "Could not write output file" in r.stderr
     r = _run("/nonexistent.png", str(out))
     assert r.returncode == 1 and "Error opening input image file." in r.stderr  # main.rs:164
