@@ -642,7 +642,9 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
         // measured (scripts/bands_exp.py, page-locked buffers, f32): 1080p 1 / 2 / 4 / 5 / 8 bands = 5.96 / 5.14 / 4.93 / 5.12 / 5.22 ms,
         // 4K 1 / 4 / 8 / 12 bands = 23.4 / 18.4 / 18.1 / 18.4 ms: few bands expose the last download, many pay 14 recomputed rows
         // and five more launches each
-        bands = span / 256;
+        // (the split-half mode computes 2.2x faster than the bus drains its output: more, smaller bands start the first download
+        // earlier -- 1080p 4 / 5 / 6 / 8 bands = 3.77 / 2.7-3.4 / 2.82 / 3.05 ms)
+        bands = span / (c->precision == SR_PRECISION_SPLIT_F16 ? 176 : 256);
         if (bands > 8) bands = 8;
         if (c->env_bands > 0) bands = std::min(c->env_bands, span / (2 * SR_HALO));  // sr_set_experiment("bands")
     }
