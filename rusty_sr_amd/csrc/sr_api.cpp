@@ -568,7 +568,8 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
             // slot -- 2 per CU with 8-row tiles, 3 with 4-row tiles -- and pull tiles from the queue
             int grid = nblk;
             if (use_pipe || c->precision == SR_PRECISION_SPLIT_F16) {
-                const int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);
+                int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);
+                if (c->env_dbg & 64) resident = (c->cus > 0 ? c->cus : 256);  // timing experiment: one workgroup per CU
                 if (grid > resident) grid = resident;
             }
             if (use_cols) {

@@ -89,6 +89,14 @@ constexpr int kThreads = 256;
 #ifndef SR_SPLIT_WAVES
 #define SR_SPLIT_WAVES 4
 #endif
+// Timing experiments that BREAK the results on purpose (StageArgs::dbg, scripts/dbg_exp.py, scripts/pmc_quick.sh) exist only in
+// builds with -DSR_EXPERIMENTS (scripts/build_variant.sh dbg -DSR_EXPERIMENTS): in the product every one of these tests is a
+// compile-time false -- a wave-uniform branch per MFMA slot is not free (measured: the column loop lost 10 % to them).
+#ifdef SR_EXPERIMENTS
+#define SR_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define SR_DBG(a, bit) false
+#endif
 #ifndef SR_SPLIT_INTERLEAVE
 #define SR_SPLIT_INTERLEAVE 1  // split-half step loop: operand reads / DMA requests interleaved 1:1 with the MFMAs (0: all in front)
 #endif
@@ -379,7 +387,9 @@ struct TileGeom {
 // software-pipelined operand reads impossible.  vmcnt bookkeeping for these is done by hand (ring_barrier).
 template <int IMM>
 __device__ __forceinline__ void lds_dma16(const void* base, uint32_t voff, uint32_t lds) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+    // (s_nop 3: the base may have been written by a VALU instruction just before the statement -- v_readlane of a spilled SGPR,
+    // v_readfirstlane -- and a VMEM instruction may read such an SGPR only 5 wait states later; the compiler pads nothing inside)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
                  :: "s"(lds), "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
 // The DMA base must sit in SGPRs.  Every caller passes a wave-uniform pointer; this spells it out for the
@@ -1213,7 +1223,7 @@ struct PipeStream {
     __device__ __forceinline__ void begin_step() { step_request(st, ring, a.wpack, wave, lane); }
     // gather instruction number g of the half tile being requested (compile-time after unrolling)
     __device__ __forceinline__ void piece(int g) {
-        if (g < HalfTile<KSN>::G::NG && rq.active && !(a.dbg & 2)) {
+        if (g < HalfTile<KSN>::G::NG && rq.active && !SR_DBG(a, 2)) {
             htn.template stage_one<PREC>(g, rq.buf, rq.src, rq.khalf, a.img_stride, a.pitch, rq.n, rq.y0, rq.x0, wave);
             st.tile_seq = ++st.issued;
         }
@@ -1257,7 +1267,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     H3 h3;
     h0.init(a.pitch, lane);
     if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
-    if (a.dbg & 1) {  // timing experiment: what would contiguous gathers cost?
+    if (SR_DBG(a, 1)) {  // timing experiment: what would contiguous gathers cost?
 #pragma unroll
         for (int g = 0; g < H0::G::NG; ++g) h0.off[g] = (uint32_t)(g * 64 + lane) * 16u;
         if constexpr (NSRC >= 2) {
@@ -1353,7 +1363,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             asm volatile("" ::: "memory");
         }
         TL(5); TL(6); TL(8);
-        if (!(a.dbg & 4))  // timing experiment (bit 2): no epilogue at all
+        if (!SR_DBG(a, 4))  // timing experiment (bit 2): no epilogue at all
         stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
         TL(7);
         if (!st.have_next) break;
@@ -1483,8 +1493,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
     // columns, so the parity runs on across tiles).  While column c executes from registers, bank (c+1) & 1 holds the taps
     // of column c+1 (being read) and bank c & 1 -- column c's own, already consumed -- receives the taps of column c+2.
     auto request_tap = [&](int bank, int t, int g) {  // this wave's KB (hi or lo) of tap g (tile-relative; >= NTAPS: next tile's)
-        const char* src = (const char*)a.wpack + (size_t)(g % NTAPS) * 2048 + wave * 1024;
-        lds_dma16<0>(uniform_ptr(src), (uint32_t)(lane * 16), __builtin_amdgcn_readfirstlane(ring_lds + (5 * bank + t) * 2048 + wave * 1024));
+        const char* src = (const char*)a.wpack + (size_t)(g % NTAPS) * 2048 + (wave & 1) * 1024;
+        lds_dma16<0>(uniform_ptr(src), (uint32_t)(lane * 16), __builtin_amdgcn_readfirstlane(ring_lds + (5 * bank + t) * 2048 + (wave & 1) * 1024));
     };
     // first tile only: half 0 (every wave moves its plane) and the weights of the first two columns
     h0.template stage<1>(lds0, a.src[0], 0, a.img_stride, a.pitch, n, y0, x0, wave);
@@ -1520,7 +1530,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[m][r] = 0.f; accx[m][r] = 0.f; }
         int pulled = 0;
-        if (tid == 0) pulled = atomicAdd(&a.queue[xcd], 1);  // the answer is looked at by the end of half 0
+        // the next tile's number: asked for now, looked at by the end of half 0 -- by a thread of a GATHERING wave, whose next
+        // vmcnt(0) is the end of the half (a weight wave would wait for the atomic's round trip at the end of this column)
+        if (tid == 128) pulled = atomicAdd(&a.queue[xcd], 1);
         int nn = 0, nx0 = 0, ny0 = 0, next = -1;
         bool have_next = false;
         const char* g_org[2] = {nullptr, nullptr};
@@ -1547,6 +1559,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
                     linpx.issue(a, n, y0, x0, tid, dummy);
                 }
                 // the half tile landed with the barrier that ended the previous column: its first column's rows
+                if (!SR_DBG(a, 128))  // (bit 7: timing experiment without these exposed reads)
                 static_for<KS + 1>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     ah[par][r] = *(const f16x8*)(abase + (r * TWH) * 16);
@@ -1573,8 +1586,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
             }
             constexpr int issue_cols = KS - 1;                  // ... spread over all but the last column of half j
             constexpr int PPC = (2 * NGR + issue_cols - 1) / issue_cols;
-            const bool gather_on = !(a.dbg & 2) && (jr < NH || have_next);
-            const bool weights_on = (c + 2 < NCOLS || have_next) && !(a.dbg & 8);
+            const bool gather_on = !SR_DBG(a, 2) && (jr < NH || have_next);
+            const bool weights_on = (c + 2 < NCOLS || have_next) && !SR_DBG(a, 8);
             constexpr int NITEMS = col_item_count(KS, KSN, same_half);
             constexpr int CAP = NITEMS > 6 * KS - 2 ? 2 : 1;
 
@@ -1582,20 +1595,30 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
             // of the next column that are due -- all indices compile-time constants (registers, not scratch)
             auto aux = [&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                if (weight_wave) {
-                    if constexpr (q < KS2) {
-                        constexpr int g2 = (P::col_tap0(c + 2) + q) % NTAPS;  // forced compile-time (the plan's loops must not reach the GPU)
-                        if (weights_on) request_tap(par, q, g2);
-                    }
-                } else if constexpr (kx < issue_cols && q < PPC && kx * PPC + q < 2 * NGR) {
-                    if (gather_on) {
-                        constexpr int e = kx * PPC + q;  // piece number within this wave's 2 * NGR
-                        constexpr int pl = e / NGR, g = e % NGR;
-                        if constexpr (KSR == KS0) lds_dma16<0>(g_org[pl], h0.off[g], g_dst[pl] + g * 1024);
-                        else lds_dma16<0>(g_org[pl], h3.off[g], g_dst[pl] + g * 1024);
+#ifndef SR_COL_NO_DMA_CODE  // (A/B build switch: the column loop without any DMA code -- timing experiment only)
+                // This column's DMA requests, ALL of them behind the first MFMA and behind ONE role branch: a wave-uniform branch per
+                // MFMA slot (the first version) cost the loop 10 % of its cycles, an EXEC-masked branch-free form three times that
+                // (the matrix pipe drains before EXEC may change).
+                if constexpr (q == 0) {
+                    if (weight_wave) {
+                        if (weights_on) static_for<KS2>([&](auto tc) {
+                            constexpr int t = decltype(tc)::value, g2 = (P::col_tap0(c + 2) + t) % NTAPS;  // forced compile-time
+                            request_tap(par, t, g2);
+                        });
+                    } else if constexpr (kx < issue_cols) {
+                        if (gather_on) static_for<PPC>([&](auto ec) {
+                            constexpr int e = kx * PPC + decltype(ec)::value;  // piece number within this wave's 2 * NGR
+                            if constexpr (e < 2 * NGR) {
+                                constexpr int pl = e / NGR, g = e % NGR;
+                                if constexpr (KSR == KS0) lds_dma16<0>(g_org[pl], h0.off[g], g_dst[pl] + g * 1024);
+                                else lds_dma16<0>(g_org[pl], h3.off[g], g_dst[pl] + g * 1024);
+                            }
+                        });
                     }
                 }
+#endif
                 constexpr int first = col_items_before(KS, KSN, same_half, q, CAP), last = col_items_before(KS, KSN, same_half, q + 1, CAP);
+                if (!SR_DBG(a, 32))  // (bit 5: timing experiment without the operand reads -- the MFMAs then run on stale registers)
                 static_for<last - first>([&](auto kc) {
                     constexpr int k = first + decltype(kc)::value;
                     constexpr ColItem it = col_item(KS, KSN, same_half, k);
@@ -1621,10 +1644,10 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
             static_assert(col_items_before(KS, KSN, same_half, 6 * KS, CAP) == NITEMS, "every operand of the next column is requested");
             // end of the column: the weights of column c+2 (requested at its start) have landed; at the end of a half also
             // the next half tile; every LDS read of this column has returned before anybody overwrites what it read
-            if constexpr (j == 0 && last_of_half) { if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, pulled); }
+            if constexpr (j == 0 && last_of_half) { if (tid == 128) *s_next = queue_resolve(a.queue, xcd, ntiles, pulled); }
             if (weight_wave || last_of_half) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!(a.dbg & 16)) __builtin_amdgcn_s_barrier();  // (bit 4: timing experiment without the column barrier)
+            if (!SR_DBG(a, 16)) __builtin_amdgcn_s_barrier();  // (bit 4: timing experiment without the column barrier)
             asm volatile("" ::: "memory");
         });
 
@@ -1642,7 +1665,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
             asm volatile("" ::: "memory");
         }
-        if (!(a.dbg & 4))
+        if (!SR_DBG(a, 4))
         stage_epilogue<TH, T, 1, FINAL, OUT_U8, 1, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
         if (!have_next) break;
         n = nn; x0 = nx0; y0 = ny0;
