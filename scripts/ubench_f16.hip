@@ -92,5 +92,11 @@ int main() {
     run<12, 2, false, 1>("kernel-like offsets + random data, no barrier");
     run<12, 2, true, 1>("kernel-like offsets + random data, barrier");
     run<0, 2, false, 1>("random data, 0 reads");
+    // one workgroup per CU (one wave per SIMD), as in the lone-workgroup ablation of the column kernel
+    run<12, 1, true>("12 MFMA, 12 reads, 1 wave/SIMD + barrier");
+    run<12, 1, false, 1>("random data, kernel-like offsets, 1 wave/SIMD, no barrier");
+    run<12, 1, true, 1>("random data, kernel-like offsets, 1 wave/SIMD, barrier");
+    run<0, 1, true, 1>("random data, 0 reads, 1 wave/SIMD, barrier");
+    run<0, 1, false, 1>("random data, 0 reads, 1 wave/SIMD, no barrier");
     return 0;
 }
