@@ -522,8 +522,30 @@ def main():
             if world > 1:
                 per_rank = [None] * world
                 dist.all_gather_object(per_rank, mine)
+            preview = None
+            if world == 1:
+                # what ONE rank of the 8-way split would do per frame: an interior 270-row band + 7 halo rows either side on this GPU
+                # (the exchange itself needs 8 GPUs; everything else of a rank's step is measured here)
+                ext = torch.from_numpy(synth_u8(3, HC, WC)[810 - 7:1080 + 7]).to(dev)
+                if not u8:
+                    ext = torch.from_numpy(r.img_to_data(ext.cpu().numpy())).to(dev)
+                ob = torch.empty((3 * 270, 3 * WC, 4 if u8 else 3), dtype=dt_in, device=dev)
+                fnb = eng.upscale_band_rgba8_dev if u8 else eng.upscale_band_f32_dev
+                for _ in range(3):
+                    fnb(ext, 7, 7, out=ob)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(ksteps):
+                    fnb(ext, 7, 7, out=ob)
+                torch.cuda.synchronize()
+                ms_b = (time.perf_counter() - t0) / ksteps * 1e3
+                preview = {"rows": 270, "halo_rows": 14, "ms_per_band": round(ms_b, 4),
+                           "eight_bands_in_parallel_would_be": round(9 * HC * WC / 1e6 / (ms_b / 1e3), 1),
+                           "note": "one interior band of the 8-way split on this GPU, without the exchange: a projection, not a measurement of 8 GPUs"}
+                del ext, ob
             if rank == 0:
                 result["config_C"] = {
+                    **({"band_preview": preview} if preview else {}),
                     "workload": f"3840x2160 RGB x3, {args.io}, resident in HBM" + (f", {world} row bands of {HC // world} rows + 7-row halos "
                                 f"(strong scaling; exchange: {exchange})" if world > 1 else ", one GPU"),
                     "value": round(9 * HC * WC / 1e6 / (ms_c / 1e3), 2), "unit": "output MP/s", "ms_per_step": round(ms_c, 4),
