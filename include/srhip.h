@@ -170,12 +170,18 @@ int sr_upscale_band_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels,
  * ranks by whatever means the host has (a file, a socket, an environment variable, torch.distributed);
  * every rank then calls sr_comm_init_rank (collective: returns when all n ranks have joined).
  * One process, n GPUs: sr_comm_init_all on n contexts of distinct devices (ncclCommInitAll; rank = index), then
- * sr_upscale_sharded_*_all drives all bands from the calling thread (grouped exchange, synchronous). */
+ * sr_upscale_sharded_*_all drives all bands from the calling thread (grouped exchange, synchronous).
+ * One process, without RCCL: sr_comm_init_local on n contexts (rank = index; the same device may appear more than
+ * once).  sr_upscale_sharded_*_all then has every context PULL its two halos from the neighbours' bands with
+ * hipMemcpyPeerAsync on its own stream (SDMA over xGMI, peer access enabled where the devices allow it): no
+ * rendezvous, no compute unit spent on the exchange.  The *_dev entry points return SR_E_COMM on such a context
+ * (a lone rank cannot see its neighbours' buffers). */
 #define SR_COMM_ID_BYTES 128
 int sr_comm_available(void);                            /* 1 if librccl could be loaded */
 int sr_comm_unique_id(uint8_t* id, size_t cap);         /* cap >= SR_COMM_ID_BYTES */
 int sr_comm_init_rank(sr_ctx* ctx, const uint8_t* id, size_t id_len, int rank, int nranks);
 int sr_comm_init_all(sr_ctx* const* ctxs, int n);
+int sr_comm_init_local(sr_ctx* const* ctxs, int n);
 void sr_comm_destroy(sr_ctx* ctx);                      /* sr_destroy does this too */
 int sr_comm_rank(sr_ctx* ctx, int* rank, int* nranks);  /* 0 of 1 without a communicator */
 int sr_last_comm_error(sr_ctx* ctx);                    /* ncclResult_t of the last failed RCCL call */

@@ -57,6 +57,7 @@ extern "C" {
     pub fn sr_comm_unique_id(id: *mut u8, cap: usize) -> c_int;
     pub fn sr_comm_init_rank(ctx: *mut SrCtx, id: *const u8, id_len: usize, rank: c_int, nranks: c_int) -> c_int;
     pub fn sr_comm_init_all(ctxs: *const *mut SrCtx, n: c_int) -> c_int;
+    pub fn sr_comm_init_local(ctxs: *const *mut SrCtx, n: c_int) -> c_int;
     pub fn sr_comm_destroy(ctx: *mut SrCtx);
     pub fn sr_comm_rank(ctx: *mut SrCtx, rank: *mut c_int, nranks: *mut c_int) -> c_int;
     pub fn sr_last_comm_error(ctx: *mut SrCtx) -> c_int;

@@ -43,6 +43,7 @@ SYMBOLS = {
     "sr_comm_unique_id": (_i, [_u8p, _sz]),
     "sr_comm_init_rank": (_i, [_vp, _u8p, _sz, _i, _i]),
     "sr_comm_init_all": (_i, [C.POINTER(_vp), _i]),
+    "sr_comm_init_local": (_i, [C.POINTER(_vp), _i]),
     "sr_comm_destroy": (None, [_vp]),
     "sr_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "sr_last_comm_error": (_i, [_vp]),

@@ -8,6 +8,12 @@
 // ncclSend / ncclRecv pair per neighbour (<= 7 * W * 12 B each: latency-bound, one xGMI link per direction),
 // issued on the stream the band's kernels follow on, so no host synchronisation sits between them.
 //
+// A host that drives all its GPUs from ONE process has a second transport (sr_comm_init_local): the neighbour's rows
+// are the caller's own device buffers, so each context pulls its two halos with hipMemcpyPeerAsync on its own stream
+// -- the SDMA engines move <= 322 KB over the xGMI link while no compute unit is taken from the band kernels, and
+// nothing has to rendezvous.  It also lets the whole sharded path run on a one-GPU box (several contexts of one
+// device), which is how tests/ cover it bit for bit.
+//
 // librccl is loaded lazily (dlopen of the SONAME): a process that already holds RCCL -- a torch process -- gets
 // that same instance, a plain C / Rust host gets the system one, and a single-GPU user never needs it at all.
 #include <dlfcn.h>
@@ -111,7 +117,7 @@ int post_exchange(sr_ctx* c, Rccl* R, const void* d_band, int h_band, const Band
 int prepare_band(sr_ctx* c, const void* d_band, int h_band, int w, size_t px_bytes, BandGeom& g, hipStream_t s) {
     if (!c || !d_band || h_band <= 0 || w <= 0) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET) return SR_E_INVALID;
-    if (c->comm_nranks > 1 && !c->comm) return SR_E_COMM;
+    if (c->comm_nranks > 1 && !c->comm && !c->comm_local) return SR_E_COMM;
     if (c->comm_nranks > 1 && h_band < SR_HALO) return SR_E_HALO;  // a neighbour reads SR_HALO rows of this band
     HIPCHK(c, hipSetDevice(c->device));
     g = band_geom(c, h_band, w, px_bytes);
@@ -130,6 +136,7 @@ int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, 
     int rc = prepare_band(c, d_band, h_band, w, u8 ? (size_t)img_ch : 3 * sizeof(float), g, s);
     if (rc != SR_OK) return rc;
     if (c->comm_nranks > 1) {
+        if (c->comm_local) return SR_E_COMM;  // the neighbours' rows are only known to sr_upscale_sharded_*_all
         Rccl* R = rccl();
         if (!R) return SR_E_COMM;
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[0], s));
@@ -158,15 +165,37 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
     if (u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
     for (int k = 0; k < n; ++k)
         if (ctxs[k]->comm_nranks != n || ctxs[k]->comm_rank != k || !d_outs[k]) return SR_E_INVALID;
-    Rccl* R = n > 1 ? rccl() : nullptr;
-    if (n > 1 && !R) return SR_E_COMM;
+    const bool local = ctxs[0]->comm_local;
+    for (int k = 1; k < n; ++k)
+        if (ctxs[k]->comm_local != local) return SR_E_INVALID;
+    Rccl* R = n > 1 && !local ? rccl() : nullptr;
+    if (n > 1 && !local && !R) return SR_E_COMM;
     std::vector<BandGeom> g(n);
     const size_t px = u8 ? (size_t)img_ch : 3 * sizeof(float);
     for (int k = 0; k < n; ++k) {
         rc = prepare_band(ctxs[k], d_bands[k], h_bands[k], w, px, g[k], ctxs[k]->stream);
         if (rc != SR_OK) return rc;
     }
-    if (n > 1) {
+    if (local) {
+        for (int k = 0; k < n; ++k)
+            if (n > 1 && h_bands[k] < SR_HALO) return SR_E_HALO;
+        // every context pulls its halos from the neighbours' bands -- caller buffers that are complete before this
+        // (synchronous) call, so no cross-stream ordering is needed
+        for (int k = 0; k < n && rc == SR_OK; ++k) {
+            sr_ctx* c = ctxs[k];
+            const size_t halo = (size_t)SR_HALO * g[k].row_bytes;
+            char* ext = (char*)c->d_ext;
+            (void)hipSetDevice(c->device);
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[0], c->stream));
+            if (g[k].top)
+                HIPCHK(c, hipMemcpyPeerAsync(ext, c->device, (const char*)d_bands[k - 1] + (size_t)(h_bands[k - 1] - SR_HALO) * g[k].row_bytes,
+                                             ctxs[k - 1]->device, halo, c->stream));
+            if (g[k].bot)
+                HIPCHK(c, hipMemcpyPeerAsync(ext + (size_t)(g[k].top + h_bands[k]) * g[k].row_bytes, c->device, d_bands[k + 1],
+                                             ctxs[k + 1]->device, halo, c->stream));
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[1], c->stream));
+        }
+    } else if (n > 1) {
         NCCLCHK(ctxs[0], R->GroupStart());
         for (int k = 0; k < n && rc == SR_OK; ++k) {
             (void)hipSetDevice(ctxs[k]->device);
@@ -183,6 +212,11 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
         const hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
         if (e != hipSuccess && first == SR_OK) { ctxs[k]->last_hip = (int)e; first = SR_E_HIP; }
     }
+    for (int k = 0; k < n && first == SR_OK && local && n > 1; ++k)
+        if (ctxs[k]->profiling) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ctxs[k]->ev_comm[0], ctxs[k]->ev_comm[1]) == hipSuccess) ctxs[k]->comm_ms = ms;
+        }
     return first;
 }
 
@@ -194,7 +228,7 @@ void sr_comm_release(sr_ctx* c) {
         if (Rccl* R = rccl()) (void)R->CommDestroy((ncclComm_t)c->comm);
         c->comm = nullptr;
     }
-    c->comm_rank = 0; c->comm_nranks = 1;
+    c->comm_rank = 0; c->comm_nranks = 1; c->comm_local = false;
     if (c->d_ext) { (void)hipFree(c->d_ext); c->d_ext = nullptr; c->ext_cap = 0; }
     for (auto& e : c->ev_comm) if (e) { (void)hipEventDestroy(e); e = nullptr; }
 }
@@ -262,6 +296,28 @@ int sr_comm_init_all(sr_ctx* const* ctxs, int n) {
         for (int k = 0; k < n; ++k) ctxs[k]->comm = comms[k];
     }
     for (int k = 0; k < n; ++k) { ctxs[k]->comm_rank = k; ctxs[k]->comm_nranks = n; }
+    return SR_OK;
+}
+
+int sr_comm_init_local(sr_ctx* const* ctxs, int n) {
+    int rc = sr_check_context_set(ctxs, n);
+    if (rc != SR_OK) return rc;
+    for (int k = 0; k < n; ++k) {
+        if (ctxs[k]->graph != SR_GRAPH_SR_NET) return SR_E_INVALID;
+        sr_comm_release(ctxs[k]);
+        HIPCHK(ctxs[k], hipSetDevice(ctxs[k]->device));
+        rc = comm_events(ctxs[k]);
+        if (rc != SR_OK) return rc;
+        for (int j : {k - 1, k + 1}) {  // direct xGMI access to the two neighbours (without it the copy is staged)
+            if (j < 0 || j >= n || ctxs[j]->device == ctxs[k]->device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, ctxs[k]->device, ctxs[j]->device) != hipSuccess || !can) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(ctxs[j]->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { ctxs[k]->last_hip = (int)e; return SR_E_HIP; }
+            (void)hipGetLastError();
+        }
+    }
+    for (int k = 0; k < n; ++k) { ctxs[k]->comm_rank = k; ctxs[k]->comm_nranks = n; ctxs[k]->comm_local = n > 1; }
     return SR_OK;
 }
 

@@ -52,6 +52,7 @@ struct sr_ctx {
     unsigned long long params_hash = 0;  // FNV-1a of the parameter vector: contexts of one sharded call must agree
     // ---- multi-GPU (sr_comm.cpp): one RCCL communicator per context, neighbour halo exchange
     void* comm = nullptr;             // ncclComm_t
+    bool comm_local = false;          // sr_comm_init_local: neighbours are contexts of this process, halos go by peer copy
     int comm_rank = 0, comm_nranks = 1;
     void* d_ext = nullptr; size_t ext_cap = 0;  // band + halo rows, the exchange lands here
     hipEvent_t ev_comm[2] = {nullptr, nullptr};

@@ -302,15 +302,20 @@ def upscale_batch_multi(engines, px: np.ndarray, out: np.ndarray = None) -> np.n
     return out
 
 
-def comm_init_all(engines):
-    """One process, one engine per device: ncclCommInitAll inside libsrhip; engine k becomes rank k."""
+def comm_init_all(engines, transport: str = "rccl"):
+    """One process, several engines; engine k becomes rank k.  transport "rccl": ncclCommInitAll inside libsrhip, one
+    engine per device.  "local": sr_comm_init_local -- halos by peer copy on each engine's own stream, no RCCL, and the
+    same device may carry several engines."""
+    if transport not in ("rccl", "local"):
+        raise ValueError("transport must be 'rccl' or 'local'")
     arr = (C.c_void_p * len(engines))(*[e._ctx for e in engines])
-    _lib.check(_lib.lib().sr_comm_init_all(arr, len(engines)), engines[0]._ctx)
+    fn = _lib.lib().sr_comm_init_all if transport == "rccl" else _lib.lib().sr_comm_init_local
+    _lib.check(fn(arr, len(engines)), engines[0]._ctx)
 
 
 def upscale_sharded_all(engines, bands, outs=None):
     """Bands (torch tensors, band k on engine k's device, rank order) of ONE image -> their output rows, through
-    sr_upscale_sharded_*_all (grouped RCCL halo exchange + band passes, synchronous)."""
+    sr_upscale_sharded_*_all (halo exchange over the transport comm_init_all chose + band passes, synchronous)."""
     import torch
     n = len(engines)
     f = engines[0].factor

@@ -212,6 +212,49 @@ def test_comm_single_rank_and_argument_rules(eng, params):
         other.close()
 
 
+@pytest.mark.parametrize("n,prec", [(2, "f32"), (3, "split_f16"), (8, "f32")])
+def test_sharded_image_through_the_library_on_one_device(params, n, prec):
+    """sr_comm_init_local + sr_upscale_sharded_*_all: the C code of the sharded path itself -- band geometry, halo
+    offsets in the extended buffer, the band passes, the drain -- with n contexts of ONE device, halos by peer copy.
+    Uneven bands (the last one short), u8 and f32, twice through the same contexts: bit-identical to the whole image.
+    (The RCCL transport differs from this only in who moves the 7 rows.)"""
+    import torch
+    import rusty_sr_amd as r
+    from rusty_sr_amd.shard import split_rows
+    H, W = 37 * n + 5, 530
+    px = synth_u8(21, 1, H, W)[0]
+    engs = [r.Engine(params["imagenet"], device=0, precision=prec) for _ in range(n)]
+    try:
+        want = engs[0].upscale_rgba8(px)
+        x = oracle.img_to_data(px)
+        want32 = engs[0].upscale_f32(x)
+        r.comm_init_all(engs, transport="local")
+        assert [e.comm_rank() for e in engs] == [(k, n) for k in range(n)]
+        cuts = split_rows(H, n)
+        bands = [torch.from_numpy(px[a:b]).cuda() for a, b in cuts]
+        for _ in range(2):
+            outs = r.upscale_sharded_all(engs, bands)
+            np.testing.assert_array_equal(np.concatenate([o.cpu().numpy() for o in outs]), want)
+        bands32 = [torch.from_numpy(x[a:b]).cuda() for a, b in cuts]
+        outs = r.upscale_sharded_all(engs, bands32)
+        np.testing.assert_array_equal(np.concatenate([o.cpu().numpy() for o in outs]), want32)
+        # very uneven bands: the smallest a neighbour can still read a halo from
+        hs = [7] * (n - 1) + [H - 7 * (n - 1)]
+        edges = np.cumsum([0] + hs)
+        outs = r.upscale_sharded_all(engs, [torch.from_numpy(px[a:b]).cuda() for a, b in zip(edges[:-1], edges[1:])])
+        np.testing.assert_array_equal(np.concatenate([o.cpu().numpy() for o in outs]), want)
+        with pytest.raises(r.SrError):   # a band shorter than the halo its neighbour needs
+            r.upscale_sharded_all(engs, [torch.from_numpy(px[:6]).cuda()] + bands[1:])
+        with pytest.raises(r.SrError):   # a lone rank of a local communicator cannot see its neighbours
+            engs[0].upscale_sharded_dev(bands[0])
+        engs[0].set_profiling(True)
+        r.upscale_sharded_all(engs, bands)
+        assert engs[0].last_comm_ms() > 0
+    finally:
+        for e in engs:
+            e.close()
+
+
 @pytest.mark.skipif("_ndev() < 2")
 def test_contexts_on_other_devices(params):
     """device != 0: the > 64 KB dynamic-LDS attribute is per (kernel, device); a context on every device of the node
@@ -245,12 +288,13 @@ def test_sharded_over_all_devices_with_rccl(params):
         engs = [r.Engine(params["imagenet"], device=k, precision=prec) for k in range(n)]
         try:
             want = engs[0].upscale_rgba8(px)
-            r.comm_init_all(engs)
             bands = [torch.from_numpy(px[a:b]).to(f"cuda:{k}") for k, (a, b) in enumerate(split_rows(H, n))]
-            for _ in range(2):
-                outs = r.upscale_sharded_all(engs, bands)
-            got = np.concatenate([o.cpu().numpy() for o in outs])
-            np.testing.assert_array_equal(got, want)
+            for transport in ("rccl", "local"):   # grouped ncclSend / ncclRecv, then peer copies over the same links
+                r.comm_init_all(engs, transport=transport)
+                for _ in range(2):
+                    outs = r.upscale_sharded_all(engs, bands)
+                got = np.concatenate([o.cpu().numpy() for o in outs])
+                np.testing.assert_array_equal(got, want, err_msg=transport)
             np.testing.assert_array_equal(r.upscale_multi(engs, px), want)
             batch = synth_u8(4, 2 * n + 1, 128, 160)
             np.testing.assert_array_equal(r.upscale_batch_multi(engs, batch), engs[0].upscale_rgba8(batch))
