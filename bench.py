@@ -32,6 +32,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -499,6 +500,23 @@ def main():
             result["x4_synthetic_weights"] = {"error": str(ex)}
 
     # ------------------------------------------------------------------ the other named configurations
+    # N > 1: the entries below contain collectives of their own (exchanges, barriers).  Should one rank fail where the
+    # others do not, they would wait for it for ever and the line above would be lost with them: a watchdog thread
+    # prints what is complete and ends the process instead.
+    watchdog = None
+    if world > 1 and not args.no_configs:
+        limit = float(os.environ.get("SRHIP_BENCH_EXTRAS_LIMIT_S", "150"))
+
+        def give_up():
+            if rank == 0:
+                line = dict(result)
+                line["watchdog"] = f"config_C / config_D did not finish within {limit:.0f} s; every other field is complete"
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(limit, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     del main_band
     torch.cuda.empty_cache()
     peak_here = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
@@ -655,9 +673,12 @@ def main():
 
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
