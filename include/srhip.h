@@ -208,8 +208,10 @@ int sr_set_precision(sr_ctx* ctx, int mode);
  * exactly that.  key "th": tile height, value "" (automatic), "4" / "8" (all stages) or five digits (one per stage);
  * "pipe": "none" forces the first form of the stage kernels; "bw": width in tiles of the column blocks the tile
  * queue walks ("" automatic, "0" plain row-major); "cols": "0" runs the split-half mode on the step form of the pipe
- * kernel instead of the column form.  ("dbg" is different: timing experiments that BREAK results, scripts/dbg_exp.py.)
- * Defaults come from SRHIP_TH / SRHIP_PIPE / SRHIP_BW / SRHIP_COLS, read once in sr_create.  Unknown key: SR_E_INVALID. */
+ * kernel instead of the column form; "bands": the host pipeline cuts one large image into that many equal row bands
+ * ("" / "0": its own plan); "geo": "0" keeps equal bands where the plan would shrink them geometrically.
+ * ("dbg" is different: timing experiments that BREAK results, scripts/dbg_exp.py.)
+ * Defaults come from SRHIP_TH / SRHIP_PIPE / SRHIP_BW / SRHIP_COLS / SRHIP_BANDS / SRHIP_GEO, read once in sr_create.  Unknown key: SR_E_INVALID. */
 int sr_set_experiment(sr_ctx* ctx, const char* key, const char* value);
 
 /* Test hook: copy the post-activation feature maps of the most recent call

@@ -252,8 +252,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[6][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"dbg", "SRHIP_DBG"}, {"cols", "SRHIP_COLS"},
-                                              {"bands", "SRHIP_BANDS"}};
+    static const char* const kSwitch[7][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"dbg", "SRHIP_DBG"}, {"cols", "SRHIP_COLS"},
+                                              {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
     {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
@@ -396,6 +396,8 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
         c->env_pipe = strcmp(v, "none") != 0;
     } else if (!strcmp(key, "bands")) {  // host pipeline: row bands of one large image ("" / "0": automatic)
         c->env_bands = *v ? atoi(v) : 0;
+    } else if (!strcmp(key, "geo")) {  // "0": equal bands also where the host pipeline would shrink them geometrically
+        c->env_geo = strcmp(v, "0") != 0;
     } else if (!strcmp(key, "cols")) {  // "0": split-half mode runs the step form of the pipe kernel instead of the column form
         c->env_cols = strcmp(v, "0") != 0;
     } else if (!strcmp(key, "dbg")) {  // timing experiments that BREAK the results (StageArgs::dbg); never set outside scripts/
@@ -462,9 +464,18 @@ int ensure_features(sr_ctx* c, sr_ctx::Workspace& w, int n, int H, int W, int ti
         w.feat_cap_px = 0; w.geo_n = 0;
         for (auto& p : w.d_feat) HIPCHK(c, hipMalloc((void**)&p, npx * 32 * sizeof(float)));
         w.feat_cap_px = npx;
+        // fresh memory: everything once (interiors too: tile rows past a band's last row are computed and discarded,
+        // and what they read should at least be numbers)
+        for (auto& p : w.d_feat) HIPCHK(c, hipMemsetAsync(p, 0, npx * 32 * sizeof(float), s));
+        w.geo_n = n; w.geo_h = H; w.geo_w = W;
     }
     if (w.geo_n != n || w.geo_h != H || w.geo_w != W) {
-        for (auto& p : w.d_feat) HIPCHK(c, hipMemsetAsync(p, 0, w.feat_cap_px * 32 * sizeof(float), s));
+        // another geometry in the same allocation: what was interior may now be border.  Only the border is cleared
+        // (1080p: 6 MB per map instead of 270 MB), so a context that meets a new image size per call pays microseconds.
+        ClearArgs ca{};
+        for (int k = 0; k < 4; ++k) ca.map[k] = w.d_feat[k];
+        ca.n = n; ca.H = H; ca.W = W; ca.pitch = pitch; ca.img_stride = img_stride; ca.total_px = (long)npx;
+        HIPCHK(c, sr_launch_clear_borders(ca, s));
         w.geo_n = n; w.geo_h = H; w.geo_w = W;
     }
     w.pitch = pitch; w.img_stride = img_stride;
@@ -613,14 +624,15 @@ struct Deal {
     int first, stride, count;
 };
 
-// Split the job.  Batches go in chunks of ~1M px of whole images.  A single large sr_net image goes as row bands that
-// all have the SAME extended height E (so the zero borders of the feature maps stay valid and
-// nothing is re-cleared between chunks): band k owns rows [y0,y1) and carries the E rows
-// [start, start+E) with start = clamp(y0 - SR_HALO, 0, h - E).
+// Split the job.  Batches go in chunks of ~1M px of whole images.  A single large sr_net image goes as row bands: band k
+// owns rows [y0,y1) and carries them plus SR_HALO rows on every side that is not an image edge.  Bands may differ in
+// height -- a workspace that meets a new geometry only has its border re-cleared (ensure_features), microseconds.
 // [y_lo, y_hi): the image rows this call is to produce (a whole image: 0, h; a device's share of a multi-GPU
 // call: its rows, sr_net and n == 1 only).
-std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t in_px_bytes, size_t out_px_bytes, int y_lo, int y_hi) {
+std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t in_px_bytes, size_t out_px_bytes, int y_lo, int y_hi,
+                               bool* in_order) {
     std::vector<Chunk> plan;
+    *in_order = false;
     const int f = c->factor, n = deal.count;
     const size_t in_img = (size_t)h * w * in_px_bytes;
     const size_t out_img = c->graph == SR_GRAPH_DOWNSAMPLE ? (size_t)(h / 3) * (w / 3) * out_px_bytes
@@ -638,33 +650,66 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
     }
     const bool part = y_lo > 0 || y_hi < h;  // a share of the image: always in band form (halo rows from the image itself)
     const int span = y_hi - y_lo;
-    int bands = 1;
+    std::vector<int> rows;  // rows of each band, top to bottom
     if (pipe && n == 1 && c->graph == SR_GRAPH_SR_NET && (size_t)span * w >= ((size_t)1 << 19)) {
-        // measured (scripts/bands_exp.py, page-locked buffers, f32): 1080p 1 / 2 / 4 / 5 / 8 bands = 5.96 / 5.14 / 4.93 / 5.12 / 5.22 ms,
-        // 4K 1 / 4 / 8 / 12 bands = 23.4 / 18.4 / 18.1 / 18.4 ms: few bands expose the last download, many pay 14 recomputed rows
-        // and five more launches each
-        // (the split-half mode computes 2.2x faster than the bus drains its output: more, smaller bands start the first download
-        // earlier -- 1080p 4 / 5 / 6 / 8 bands = 3.77 / 2.7-3.4 / 2.82 / 3.05 ms)
-        bands = span / (c->precision == SR_PRECISION_SPLIT_F16 ? 176 : 256);
-        if (bands > 8) bands = 8;
-        if (c->env_bands > 0) bands = std::min(c->env_bands, span / (2 * SR_HALO));  // sr_set_experiment("bands")
+        // Kernel and download time per input pixel decide the shape of the plan (measured, page-locked buffers, PCIe 5 x16):
+        const double kern_ns = (c->precision == SR_PRECISION_SPLIT_F16 ? 0.9 : 2.0) * (f == 4 ? 1.2 : 1.0);
+        const double d2h_ns = (double)out_px_bytes * f * f / 52.0;
+        const double rho = kern_ns / d2h_ns;
+        if (c->env_bands > 0) {  // sr_set_experiment("bands"): that many equal bands
+            const int nb = std::min(c->env_bands, span / (2 * SR_HALO));
+            for (int k = 0; k < nb; ++k) rows.push_back((span * (k + 1)) / nb - (span * k) / nb);
+        } else {
+            // Compute-bound (f32 arithmetic, u8 output: rho = 2.9): only the LAST band's download is exposed, and band
+            // i's download hides under band i+1's kernels as long as band i+1 is at least 1/rho of it -- bands that
+            // shrink geometrically, as many as keep the last one >= 300K px (smaller bands no longer fill the chip: at
+            // 1080p the 128-row third band costs more than it hides, 4.95 against 4.85 ms with four equal bands).
+            // They compute IN ORDER on one stream: on two, band 1 runs beside band 0, both finish late and the
+            // largest download is the exposed one (1080p 5.54 ms).  Measured (scripts/geo_exp.py), geometric
+            // against equal bands: 2560x1440 8.17 / 8.37 ms, 3840x2160 17.50 / 17.78 ms.
+            const double r = std::min(rho * 0.85, 3.0);
+            int nb = 1;
+            double sum = 1.0, term = 1.0;
+            while (rho >= 2.0 && c->env_geo && nb < 5 && (double)span * w / (sum + term * r) >= 300e3) { term *= r; sum += term; ++nb; }
+            if (nb >= 3) {
+                int left = span;
+                for (int k = 0; k < nb - 1; ++k) {
+                    int rk = (int)((double)span * term / sum) / 8 * 8;  // whole 8-row tiles
+                    rk = std::max(2 * SR_HALO, std::min(rk, left - 2 * SR_HALO));
+                    rows.push_back(rk);
+                    left -= rk;
+                    term /= r;
+                }
+                rows.push_back(left);
+                *in_order = true;
+            }
+        }
+        if (rows.empty()) {
+            // Download-bound or balanced (f32 output, the split-half mode): equal bands.  Few expose the first upload
+            // and the last download, many pay 14 recomputed rows and five launches each.  Measured, f32 1080p
+            // 1 / 2 / 4 / 5 / 8 bands = 5.96 / 5.14 / 4.93 / 5.12 / 5.22 ms; the split-half mode computes 2.2x faster
+            // than the bus drains its output and prefers more: 4 / 5 / 6 / 8 bands = 3.77 / 2.7-3.4 / 2.82 / 3.05 ms.
+            int nb = span / (c->precision == SR_PRECISION_SPLIT_F16 ? 176 : 256);
+            if (nb > 8) nb = 8;
+            for (int k = 0; k < nb; ++k) rows.push_back((span * (k + 1)) / nb - (span * k) / nb);
+        }
     }
     const size_t img0_in = (size_t)deal.first * in_img, img0_out = (size_t)deal.first * out_img;
-    if (bands >= 2) {
-        const int rows = (span + bands - 1) / bands, E = rows + 2 * SR_HALO;
-        bool ok = E <= h;
-        for (int k = 0; k < bands && ok; ++k) {
-            const int y0 = y_lo + k * rows, y1 = std::min(y_hi, y0 + rows);
-            int start = std::max(0, y0 - SR_HALO);
-            if (start > h - E) start = h - E;
-            const int ht = y0 - start, hb = start + E - y1;
-            ok = y1 > y0 && (ht == 0 || ht >= SR_HALO) && (hb == 0 || hb >= SR_HALO) && (ht == 0) == (y0 == 0) &&
-                 (hb == 0) == (y1 == h);
-            plan.push_back({img0_in + (size_t)start * w * in_px_bytes, (size_t)E * w * in_px_bytes,
-                            img0_out + (size_t)y0 * f * w * f * out_px_bytes, (size_t)(y1 - y0) * f * w * f * out_px_bytes, 1, E, ht, hb,
+    if (rows.size() >= 2) {
+        bool ok = true;
+        int y0 = y_lo;
+        for (int rk : rows) {
+            const int y1 = y0 + rk;
+            const int start = std::max(0, y0 - SR_HALO), end = std::min(h, y1 + SR_HALO);
+            const int ht = y0 - start, hb = end - y1;
+            // sr_run_stack's rules: a halo is SR_HALO rows or, at an image edge, none
+            ok = ok && rk > 0 && (ht == 0 || ht == SR_HALO) && (hb == 0 || hb == SR_HALO);
+            plan.push_back({img0_in + (size_t)start * w * in_px_bytes, (size_t)(end - start) * w * in_px_bytes,
+                            img0_out + (size_t)y0 * f * w * f * out_px_bytes, (size_t)rk * f * w * f * out_px_bytes, 1, end - start, ht, hb,
                             0, 0});
+            y0 = y1;
         }
-        if (ok) return plan;
+        if (ok && y0 == y_hi) return plan;
         plan.clear();
     }
     if (part) {  // one band: the rows themselves plus SR_HALO rows on every side that is not an image edge
@@ -696,7 +741,8 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     if ((y_lo > 0 || y_hi < h) && (n != 1 || c->graph != SR_GRAPH_SR_NET)) return SR_E_INVALID;
     if (y_lo > 0 && y_lo < SR_HALO) return SR_E_HALO;
     if (y_hi < h && h - y_hi < SR_HALO) return SR_E_HALO;
-    const std::vector<Chunk> plan = plan_chunks(c, deal, h, w, in_px, out_px, y_lo, y_hi);
+    bool in_order = false;
+    const std::vector<Chunk> plan = plan_chunks(c, deal, h, w, in_px, out_px, y_lo, y_hi, &in_order);
     const int nch = (int)plan.size();
     const int slots = nch > 1 ? 2 : 1;
     size_t in_max = 0, out_max = 0;
@@ -729,7 +775,8 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     // chunk i computes on stream i % 2 with workspace i % 2: consecutive chunks' stage launches overlap (the tail of one
     // launch -- its last, partly filled round of workgroups -- runs beside the head of the other stream's next launch;
     // measured at 1080p, one stream: five bands cost 19 % more kernel time than the undivided pass)
-    auto cstream = [&](int i) { return (slots == 2 && (i & 1)) ? c->stream2 : c->stream; };
+    // (a geometric band plan wants the opposite: band i finished, and downloading, before band i+1 takes the chip)
+    auto cstream = [&](int i) { return (slots == 2 && (i & 1) && !in_order) ? c->stream2 : c->stream; };
     auto issue_front = [&](int i) -> int {  // upload + kernels of chunk i
         const Chunk& k = plan[i];
         const int sl = i % slots;

@@ -49,6 +49,7 @@ struct sr_ctx {
     int env_bw = -1;                  // tile-order column-block width in tiles (-1: automatic)
     int env_dbg = 0;                  // StageArgs::dbg timing experiments (results invalid when non-zero)
     int env_bands = 0;                // host pipeline: forced number of row bands (0: automatic)
+    bool env_geo = true;              // host pipeline: geometric band plan where the call is compute-bound
     unsigned long long params_hash = 0;  // FNV-1a of the parameter vector: contexts of one sharded call must agree
     // ---- multi-GPU (sr_comm.cpp): one RCCL communicator per context, neighbour halo exchange
     void* comm = nullptr;             // ncclComm_t

@@ -74,6 +74,16 @@ inline void set_tile_order(StageArgs& a, int bw) {
 constexpr int kFeatPad = 2;          // 5x5 halo
 constexpr int kFeatPadBottom = 12;   // last tile row may start at H-1: + 8 rows + 2 halo (+2 spare)
 
+// Restore that border for a new geometry: zero every cell of the four maps that is not the interior of one of the n images
+// (a few MB instead of the whole allocation -- a context that meets images of many sizes changes geometry per call).
+struct ClearArgs {
+    float* map[4];
+    int n, H, W, pitch;
+    long img_stride;  // pixels
+    long total_px;    // n * img_stride + the rows above image 0 + slack
+};
+hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s);
+
 struct AuxArgs {          // bilinear_net / downsample_net (parameter-free graphs)
     const void* img;      // n*H*W*3 f32 or n*H*W*img_ch u8
     void* out;            // bilinear: n*3H*3W*(3 f32 | 4 u8); downsample: n*(H/3)*(W/3)*(3 f32 | 4 u8)

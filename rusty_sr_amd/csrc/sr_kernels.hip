@@ -1755,6 +1755,33 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
 }
 
 // ---------------------------------------------------------------------------
+// zero border of the feature maps for a new geometry: one workgroup per buffer row (and per map)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clear_borders_kernel(ClearArgs a) {
+    float4* m = reinterpret_cast<float4*>(a.map[blockIdx.y]);
+    const long rows_per = a.img_stride / a.pitch;
+    const long row = blockIdx.x;
+    const long base = row * a.pitch;            // first pixel of the row
+    long end = base + a.pitch;
+    if (end > a.total_px) end = a.total_px;     // the slack after the last row is a partial row
+    const long img = row / rows_per, local = row - img * rows_per;
+    const bool interior = img < a.n && local >= kFeatPad && local < kFeatPad + a.H;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!interior) {
+        for (long q = base * 8 + threadIdx.x; q < end * 8; q += 256) m[q] = z;   // 8 float4 per 32-channel pixel
+        return;
+    }
+    for (long q = base * 8 + threadIdx.x; q < (base + kFeatPad) * 8; q += 256) m[q] = z;
+    for (long q = (base + kFeatPad + a.W) * 8 + threadIdx.x; q < end * 8; q += 256) m[q] = z;
+}
+
+hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s) {
+    const long rows = (a.total_px + a.pitch - 1) / a.pitch;
+    hipLaunchKernelGGL(clear_borders_kernel, dim3((unsigned)rows, 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // host-side launchers (called from sr_api.cpp through sr_kernels.h)
 // ---------------------------------------------------------------------------
 template <int TH, int KS0>

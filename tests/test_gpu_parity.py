@@ -239,10 +239,11 @@ def test_full_size_properties_1080p(engines, params, H, W):
     assert torch.equal(out8[..., :3], q) and bool((out8[..., 3] == 255).all())
 
 
-@pytest.mark.parametrize("h,w", [(1080, 1920), (577, 911), (523, 1100), (2000, 270)])
+@pytest.mark.parametrize("h,w", [(1080, 1920), (577, 911), (523, 1100), (2000, 270), (1400, 2100)])
 def test_host_pipeline_bands_are_bit_identical(engines, h, w):
     """sr_upscale_* on host pointers splits a large image into row bands (upload / kernels /
-    download overlap); the result must equal the undivided pass bit for bit, f32 and u8,
+    download overlap; equal bands, or -- f32 arithmetic with u8 output from ~2.9 M px, here 1400x2100 -- three
+    geometrically shrinking ones computed in order); the result must equal the undivided pass bit for bit, f32 and u8,
     pageable and page-locked (sr_host_alloc) destinations alike."""
     import rusty_sr_amd as r
     from rusty_sr_amd.engine import host_alloc
@@ -254,7 +255,7 @@ def test_host_pipeline_bands_are_bit_identical(engines, h, w):
         want32, want8 = eng.upscale_f32(x), eng.upscale_rgba8(px)
         assert eng.read_feature(0, h, w).shape == (h, w, 32)   # allowed after an undivided pass
         eng.set_pipeline(True)
-        got32, got8 = eng.upscale_f32(x), eng.upscale_rgba8(px)
+        got8, got32 = eng.upscale_rgba8(px), eng.upscale_f32(x)   # f32 output is download-bound: banded at every one of these sizes
         t = eng.last_timing()
         assert t["total_ms"] > 0 and t["h2d_ms"] > 0 and t["d2h_ms"] > 0
         with pytest.raises(r.SrError):      # feature maps hold the last band only
@@ -267,6 +268,33 @@ def test_host_pipeline_bands_are_bit_identical(engines, h, w):
     np.testing.assert_array_equal(got32, want32)
     np.testing.assert_array_equal(got8, want8)
     np.testing.assert_array_equal(got8p, want8)
+
+
+@pytest.mark.parametrize("precision", ["f32", "split_f16"])
+def test_a_new_geometry_only_needs_its_border_cleared(params, precision):
+    """One context meets images of many sizes (a folder of pictures): the feature maps keep their allocation and a new
+    geometry re-zeroes just the cells outside the image interiors (clear_borders_kernel) -- what was interior data of
+    the previous, larger or differently pitched image must not leak into the zero padding.  Every result equals the
+    one a fresh context gives."""
+    import rusty_sr_amd as r
+    seq = [(1, 300, 515), (1, 40, 70), (3, 37, 129), (1, 16, 3000), (1, 2000, 40), (2, 64, 64), (1, 301, 514), (1, 8, 32), (1, 300, 515)]
+    rng = np.random.default_rng(17)
+    imgs = [rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8) for (n, h, w) in seq]
+    eng = r.Engine(params["imagenet"], precision=precision)
+    try:
+        got = [eng.upscale_rgba8(px) for px in imgs]
+        import torch
+        ext = torch.from_numpy(imgs[0][0][100:160].copy()).cuda()         # a band in a workspace last used for another shape
+        got_band = eng.upscale_band_rgba8_dev(ext, 7, 7).cpu().numpy()
+    finally:
+        eng.close()
+    for px, g in zip(imgs, got):
+        fresh = r.Engine(params["imagenet"], precision=precision)
+        try:
+            np.testing.assert_array_equal(g, fresh.upscale_rgba8(px), err_msg=str(px.shape))
+        finally:
+            fresh.close()
+    np.testing.assert_array_equal(got_band, got[0][0][3 * 107:3 * 153])
 
 
 @pytest.mark.parametrize("precision", ["f32", "split_f16"])
