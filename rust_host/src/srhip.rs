@@ -36,6 +36,8 @@ extern "C" {
     pub fn sr_upscale_f32(ctx: *mut SrCtx, input: *const f32, n: c_int, h: c_int, w: c_int, out: *mut f32) -> c_int;
     pub fn sr_upscale_rgba8(ctx: *mut SrCtx, input: *const u8, in_channels: c_int, n: c_int, h: c_int, w: c_int,
                             out_rgba: *mut u8) -> c_int;
+    pub fn sr_reserve_f32(ctx: *mut SrCtx, n: c_int, h: c_int, w: c_int) -> c_int;
+    pub fn sr_reserve_rgba8(ctx: *mut SrCtx, in_channels: c_int, n: c_int, h: c_int, w: c_int) -> c_int;
     pub fn sr_upscale_f32_dev(ctx: *mut SrCtx, d_in: *const f32, n: c_int, h: c_int, w: c_int, d_out: *mut f32,
                               stream: *mut c_void) -> c_int;
     pub fn sr_upscale_rgba8_dev(ctx: *mut SrCtx, d_in: *const u8, in_channels: c_int, n: c_int, h: c_int, w: c_int,

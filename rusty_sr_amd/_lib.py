@@ -29,6 +29,8 @@ SYMBOLS = {
     "sr_destroy": (None, [_vp]),
     "sr_upscale_f32": (_i, [_vp, _fp, _i, _i, _i, _fp]),
     "sr_upscale_rgba8": (_i, [_vp, _u8p, _i, _i, _i, _i, _u8p]),
+    "sr_reserve_f32": (_i, [_vp, _i, _i, _i]),
+    "sr_reserve_rgba8": (_i, [_vp, _i, _i, _i, _i]),
     "sr_upscale_f32_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sr_upscale_rgba8_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sr_upscale_band_f32_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -64,8 +64,8 @@ def build_host(force=False, verbose=False):
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     res = os.path.join(HERE, "res")
     cmds = [
-        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[1], srcs[2], "-lz", "-o", PNGLIB],
-        ["g++", "-O2", "-std=c++17", "-pthread", f'-DSR_RES_DIR="{res}"', *srcs, "-L", HERE, "-lsrhip", "-lz",
+        ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[1], srcs[2], "-lz", "-o", PNGLIB],
+        ["g++", "-O3", "-std=c++17", "-pthread", f'-DSR_RES_DIR="{res}"', *srcs, "-L", HERE, "-lsrhip", "-lz",
          "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", CLI],
     ]
     for cmd in cmds:

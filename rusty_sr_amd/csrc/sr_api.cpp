@@ -727,10 +727,12 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
 // three streams.  Issue order is H2D(i+1), kernels(i+1), D2H(i): with pageable caller memory the
 // runtime blocks the calling thread inside each copy, and this order keeps kernels queued behind
 // it; with pinned memory (sr_host_alloc) all three engines run concurrently.
+// reserve: no caller buffers -- everything else of the call happens (allocations, events, the kernels on whatever the
+// staging buffers hold), so that the first real call costs what every later one does (sr_reserve_*).
 int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int h, int w, void* out, bool out_u8, int y_lo = 0,
-             int y_hi = -1) {
+             int y_hi = -1, bool reserve = false) {
     const int n = deal.count;
-    if (!c || !in || !out || n <= 0 || h <= 0 || w <= 0 || deal.first < 0 || deal.stride < 1) return SR_E_INVALID;
+    if (!c || ((!in || !out) && !reserve) || n <= 0 || h <= 0 || w <= 0 || deal.first < 0 || deal.stride < 1) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
     if (c->graph == SR_GRAPH_DOWNSAMPLE && (h < 3 || w < 3)) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET && img_u8 != out_u8) return SR_E_INVALID;
@@ -763,6 +765,7 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     char* dst = (char*)out;
     // a chunk's images are contiguous on the device; in the caller's buffers they are in_step / out_step apart
     auto copy_images = [&](const Chunk& k, bool up, int sl) -> int {
+        if (reserve) return SR_OK;
         const bool contiguous = k.n == 1 || (up ? k.in_step == k.in_bytes / k.n : k.out_step == k.out_bytes / k.n);
         const int pieces = contiguous ? 1 : k.n;
         const size_t in_img = k.in_bytes / (contiguous ? 1 : k.n), out_img = k.out_bytes / (contiguous ? 1 : k.n);
@@ -865,6 +868,14 @@ int sr_upscale_band_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, i
                               int halo_top, int halo_bot, uint8_t* d_out, void* stream) {
     return sr_run_stack(c, d_in, true, in_channels, 1, h_ext, w, halo_top, halo_bot, d_out, true,
                         (hipStream_t)stream);
+}
+
+int sr_reserve_f32(sr_ctx* c, int n, int h, int w) {
+    return run_host(c, nullptr, false, 3, Deal{0, 1, n}, h, w, nullptr, false, 0, -1, true);
+}
+
+int sr_reserve_rgba8(sr_ctx* c, int in_channels, int n, int h, int w) {
+    return run_host(c, nullptr, true, in_channels, Deal{0, 1, n}, h, w, nullptr, true, 0, -1, true);
 }
 
 int sr_upscale_f32(sr_ctx* c, const float* in, int n, int h, int w, float* out) {

@@ -122,6 +122,15 @@ class Engine:
         _lib.check(self._L.sr_upscale_rgba8(self._ctx, px.ctypes.data_as(u8p), c, n, h, w, out.ctypes.data_as(u8p)), self._ctx)
         return out[0] if squeeze else out
 
+    def reserve(self, n: int, h: int, w: int, io: str = "rgba8", channels: int = 3):
+        """Allocate and warm everything upscale_rgba8 / upscale_f32 of that shape needs (sr_reserve_*): optional."""
+        if io == "rgba8":
+            _lib.check(self._L.sr_reserve_rgba8(self._ctx, channels, n, h, w), self._ctx)
+        elif io == "f32":
+            _lib.check(self._L.sr_reserve_f32(self._ctx, n, h, w), self._ctx)
+        else:
+            raise ValueError("io must be 'rgba8' or 'f32'")
+
     # ---- device-memory entry points (torch tensors on this GPU) ------------
     @staticmethod
     def _stream_ptr(stream=None):

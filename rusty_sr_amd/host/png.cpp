@@ -9,7 +9,11 @@
 #include <cstring>
 #include <climits>
 #include <exception>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
+#include <sched.h>
 
 namespace srpng {
 namespace {
@@ -25,26 +29,44 @@ int paeth(int a, int b, int c) {
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// undo PNG filtering in place: `rows` scanlines of `stride` bytes, each preceded by its filter byte
+// undo PNG filtering in place: `rows` scanlines of `stride` bytes, each preceded by its filter byte.  One loop per
+// filter type with the first pixel (no left neighbour) peeled off, so the inner loops carry no tests.
 bool unfilter(uint8_t* d, int rows, size_t stride, int bpp, std::string& err) {
     const uint8_t* prev = nullptr;
+    const size_t B = (size_t)bpp, head = std::min(B, stride);
     for (int y = 0; y < rows; ++y) {
         uint8_t* line = d + (size_t)y * (stride + 1);
         const int ft = line[0];
         uint8_t* cur = line + 1;
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev ? prev[i] : 0,
-                      c = (prev && i >= (size_t)bpp) ? prev[i - bpp] : 0;
-            int add;
-            switch (ft) {
-                case 0: add = 0; break;
-                case 1: add = a; break;
-                case 2: add = b; break;
-                case 3: add = (a + b) >> 1; break;
-                case 4: add = paeth(a, b, c); break;
-                default: err = "bad PNG filter type"; return false;
-            }
-            cur[i] = (uint8_t)(cur[i] + add);
+        switch (ft) {
+            case 0: break;
+            case 1:
+                for (size_t i = B; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - B]);
+                break;
+            case 2:
+                if (prev) for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]);
+                break;
+            case 3:
+                if (prev) {
+                    for (size_t i = 0; i < head; ++i) cur[i] = (uint8_t)(cur[i] + (prev[i] >> 1));
+                    for (size_t i = B; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + ((cur[i - B] + prev[i]) >> 1));
+                } else {
+                    for (size_t i = B; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + (cur[i - B] >> 1));
+                }
+                break;
+            case 4:
+                if (prev) {
+                    for (size_t i = 0; i < head; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]);  // paeth(0, b, 0) = b
+                    for (size_t i = B; i < stride; ++i) {
+                        const int a = cur[i - B], bb = prev[i], c = prev[i - B];
+                        const int pa = abs(bb - c), pb = abs(a - c), pc = abs(a + bb - 2 * c);
+                        cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c)));
+                    }
+                } else {
+                    for (size_t i = B; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - B]);  // paeth(a, 0, 0) = a
+                }
+                break;
+            default: err = "bad PNG filter type"; return false;
         }
         prev = cur;
     }
@@ -59,6 +81,12 @@ int channels_of(int ctype) { return ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3
 void expand_row(const Hdr& H, const uint8_t* row, int n, const std::vector<uint8_t>& plte,
                 const std::vector<uint8_t>& trns, uint8_t* out, int x0, int dx) {
     const int ch = channels_of(H.ctype);
+    if (H.depth == 8 && dx == 1 && (H.ctype == 2 || H.ctype == 6)) {  // the common cases, without the per-sample tests
+        uint8_t* o = out + (size_t)x0 * 4;
+        if (H.ctype == 6) { memcpy(o, row, (size_t)n * 4); return; }
+        for (int k = 0; k < n; ++k) { o[4 * k] = row[3 * k]; o[4 * k + 1] = row[3 * k + 1]; o[4 * k + 2] = row[3 * k + 2]; o[4 * k + 3] = 255; }
+        return;
+    }
     for (int k = 0; k < n; ++k) {
         int s[4] = {0, 0, 0, 255};
         for (int c = 0; c < ch; ++c) {
@@ -273,6 +301,51 @@ static bool decode_bmp(const uint8_t* d, size_t len, Image& out, std::string& er
 
 static bool decode_any_memory(const std::vector<uint8_t>& buf, Image& out, std::string& err);
 
+bool probe_image_size(const std::string& path, int& w, int& h) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> b(65536);
+    b.resize(fread(b.data(), 1, b.size(), f));
+    fclose(f);
+    const size_t n = b.size();
+    long W = 0, Hh = 0;
+    if (n >= 24 && b[0] == 0x89 && b[1] == 'P' && !memcmp(b.data() + 12, "IHDR", 4)) {
+        W = be32(b.data() + 16); Hh = be32(b.data() + 20);
+    } else if (n >= 26 && b[0] == 'B' && b[1] == 'M') {
+        const int32_t bw = (int32_t)((uint32_t)b[18] | b[19] << 8 | b[20] << 16 | (uint32_t)b[21] << 24);
+        const int32_t bh = (int32_t)((uint32_t)b[22] | b[23] << 8 | b[24] << 16 | (uint32_t)b[25] << 24);
+        W = bw; Hh = bh < 0 ? -(long)bh : bh;
+    } else if (n >= 7 && b[0] == 'P' && b[1] >= '1' && b[1] <= '6' && isspace(b[2])) {
+        size_t pos = 2;
+        long v[2] = {0, 0};
+        for (int k = 0; k < 2; ++k) {
+            for (;;) {
+                if (pos >= n) return false;
+                if (b[pos] == '#') { while (pos < n && b[pos] != '\n') ++pos; continue; }
+                if (isspace(b[pos])) { ++pos; continue; }
+                break;
+            }
+            if (!isdigit(b[pos])) return false;
+            while (pos < n && isdigit(b[pos]) && v[k] < (1L << 40)) { v[k] = v[k] * 10 + (b[pos] - '0'); ++pos; }
+        }
+        W = v[0]; Hh = v[1];
+    } else if (n >= 4 && b[0] == 0xff && b[1] == 0xd8) {
+        size_t pos = 2;
+        while (pos + 9 < n) {  // marker segments up to the frame header (SOF0 / 1 / 2)
+            if (b[pos] != 0xff) return false;
+            const int m = b[pos + 1];
+            if (m == 0xff) { ++pos; continue; }
+            const size_t len = (size_t)b[pos + 2] << 8 | b[pos + 3];
+            if (m == 0xc0 || m == 0xc1 || m == 0xc2) { Hh = b[pos + 5] << 8 | b[pos + 6]; W = b[pos + 7] << 8 | b[pos + 8]; break; }
+            if (m == 0xda || len < 2) return false;
+            pos += 2 + len;
+        }
+    }
+    if (W <= 0 || Hh <= 0 || W > (1 << 20) || Hh > (1 << 20) || (uint64_t)W * (uint64_t)Hh > kMaxPixels) return false;
+    w = (int)W; h = (int)Hh;
+    return true;
+}
+
 bool decode_image_file(const std::string& path, Image& out, std::string& err) {
     std::vector<uint8_t> buf;
     if (!read_all(path, buf, err)) return false;
@@ -305,30 +378,79 @@ bool decode_file(const std::string& path, Image& out, std::string& err) {
     return decode_memory(buf.data(), buf.size(), out, err);
 }
 
-// Filter + deflate rows [y0, y1) into one raw-deflate segment that ends on a byte boundary
-// (Z_SYNC_FLUSH) or, for the last band, with the final block (Z_FINISH).  Segments of
-// independent bands concatenate into one valid deflate stream (the pigz construction).
-static bool encode_band(const uint8_t* rgba, int w, int y0, int y1, bool last, int zlevel,
-                        std::vector<uint8_t>& comp, uLong& adler, size_t& raw_len) {
+// CPUs this process may really use: the affinity mask, capped by the cgroup quota (a container that shows 256 logical CPUs
+// may be allowed 16 -- more threads than that only fight over them).
+unsigned usable_cpus() {
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = (atol(quota) + period - 1) / period;
+            if (q > 0 && (unsigned)q < n) n = (unsigned)q;
+        }
+        fclose(f);
+    }
+    return n ? n : 4;
+}
+
+// One scanline, all candidate filters in ONE pass over the pixels (None / Sub / Up / Paeth; 4 bytes per pixel): the
+// residuals go to four buffers, the libpng heuristic (smallest sum of |signed residual|) picks one.  Written so that
+// the compiler vectorises it -- no branch depends on the data.
+__attribute__((target_clones("avx2", "default")))  // picked at load time: the build has no -march
+static int filter_row(const uint8_t* cur, const uint8_t* prev, size_t stride, uint8_t* cand /* 4 x stride */) {
+    uint8_t* f0 = cand; uint8_t* f1 = cand + stride; uint8_t* f2 = cand + 2 * stride; uint8_t* f4 = cand + 3 * stride;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s4 = 0;
+    auto mag = [](uint8_t v) -> uint32_t { return v < 128 ? v : 256u - v; };
+    for (size_t i = 0; i < 4 && i < stride; ++i) {  // first pixel: no left neighbour (Paeth degenerates to Up)
+        const uint8_t x = cur[i], bb = prev ? prev[i] : 0;
+        f0[i] = x; f1[i] = x; f2[i] = (uint8_t)(x - bb); f4[i] = (uint8_t)(x - bb);
+        s0 += mag(f0[i]); s1 += mag(f1[i]); s2 += mag(f2[i]); s4 += mag(f4[i]);
+    }
+    if (prev) {
+        for (size_t i = 4; i < stride; ++i) {
+            const int x = cur[i], a = cur[i - 4], bb = prev[i], c = prev[i - 4];
+            const int pa = bb > c ? bb - c : c - bb, pb = a > c ? a - c : c - a;
+            const int t = a + bb - 2 * c, pc = t < 0 ? -t : t;
+            const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
+            const uint8_t r0 = (uint8_t)x, r1 = (uint8_t)(x - a), r2 = (uint8_t)(x - bb), r4 = (uint8_t)(x - pred);
+            f0[i] = r0; f1[i] = r1; f2[i] = r2; f4[i] = r4;
+            s0 += r0 < 128 ? r0 : 256u - r0; s1 += r1 < 128 ? r1 : 256u - r1;
+            s2 += r2 < 128 ? r2 : 256u - r2; s4 += r4 < 128 ? r4 : 256u - r4;
+        }
+    } else {  // first row of the image: Up = None, Paeth = Sub
+        for (size_t i = 4; i < stride; ++i) {
+            const uint8_t r0 = cur[i], r1 = (uint8_t)(cur[i] - cur[i - 4]);
+            f0[i] = r0; f1[i] = r1; f2[i] = r0; f4[i] = r1;
+            s0 += r0 < 128 ? r0 : 256u - r0; s1 += r1 < 128 ? r1 : 256u - r1;
+        }
+        s2 = s0; s4 = s1;
+    }
+    int best = 0;
+    uint32_t bs = s0;
+    if (s1 < bs) { bs = s1; best = 1; }
+    if (s2 < bs) { bs = s2; best = 2; }
+    if (s4 < bs) { bs = s4; best = 4; }
+    return best;
+}
+
+// Filter + deflate rows [y0, y1) into one raw-deflate segment that ends on a byte boundary (Z_SYNC_FLUSH) or, for the
+// last band, with the final block (Z_FINISH): segments of independent bands concatenate into one valid deflate stream
+// (the pigz construction).  The segment comes back wrapped as a complete IDAT chunk -- length, type, data, CRC -- so the
+// CRC is computed here too, in parallel; the first band's data starts with the two zlib header bytes.
+static bool encode_band(const uint8_t* rgba, int w, int y0, int y1, bool first, bool last, int zlevel,
+                        std::vector<uint8_t>& chunk, uLong& adler, size_t& raw_len) {
     const size_t stride = (size_t)w * 4;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)(y1 - y0)), cand(stride);
+    std::vector<uint8_t> raw((stride + 1) * (size_t)(y1 - y0)), cand(4 * stride);
     for (int y = y0; y < y1; ++y) {
         const uint8_t* cur = rgba + (size_t)y * stride;
         const uint8_t* prev = y ? cur - stride : nullptr;  // the row above, also across band seams
-        // adaptive filter: minimum sum of absolute (signed) residuals among None/Sub/Up/Paeth
-        long best = -1;
         uint8_t* dst = raw.data() + (size_t)(y - y0) * (stride + 1);
-        for (int ft : {0, 1, 2, 4}) {
-            long sum = 0;
-            for (size_t i = 0; i < stride; ++i) {
-                const int a = i >= 4 ? cur[i - 4] : 0, b = prev ? prev[i] : 0, c = (prev && i >= 4) ? prev[i - 4] : 0;
-                const int pred = ft == 0 ? 0 : ft == 1 ? a : ft == 2 ? b : paeth(a, b, c);
-                const uint8_t v = (uint8_t)(cur[i] - pred);
-                cand[i] = v;
-                sum += v < 128 ? v : 256 - v;
-            }
-            if (best < 0 || sum < best) { best = sum; dst[0] = (uint8_t)ft; memcpy(dst + 1, cand.data(), stride); }
-        }
+        const int ft = filter_row(cur, prev, stride, cand.data());
+        dst[0] = (uint8_t)ft;
+        memcpy(dst + 1, cand.data() + (ft == 4 ? 3 : ft) * stride, stride);
     }
     raw_len = raw.size();
     if (raw.size() > 0xfffffff0u) return false;  // zlib's uInt counters: never truncate silently
@@ -336,46 +458,40 @@ static bool encode_band(const uint8_t* rgba, int w, int y0, int y1, bool last, i
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (deflateInit2(&zs, zlevel, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    comp.resize(deflateBound(&zs, (uLong)raw.size()) + 16);
+    const size_t head = 8 + (first ? 2 : 0);
+    chunk.resize(head + deflateBound(&zs, (uLong)raw.size()) + 16 + 4);
     zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
-    zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
+    zs.next_out = chunk.data() + head; zs.avail_out = (uInt)(chunk.size() - head - 4);
     const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
     const bool ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0);
-    comp.resize(comp.size() - zs.avail_out);
+    const size_t n = head - 8 + (chunk.size() - head - 4 - zs.avail_out);  // chunk data bytes
     deflateEnd(&zs);
-    return ok;
+    if (!ok || n > 0x7fffffffu) return false;
+    chunk.resize(8 + n + 4);
+    chunk[0] = (uint8_t)(n >> 24); chunk[1] = (uint8_t)(n >> 16); chunk[2] = (uint8_t)(n >> 8); chunk[3] = (uint8_t)n;
+    memcpy(chunk.data() + 4, "IDAT", 4);
+    if (first) { chunk[8] = 0x78; chunk[9] = 0x5e; }  // zlib header: deflate, 32 KB window, check bits
+    const uint32_t crc = (uint32_t)crc32(0, chunk.data() + 4, (uInt)(n + 4));
+    uint8_t* t = chunk.data() + 8 + n;
+    t[0] = (uint8_t)(crc >> 24); t[1] = (uint8_t)(crc >> 16); t[2] = (uint8_t)(crc >> 8); t[3] = (uint8_t)crc;
+    return true;
 }
 
 bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int zlevel) {
     if (w <= 0 || h <= 0 || !rgba) { err = "empty image"; return false; }
-    // Row bands are filtered and deflated in parallel: at 4K-in the RGBA output is 299 MB and a
-    // single-threaded deflate would dwarf the GPU time.
-    const size_t bytes = (size_t)w * h * 4;
-    unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 4;
-    int nband = (int)std::min<size_t>({(size_t)hw, (size_t)64, bytes / (1u << 20) + 1, (size_t)h});
-    std::vector<std::vector<uint8_t>> parts(nband);
-    std::vector<uLong> adl(nband);
-    std::vector<size_t> rawlen(nband);
-    std::vector<char> okv(nband, 0);
-    std::vector<std::thread> th;
-    for (int b = 0; b < nband; ++b)
-        th.emplace_back([&, b] {
-            const int y0 = (int)((long long)h * b / nband), y1 = (int)((long long)h * (b + 1) / nband);
-            okv[b] = encode_band(rgba, w, y0, y1, b == nband - 1, zlevel, parts[b], adl[b], rawlen[b]);
-        });
-    for (auto& t : th) t.join();
-    std::vector<uint8_t> comp = {0x78, 0x5e};  // zlib header: deflate, 32 KB window, check bits
-    uLong adler = adler32(0L, Z_NULL, 0);
-    for (int b = 0; b < nband; ++b) {
-        if (!okv[b]) { err = "deflate failed"; return false; }
-        comp.insert(comp.end(), parts[b].begin(), parts[b].end());
-        adler = adler32_combine(adler, adl[b], (z_off_t)rawlen[b]);
-    }
-    put32(comp, (uint32_t)adler);
-    const uLongf clen = (uLongf)comp.size();
-    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    auto chunk = [&](const char* type, const uint8_t* d, size_t n) {
+    // At 4K-in the RGBA output is 299 MB: a single-threaded filter + deflate would dwarf the GPU time (SURVEY.md 8(f)
+    // item 2).  Row bands of ~2 MB are filtered, deflated and wrapped as IDAT chunks by a pool of worker threads that
+    // take them in order; this thread writes each chunk as soon as all before it are out, so compression, CRC and the
+    // file write overlap and nothing is concatenated in memory.
+    const size_t stride = (size_t)w * 4, bytes = stride * h;
+    if (zlevel < 0) zlevel = bytes > ((size_t)8 << 20) ? 2 : 3;  // large images: a fast level (75 MB of pixels: level 1 / 2 / 3 / 6 = 31.6 / 30.6 / 29.2 / 27.0 MB in 265 / 270 / 370 / 1400 ms on 8 threads)
+    const int rows_per = (int)std::max<size_t>(1, ((size_t)2 << 20) / stride);
+    const int nband = (h + rows_per - 1) / rows_per;
+    const int nthr = (int)std::min<size_t>(usable_cpus(), (size_t)nband);
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { err = "cannot create file"; return false; }
+    std::vector<uint8_t> head = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    auto chunk = [&](std::vector<uint8_t>& out, const char* type, const uint8_t* d, size_t n) {
         put32(out, (uint32_t)n);
         const size_t s = out.size();
         out.insert(out.end(), type, type + 4);
@@ -387,19 +503,50 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
     ihdr[0] = W >> 24; ihdr[1] = W >> 16; ihdr[2] = W >> 8; ihdr[3] = W;
     ihdr[4] = Hh >> 24; ihdr[5] = Hh >> 16; ihdr[6] = Hh >> 8; ihdr[7] = Hh;
     ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;  // 8-bit RGBA like the reference's outputs
-    chunk("IHDR", ihdr, 13);
-    // a PNG chunk length is at most 2^31 - 1: a large stream goes out as several IDAT chunks (the decoder
-    // concatenates them, PNG spec 11.2.4)
-    const size_t kMaxIdat = (size_t)1 << 30;
-    for (size_t off = 0; off < clen || off == 0; off += kMaxIdat) {
-        chunk("IDAT", comp.data() + off, std::min(kMaxIdat, (size_t)clen - off));
-        if (clen == 0) break;
+    chunk(head, "IHDR", ihdr, 13);
+    bool ok = fwrite(head.data(), 1, head.size(), f) == head.size();
+
+    std::vector<std::vector<uint8_t>> parts(nband);
+    std::vector<uLong> adl(nband);
+    std::vector<size_t> rawlen(nband);
+    std::vector<char> state(nband, 0);  // 0 pending, 1 done, 2 failed
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> next{0};
+    auto worker = [&] {
+        for (;;) {
+            const int b = next.fetch_add(1);
+            if (b >= nband) return;
+            const int y0 = b * rows_per, y1 = std::min(h, y0 + rows_per);
+            bool good = false;
+            try { good = encode_band(rgba, w, y0, y1, b == 0, b == nband - 1, zlevel, parts[b], adl[b], rawlen[b]); } catch (...) { good = false; }
+            { std::lock_guard<std::mutex> lk(mu); state[b] = good ? 1 : 2; }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; ++t) th.emplace_back(worker);
+    uLong adler = adler32(0L, Z_NULL, 0);
+    bool failed = false;
+    for (int b = 0; b < nband; ++b) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return state[b] != 0; }); }
+        if (state[b] == 2) failed = true;
+        if (!failed && ok) {
+            ok = fwrite(parts[b].data(), 1, parts[b].size(), f) == parts[b].size();
+            adler = adler32_combine(adler, adl[b], (z_off_t)rawlen[b]);
+        }
+        std::vector<uint8_t>().swap(parts[b]);
     }
-    chunk("IEND", nullptr, 0);
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) { err = "cannot create file"; return false; }
-    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
-    fclose(f);
+    for (auto& t : th) t.join();
+    if (failed) { fclose(f); err = "deflate failed"; return false; }
+    // the zlib trailer (Adler-32 of all filtered bytes) is known only now: a last four-byte IDAT chunk (IDAT data
+    // concatenates across chunks, PNG spec 11.2.4)
+    std::vector<uint8_t> tail;
+    const uint8_t ad[4] = {(uint8_t)(adler >> 24), (uint8_t)(adler >> 16), (uint8_t)(adler >> 8), (uint8_t)adler};
+    chunk(tail, "IDAT", ad, 4);
+    chunk(tail, "IEND", nullptr, 0);
+    ok = ok && fwrite(tail.data(), 1, tail.size(), f) == tail.size();
+    ok = (fclose(f) == 0) && ok;
     if (!ok) err = "short write";
     return ok;
 }
@@ -466,5 +613,6 @@ int srpng_encode_rgba8(const char* path, const uint8_t* rgba, int w, int h) {
     std::string err;
     return srpng::encode_file(path, rgba, w, h, err) ? 0 : -1;
 }
+int srpng_probe_size(const char* path, int* w, int* h) { return srpng::probe_image_size(path, *w, *h) ? 0 : -1; }
 void srpng_free(uint8_t* p) { free(p); }
 }

@@ -13,11 +13,16 @@ namespace srpng {
 struct Image { int w = 0, h = 0; std::vector<uint8_t> rgba; };
 bool decode_file(const std::string& path, Image& out, std::string& err);
 bool decode_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
-bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int zlevel = 3);
+// zlevel < 0: by size (level 3 up to 8 MB of pixels, level 1 above)
+bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int zlevel = -1);
+unsigned usable_cpus();  // affinity mask capped by the cgroup CPU quota
 // baseline JPEG (jpeg.cpp); binary PPM / PGM and uncompressed 24 / 32-bit BMP (png.cpp)
 bool decode_jpeg_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
 // image::open stand-in: picks the decoder from the file's magic bytes (PNG, JPEG, PPM/PGM, BMP)
 bool decode_image_file(const std::string& path, Image& out, std::string& err);
+// width / height from the first bytes of the file (PNG, BMP, PNM, JPEG with its frame header in the first 64 KB) without
+// decoding it: lets the CLI size its buffers while the decoder still runs.  false: unknown (decode will tell).
+bool probe_image_size(const std::string& path, int& w, int& h);
 // `.save(path)` stand-in (reference main.rs:175: the image crate picks the container from the extension):
 // .png (RGBA8), .jpg / .jpeg (baseline, quality 75, alpha dropped), .bmp (32-bit), .ppm (binary P6, alpha dropped)
 bool encode_image_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err);
@@ -30,5 +35,6 @@ int srpng_decode_rgba8(const char* path, int* w, int* h, uint8_t** rgba);  // ca
 int srpng_decode_any_rgba8(const char* path, int* w, int* h, uint8_t** rgba);  // PNG / JPEG / PPM / BMP by magic
 int srpng_encode_rgba8(const char* path, const uint8_t* rgba, int w, int h);
 int srpng_encode_any_rgba8(const char* path, const uint8_t* rgba, int w, int h);  // container by extension: png / jpg / bmp / ppm
+int srpng_probe_size(const char* path, int* w, int* h);  // header only; -1 if it cannot tell
 void srpng_free(uint8_t* p);
 }

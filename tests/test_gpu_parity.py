@@ -270,6 +270,32 @@ def test_host_pipeline_bands_are_bit_identical(engines, h, w):
     np.testing.assert_array_equal(got8p, want8)
 
 
+def test_reserve_allocates_and_warms_without_touching_results(params):
+    """sr_reserve_*: the allocations and one pass of the kernels of a later sr_upscale_* call of that shape, on whatever
+    the staging buffers hold.  Results of the real calls are what a context that never reserved gives -- also when the
+    reserved shape is not the one that comes, and in band form."""
+    import rusty_sr_amd as r
+    px = synth_u8(5, 1, 523, 1100)[0]
+    x = oracle.img_to_data(px)
+    plain = r.Engine(params["imagenet"])
+    want8, want32 = plain.upscale_rgba8(px), plain.upscale_f32(x)
+    plain.close()
+    eng = r.Engine(params["imagenet"])
+    try:
+        eng.reserve(1, 523, 1100, io="rgba8", channels=3)
+        np.testing.assert_array_equal(eng.upscale_rgba8(px), want8)
+        eng.reserve(1, 523, 1100, io="f32")          # banded plan (f32 output is download-bound)
+        np.testing.assert_array_equal(eng.upscale_f32(x), want32)
+        eng.reserve(4, 64, 64)                       # another shape than the one that follows
+        np.testing.assert_array_equal(eng.upscale_rgba8(px), want8)
+        with pytest.raises(r.SrError):
+            eng.reserve(1, 0, 10)
+        with pytest.raises(r.SrError):
+            eng.reserve(1, 16, 16, channels=5)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("precision", ["f32", "split_f16"])
 def test_a_new_geometry_only_needs_its_border_cleared(params, precision):
     """One context meets images of many sizes (a folder of pictures): the feature maps keep their allocation and a new

@@ -61,6 +61,78 @@ def test_png_decode_matches_pillow_on_reference_images(png):
             np.testing.assert_array_equal(png.decode(os.path.join(GOLDEN, name)), want, err_msg=name)
 
 
+def test_png_encoder_bands_chunks_and_filters(png, tmp_path):
+    """The encoder cuts the image into ~2 MB row bands, each filtered, deflated and wrapped as its own IDAT chunk by a
+    worker pool, written in order while later bands still compress; the Adler-32 trailer goes in a last 4-byte IDAT.
+    An image of five bands whose rows favour different filters (flat, horizontal ramp, vertical ramp, smooth, noise)
+    must come back exactly through Pillow (an independent inflate + unfilter) and through our own decoder."""
+    import struct
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    h, w = 1500, 1600
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.empty((h, w, 4), np.uint8)
+    a[..., 0] = (xx * 3) & 255                                   # Sub wins
+    a[..., 1] = (yy * 5) & 255                                   # Up wins
+    a[..., 2] = ((xx + yy) // 2 + rng.integers(0, 3, (h, w))) & 255  # Paeth territory
+    a[..., 3] = 255
+    a[:200] = 77                                                  # None / anything
+    a[700:900, :, :3] = rng.integers(0, 256, (200, w, 3), dtype=np.uint8)
+    p = tmp_path / "bands.png"
+    png.encode(p, a)
+    np.testing.assert_array_equal(np.array(Image.open(p)), a)
+    np.testing.assert_array_equal(png.decode(p), a)
+    d = p.read_bytes()
+    pos, kinds, filters = 8, [], set()
+    while pos < len(d):
+        n, t = struct.unpack(">I", d[pos:pos + 4])[0], d[pos + 4:pos + 8]
+        kinds.append((t, n))
+        pos += 12 + n
+    idat = [n for t, n in kinds if t == b"IDAT"]
+    assert kinds[0] == (b"IHDR", 13) and kinds[-1] == (b"IEND", 0)
+    assert len(idat) == -(-h // ((2 << 20) // (4 * w))) + 1 and idat[-1] == 4   # one chunk per band + the trailer
+    import zlib
+    raw = zlib.decompress(b"".join(d[i:i + n] for i, n in _idat_spans(d)))
+    filters = set(raw[:: 4 * w + 1])
+    assert filters >= {1, 2, 4}
+
+
+def _idat_spans(d):
+    import struct
+    pos = 8
+    while pos < len(d):
+        n, t = struct.unpack(">I", d[pos:pos + 4])[0], d[pos + 4:pos + 8]
+        if t == b"IDAT":
+            yield pos + 8, n
+        pos += 12 + n
+
+
+def test_probe_reads_the_size_from_the_header_of_every_container(png, tmp_path):
+    """probe_image_size: what the CLI sizes its page-locked output with while the decoder still runs -- PNG, BMP (also
+    top-down), PPM with a comment, baseline and progressive JPEG; garbage and truncated headers say 'unknown'."""
+    import ctypes as C
+    from PIL import Image
+    L = C.CDLL(os.path.join(ROOT, "rusty_sr_amd", "libsrpng.so"))
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    files = {}
+    for name, kw in (("a.png", {}), ("a.bmp", {}), ("a.jpg", {}), ("p.jpg", {"progressive": True}), ("a.ppm", {})):
+        Image.fromarray(a).save(tmp_path / name, **kw)
+        files[name] = (53, 37)
+    (tmp_path / "c.ppm").write_bytes(b"P6\n# a comment\n5 # another\n 7\n255\n" + bytes(5 * 7 * 3))
+    files["c.ppm"] = (5, 7)
+    for name, (w, h) in files.items():
+        W, H = C.c_int(), C.c_int()
+        assert L.srpng_probe_size(str(tmp_path / name).encode(), C.byref(W), C.byref(H)) == 0, name
+        assert (W.value, H.value) == (w, h), name
+    for name, data in (("junk.bin", b"hello world, not an image"), ("short.png", (tmp_path / "a.png").read_bytes()[:20]),
+                       ("zero.png", (tmp_path / "a.png").read_bytes()[:16] + bytes(8) + (tmp_path / "a.png").read_bytes()[24:])):
+        (tmp_path / name).write_bytes(data)
+        W, H = C.c_int(), C.c_int()
+        assert L.srpng_probe_size(str(tmp_path / name).encode(), C.byref(W), C.byref(H)) == -1, name
+    assert L.srpng_probe_size(str(tmp_path / "missing.png").encode(), C.byref(W), C.byref(H)) == -1
+
+
 def test_png_colour_types_depths_and_roundtrip(png, tmp_path):
     from PIL import Image
     rng = np.random.default_rng(0)
