@@ -299,7 +299,8 @@ static bool decode_bmp(const uint8_t* d, size_t len, Image& out, std::string& er
     return true;
 }
 
-static bool decode_any_memory(const std::vector<uint8_t>& buf, Image& out, std::string& err);
+bool decode_more_formats(const uint8_t* d, size_t len, bool tga_by_name, Image& out, std::string& err, bool& recognised);  // formats.cpp
+static bool decode_any_memory(const std::vector<uint8_t>& buf, Image& out, std::string& err, bool tga_by_name);
 
 bool probe_image_size(const std::string& path, int& w, int& h) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -329,6 +330,8 @@ bool probe_image_size(const std::string& path, int& w, int& h) {
             while (pos < n && isdigit(b[pos]) && v[k] < (1L << 40)) { v[k] = v[k] * 10 + (b[pos] - '0'); ++pos; }
         }
         W = v[0]; Hh = v[1];
+    } else if (n >= 10 && !memcmp(b.data(), "GIF8", 4)) {
+        W = b[6] | b[7] << 8; Hh = b[8] | b[9] << 8;  // the logical screen, which is what the decoder returns
     } else if (n >= 4 && b[0] == 0xff && b[1] == 0xd8) {
         size_t pos = 2;
         while (pos + 9 < n) {  // marker segments up to the frame header (SOF0 / 1 / 2)
@@ -349,8 +352,16 @@ bool probe_image_size(const std::string& path, int& w, int& h) {
 bool decode_image_file(const std::string& path, Image& out, std::string& err) {
     std::vector<uint8_t> buf;
     if (!read_all(path, buf, err)) return false;
+    // TGA has no magic bytes: like the image crate (which goes by the extension for every format) it is taken by name
+    bool tga = false;
+    {
+        const size_t dot = path.find_last_of('.');
+        std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
+        for (auto& ch : ext) ch = (char)tolower((unsigned char)ch);
+        tga = ext == "tga";
+    }
     try {  // backstop: whatever a hostile header makes a container ask for, the caller gets an error, not a terminate()
-        return decode_any_memory(buf, out, err);
+        return decode_any_memory(buf, out, err, tga);
     } catch (const std::exception& e) {
         err = std::string("image too large or corrupt (") + e.what() + ")";
         out = Image();
@@ -358,13 +369,16 @@ bool decode_image_file(const std::string& path, Image& out, std::string& err) {
     }
 }
 
-static bool decode_any_memory(const std::vector<uint8_t>& buf, Image& out, std::string& err) {
+static bool decode_any_memory(const std::vector<uint8_t>& buf, Image& out, std::string& err, bool tga_by_name) {
     if (buf.size() >= 8 && buf[0] == 0x89 && buf[1] == 'P') return decode_memory(buf.data(), buf.size(), out, err);
     if (buf.size() >= 4 && buf[0] == 0xff && buf[1] == 0xd8) return decode_jpeg_memory(buf.data(), buf.size(), out, err);
     if (buf.size() >= 7 && buf[0] == 'P' && buf[1] >= '1' && buf[1] <= '6' && isspace(buf[2])) return decode_pnm(buf.data(), buf.size(), out, err);
     if (buf.size() >= 54 && buf[0] == 'B' && buf[1] == 'M') return decode_bmp(buf.data(), buf.size(), out, err);
-    err = "unrecognised image format (this build reads PNG, baseline JPEG, PPM/PGM/PBM, BMP)";
-    return false;
+    bool recognised = false;
+    const bool ok = decode_more_formats(buf.data(), buf.size(), tga_by_name, out, err, recognised);  // GIF, TIFF, ICO, TGA
+    if (!recognised) err = "unrecognised image format (this build reads PNG, JPEG, GIF, TIFF, BMP, ICO, TGA, PPM/PGM/PBM)";
+    if (!ok) out = Image();
+    return ok;
 }
 
 bool decode_file(const std::string& path, Image& out, std::string& err) {

@@ -3,7 +3,7 @@
 // DynamicImage::to_rgba().save main.rs:175).  Decodes non-interlaced and Adam7
 // PNGs of colour types 0/2/3/4/6 at 1..16 bits to RGBA8 (16-bit samples keep their
 // high byte; no gamma / colour management, like the reference); encodes RGBA8.  Plus the other containers the CLI
-// reads (JPEG baseline + progressive, PNM, BMP) and writes (PNG, JPEG, BMP, PPM).
+// reads (JPEG baseline + progressive, GIF, TIFF, TGA, ICO, PNM, BMP) and writes (PNG, JPEG, BMP, PPM).
 #pragma once
 #include <cstdint>
 #include <string>
@@ -18,9 +18,10 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
 unsigned usable_cpus();  // affinity mask capped by the cgroup CPU quota
 // baseline JPEG (jpeg.cpp); binary PPM / PGM and uncompressed 24 / 32-bit BMP (png.cpp)
 bool decode_jpeg_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
-// image::open stand-in: picks the decoder from the file's magic bytes (PNG, JPEG, PPM/PGM, BMP)
+// image::open stand-in: picks the decoder from the file's magic bytes (PNG, JPEG, GIF, TIFF, BMP, ICO, PPM/PGM/PBM;
+// formats.cpp has GIF / TIFF / ICO / TGA) -- TGA, which has none, from the .tga extension
 bool decode_image_file(const std::string& path, Image& out, std::string& err);
-// width / height from the first bytes of the file (PNG, BMP, PNM, JPEG with its frame header in the first 64 KB) without
+// width / height from the first bytes of the file (PNG, BMP, GIF, PNM, JPEG with its frame header in the first 64 KB) without
 // decoding it: lets the CLI size its buffers while the decoder still runs.  false: unknown (decode will tell).
 bool probe_image_size(const std::string& path, int& w, int& h);
 // `.save(path)` stand-in (reference main.rs:175: the image crate picks the container from the extension):

@@ -1,7 +1,7 @@
-"""The hand-written decoders of the host CLI (rusty_sr_amd/host/png.cpp, jpeg.cpp: the stand-ins for `image::open`,
+"""The hand-written decoders of the host CLI (rusty_sr_amd/host/png.cpp, jpeg.cpp, formats.cpp: the stand-ins for `image::open`,
 reference main.rs:164) parse untrusted files.  They are built under AddressSanitizer + UBSan
 (rusty_sr_amd/bin/srcodec_asan) and fed truncated, bit-flipped and chunk-mangled variants of the seven reference PNGs
-and of JPEG / PNM / BMP files: every file must end in "ok WxH" or a clean "error: ..." line -- the counterpart of the
+and of JPEG / PNM / BMP / GIF / TIFF / TGA / ICO files: every file must end in "ok WxH" or a clean "error: ..." line -- the counterpart of the
 reference's `.expect("Error opening input image file.")` -- never in a sanitizer report, crash, hang or huge
 allocation."""
 import io
@@ -54,6 +54,16 @@ def _seed_files(tmp):
     b = io.BytesIO(); img.save(b, "PNG", interlace=1); seeds["adam7.png"] = b.getvalue()
     b = io.BytesIO(); img.save(b, "PPM"); seeds["rgb.ppm"] = b.getvalue()
     b = io.BytesIO(); img.save(b, "BMP"); seeds["rgb.bmp"] = b.getvalue()
+    # formats.cpp: GIF, TIFF, TGA (taken by its extension), ICO
+    smooth = Image.fromarray((np.add.outer(np.arange(37) * 5, np.arange(53) * 3)[..., None] + np.arange(3) * 40).astype(np.uint8))
+    for tag, fmt, im, kw in (("a.gif", "GIF", smooth.convert("P"), {}), ("i.gif", "GIF", img.convert("P"), {"interlace": True}),
+                             ("lzw.tif", "TIFF", smooth, {"compression": "tiff_lzw"}), ("pred.tif", "TIFF", smooth, {"compression": "tiff_lzw", "tiffinfo": {317: 2}}),
+                             ("pb.tif", "TIFF", smooth, {"compression": "packbits"}), ("def.tif", "TIFF", img, {"compression": "tiff_adobe_deflate"}),
+                             ("raw.tif", "TIFF", img, {"compression": "raw"}), ("p.tif", "TIFF", img.convert("P"), {}), ("bw.tif", "TIFF", img.convert("1"), {}),
+                             ("a.tga", "TGA", img, {}), ("rle.tga", "TGA", smooth, {"compression": "tga_rle"}), ("p.tga", "TGA", img.convert("P"), {}),
+                             ("png.ico", "ICO", img.convert("RGBA"), {"sizes": [(32, 32)]}),
+                             ("bmp.ico", "ICO", img.convert("RGBA"), {"sizes": [(32, 32)], "bitmap_format": "bmp"})):
+        b = io.BytesIO(); im.save(b, fmt, **kw); seeds[tag] = b.getvalue()
     return seeds
 
 
@@ -91,7 +101,7 @@ def test_truncated_and_bit_flipped_files_fail_cleanly(harness, tmp_path):
             pos = int(rng.integers(0, max(1, len(b) - 16)))
             b[pos:pos + 16] = rng.integers(0, 256, 16, dtype=np.uint8).tobytes()
             p = tmp_path / f"{stem}_junk{k}{ext}"; p.write_bytes(bytes(b)); paths.append(p)
-    assert len(paths) > 800
+    assert len(paths) > 1500
     for i in range(0, len(paths), 200):
         _run(harness, paths[i:i + 200])
 
@@ -135,6 +145,59 @@ def test_hostile_png_headers(harness, tmp_path):
     for name in ("huge", "wide", "zero_w", "depth3", "ct5", "rgb16_as_pal", "short_idat", "bad_filter", "no_plte", "len_past_eof",
                  "len_negative", "not_zlib", "adam7_short"):
         assert lines[name].startswith("error: "), (name, lines[name])
+
+
+def test_hostile_gif_tiff_tga_ico_headers(harness, tmp_path):
+    """A few bytes must not buy a gigabyte, an offset must not leave the file, a code must not leave its table."""
+    def tiff(entries, data=b"", be=False):
+        e = ">" if be else "<"
+        out = (b"MM\x00*" if be else b"II*\x00") + struct.pack(e + "I", 8) + struct.pack(e + "H", len(entries))
+        for tag, typ, cnt, val in entries:
+            out += struct.pack(e + "HHI", tag, typ, cnt) + (struct.pack(e + "I", val) if typ == 4 else struct.pack(e + "HH", val, 0))
+        return out + struct.pack(e + "I", 0) + data
+    base = [(256, 4, 1, 4), (257, 4, 1, 4), (258, 3, 1, 8), (259, 3, 1, 1), (262, 3, 1, 1), (277, 3, 1, 1), (278, 4, 1, 4)]
+    gif_hdr = lambda sw, sh: b"GIF89a" + struct.pack("<HH", sw, sh) + b"\x80\x00\x00" + bytes(6)
+    gif_img = lambda x, y, w, h, data: b"\x2c" + struct.pack("<HHHH", x, y, w, h) + b"\x00\x02" + bytes([len(data)]) + data + b"\x00\x3b"
+    tga = lambda typ, w, h, bpp, rest, cm=(0, 0, 0, 0): bytes([0, cm[0], typ]) + struct.pack("<HHB", cm[1], cm[2], cm[3]) + bytes(4) + struct.pack("<HHBB", w, h, bpp, 0) + rest
+    ico = lambda w, h, size, off, payload: b"\x00\x00\x01\x00\x01\x00" + bytes([w, h, 0, 0, 1, 0, 32, 0]) + struct.pack("<II", size, off) + payload
+    dib = lambda w, h2, bpp: struct.pack("<IiiHHIIiiII", 40, w, h2, 1, bpp, 0, 0, 0, 0, 0, 0)
+    cases = {
+        "screen_huge.gif": gif_hdr(16000, 16000) + gif_img(0, 0, 2, 2, b"\x44\x01"),
+        "frame_outside.gif": gif_hdr(4, 4) + gif_img(3, 3, 4, 4, b"\x44\x01"),
+        "lzw_bad_code.gif": gif_hdr(4, 4) + gif_img(0, 0, 4, 4, b"\xff\xff\xff\xff"),
+        "lzw_short.gif": gif_hdr(64, 64) + gif_img(0, 0, 64, 64, b"\x44\x01"),
+        "min_bits_13.gif": gif_hdr(4, 4) + b"\x2c" + bytes(8) + b"\x00\x0d\x01\x00\x00\x3b",
+        "no_image.gif": gif_hdr(4, 4) + b"\x3b",
+        "ext_past_eof.gif": gif_hdr(4, 4) + b"\x21\xf9\xff" + bytes(5),
+        "huge.tif": tiff([(256, 4, 1, 1 << 20), (257, 4, 1, 200)] + base[2:] + [(273, 4, 1, 8), (279, 4, 1, 4)]),
+        "strip_past_eof.tif": tiff(base + [(273, 4, 1, 0x7ffffff0), (279, 4, 1, 16)], bytes(16)),
+        "count_past_eof.tif": tiff(base + [(273, 4, 1, 8), (279, 4, 1, 0x7ffffff0)], bytes(16)),
+        "ifd_past_eof.tif": b"II*\x00" + struct.pack("<I", 0x7ffffff0),
+        "entries_past_eof.tif": b"II*\x00" + struct.pack("<I", 8) + struct.pack("<H", 60000),
+        "no_strips.tif": tiff(base),
+        "bits_7.tif": tiff([(256, 4, 1, 4), (257, 4, 1, 4), (258, 3, 1, 7)] + base[3:] + [(273, 4, 1, 8), (279, 4, 1, 16)], bytes(16)),
+        "tiled.tif": tiff(base + [(322, 4, 1, 16), (273, 4, 1, 8), (279, 4, 1, 16)], bytes(16)),
+        "lzw_garbage.tif": tiff(base[:3] + [(259, 3, 1, 5)] + base[4:] + [(273, 4, 1, 8), (279, 4, 1, 16)], b"\xff" * 16),
+        "rows_per_strip_0.tif": tiff(base[:6] + [(278, 4, 1, 0), (273, 4, 1, 8), (279, 4, 1, 16)], bytes(16)),
+        "be_short.tif": tiff(base + [(273, 4, 1, 8), (279, 4, 1, 3)], bytes(3), be=True),
+        "huge.tga": tga(2, 60000, 60000, 24, bytes(30)),
+        "short.tga": tga(2, 16, 16, 24, bytes(30)),
+        "rle_short.tga": tga(10, 16, 16, 24, b"\xff\x01\x02\x03"),
+        "rle_huge.tga": tga(10, 16000, 16000, 24, b"\xff\x01\x02\x03"),
+        "cmap_oob.tga": tga(1, 2, 2, 8, bytes(6) + b"\x05\x00\x00\x00", cm=(1, 0, 2, 24)),
+        "type_7.tga": tga(7, 2, 2, 24, bytes(12)),
+        "entry_past_eof.ico": ico(16, 16, 0x7ffffff0, 22, bytes(64)),
+        "off_past_eof.ico": ico(16, 16, 64, 0x7ffffff0, bytes(64)),
+        "dib_huge.ico": ico(0, 0, 104, 22, dib(100000, 200000, 32) + bytes(64)),
+        "dib_short.ico": ico(16, 16, 104, 22, dib(16, 32, 32) + bytes(64)),
+        "count_huge.ico": b"\x00\x00\x01\x00\xff\xff" + bytes(40),
+    }
+    paths = []
+    for name, data in cases.items():
+        p = tmp_path / name; p.write_bytes(data); paths.append(p)
+    lines = dict(zip(cases, _run(harness, paths)))
+    for name, line in lines.items():
+        assert line.startswith("error: "), (name, line)
 
 
 def test_hostile_jpeg_and_pnm_and_bmp_headers(harness, tmp_path):
