@@ -3,8 +3,9 @@
 //
 //   rusty_sr <INPUT_FILE> <OUTPUT_FILE> [-p imagenet|imagenetlinear|anime|bilinear] [-c FILE] [-d]
 //
-// Differences from the reference, all outside the hot path: own codecs (PNG over zlib, baseline + progressive JPEG,
-// PPM/PGM/PBM, BMP in; PNG, JPEG, BMP, PPM out by extension -- the reference's `image` crate also knows GIF, TIFF, WebP, ICO), the `train` sub-command
+// Differences from the reference, all outside the hot path: own codecs (PNG over zlib, baseline + progressive JPEG, GIF,
+// TIFF, TGA, ICO, PPM/PGM/PBM, BMP in; PNG, JPEG, BMP, PPM out by extension -- of what the reference's `image` crate reads
+// only WebP is missing), the `train` sub-command
 // is not part of this build, and three extra options that cannot collide with the
 // reference's (-p -c -d): --device N, --precision f32|split_f16, --timing.
 #include <cstdio>
