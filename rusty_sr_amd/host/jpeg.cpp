@@ -7,7 +7,9 @@
 // with libjpeg's triangle filter for 2:1 ratios and the IDCT is a plain float separable transform,
 // so pixels can differ from libjpeg's by a few levels -- as they do between any two JPEG decoders.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -438,13 +440,15 @@ struct BitWriter {
     void flush() { if (cnt) put(0x7f, 8 - cnt); }
 };
 void fdct8x8(const float* in, float* out) {  // plain separable forward DCT-II (orthonormal JPEG scaling)
-    static float c[8][8];
-    static bool init = false;
-    if (!init) {
-        for (int u = 0; u < 8; ++u)
-            for (int x = 0; x < 8; ++x) c[u][x] = (u == 0 ? std::sqrt(0.125f) : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846f / 16.0f);
-        init = true;
-    }
+    struct Basis {
+        float c[8][8];
+        Basis() {
+            for (int u = 0; u < 8; ++u)
+                for (int x = 0; x < 8; ++x) c[u][x] = (u == 0 ? std::sqrt(0.125f) : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846f / 16.0f);
+        }
+    };
+    static const Basis basis;  // initialised once, thread-safely: the encoder's workers all land here
+    const auto& c = basis.c;
     float tmp[64];
     for (int y = 0; y < 8; ++y)
         for (int u = 0; u < 8; ++u) { float s = 0; for (int x = 0; x < 8; ++x) s += c[u][x] * in[y * 8 + x]; tmp[y * 8 + u] = s; }
@@ -471,15 +475,23 @@ bool encode_jpeg_file(const std::string& path, const uint8_t* rgba, int w, int h
     auto dht = [&](int tc_th, const uint8_t* bits16, const uint8_t* vals, int nvals) {
         marker(0xc4, 17 + nvals); out.push_back((uint8_t)tc_th); out.insert(out.end(), bits16, bits16 + 16); out.insert(out.end(), vals, vals + nvals); };
     dht(0x00, kDcLumBits, kDcVals, 12); dht(0x10, kAcLumBits, kAcLumVals, 162); dht(0x01, kDcChrBits, kDcVals, 12); dht(0x11, kAcChrBits, kAcChrVals, 162);
+    // One restart interval per row of 8x8 blocks (DRI): every interval starts with fresh DC predictors on a byte boundary,
+    // so the rows are entropy-coded independently -- by a pool of threads, each into its own buffer -- and joined with
+    // RST0..7 markers.  (The colour transform, DCT and Huffman coding of a 5760x3240 output took 283 ms on one core.)
+    const int mcu_w = (w + 7) / 8, mcu_h = (h + 7) / 8;
+    if (mcu_h > 1) { marker(0xdd, 2); put16(mcu_w); }
     marker(0xda, 10); out.push_back(3);
     for (int c = 0; c < 3; ++c) { out.push_back((uint8_t)(c + 1)); out.push_back((uint8_t)(c ? 0x11 : 0x00)); }
     out.push_back(0); out.push_back(63); out.push_back(0);
     const EncTable dcT[2] = {make_enc(kDcLumBits, kDcVals), make_enc(kDcChrBits, kDcVals)};
     const EncTable acT[2] = {make_enc(kAcLumBits, kAcLumVals), make_enc(kAcChrBits, kAcChrVals)};
-    BitWriter bw{out};
-    int pred[3] = {0, 0, 0};
-    for (int by = 0; by < (h + 7) / 8; ++by)
-        for (int bx = 0; bx < (w + 7) / 8; ++bx) {
+    std::vector<std::vector<uint8_t>> rows(mcu_h);
+    auto encode_row = [&](int by) {
+        std::vector<uint8_t>& seg = rows[by];
+        seg.reserve((size_t)mcu_w * 48);
+        BitWriter bw{seg};
+        int pred[3] = {0, 0, 0};
+        for (int bx = 0; bx < mcu_w; ++bx) {
             float px[3][64];
             for (int y = 0; y < 8; ++y)
                 for (int x = 0; x < 8; ++x) {
@@ -514,7 +526,22 @@ bool encode_jpeg_file(const std::string& path, const uint8_t* rgba, int w, int h
                 if (run) bw.put(acT[t].code[0], acT[t].len[0]);
             }
         }
-    bw.flush();
+        bw.flush();
+    };
+    {
+        std::atomic<int> next{0};
+        auto worker = [&] { for (int by; (by = next.fetch_add(1)) < mcu_h;) encode_row(by); };
+        const int nthr = (int)std::min<size_t>(usable_cpus(), (size_t)std::max(1, mcu_h / 4));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthr; ++t) th.emplace_back(worker);
+        worker();
+        for (auto& t : th) t.join();
+    }
+    for (int by = 0; by < mcu_h; ++by) {
+        out.insert(out.end(), rows[by].begin(), rows[by].end());
+        std::vector<uint8_t>().swap(rows[by]);
+        if (by + 1 < mcu_h) { out.push_back(0xff); out.push_back((uint8_t)(0xd0 + (by & 7))); }
+    }
     out.push_back(0xff); out.push_back(0xd9);
     FILE* fo = fopen(path.c_str(), "wb");
     if (!fo) { err = "cannot create file"; return false; }

@@ -11,7 +11,9 @@
 #include <exception>
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <sched.h>
 
@@ -455,53 +457,61 @@ static int filter_row(const uint8_t* cur, const uint8_t* prev, size_t stride, ui
 // (the pigz construction).  The segment comes back wrapped as a complete IDAT chunk -- length, type, data, CRC -- so the
 // CRC is computed here too, in parallel; the first band's data starts with the two zlib header bytes.
 static bool encode_band(const uint8_t* rgba, int w, int y0, int y1, bool first, bool last, int zlevel,
-                        std::vector<uint8_t>& chunk, uLong& adler, size_t& raw_len) {
+                        uint8_t* raw /* (stride + 1) * rows */, uint8_t* cand /* 4 * stride */, uint8_t* chunk, size_t cap, size_t& chunk_len,
+                        uLong& adler, size_t& raw_len) {
     const size_t stride = (size_t)w * 4;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)(y1 - y0)), cand(4 * stride);
     for (int y = y0; y < y1; ++y) {
         const uint8_t* cur = rgba + (size_t)y * stride;
         const uint8_t* prev = y ? cur - stride : nullptr;  // the row above, also across band seams
-        uint8_t* dst = raw.data() + (size_t)(y - y0) * (stride + 1);
-        const int ft = filter_row(cur, prev, stride, cand.data());
+        uint8_t* dst = raw + (size_t)(y - y0) * (stride + 1);
+        const int ft = filter_row(cur, prev, stride, cand);
         dst[0] = (uint8_t)ft;
-        memcpy(dst + 1, cand.data() + (ft == 4 ? 3 : ft) * stride, stride);
+        memcpy(dst + 1, cand + (ft == 4 ? 3 : ft) * stride, stride);
     }
-    raw_len = raw.size();
-    if (raw.size() > 0xfffffff0u) return false;  // zlib's uInt counters: never truncate silently
-    adler = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
+    raw_len = (stride + 1) * (size_t)(y1 - y0);
+    if (raw_len > 0xfffffff0u) return false;  // zlib's uInt counters: never truncate silently
+    adler = adler32(adler32(0L, Z_NULL, 0), raw, (uInt)raw_len);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, zlevel, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    // Z_RLE (matches at distance 1 only: runs) + dynamic Huffman.  On filtered residuals of continuous-tone images longer
+    // LZ77 matches are rare and distort the literal statistics: measured on upscaled photographs and on the reference's
+    // cartoon output, RLE files are 3-20 % SMALLER than zlib levels 1-6 and deflate 1.5x faster than level 2 (13x level 6).
+    // zlevel <= 0 keeps the general matcher (level 3): flat synthetic images with repeating patterns want it.
+    if (deflateInit2(&zs, zlevel > 0 ? zlevel : 3, Z_DEFLATED, -15, 8, zlevel > 0 ? Z_RLE : Z_DEFAULT_STRATEGY) != Z_OK) return false;
     const size_t head = 8 + (first ? 2 : 0);
-    chunk.resize(head + deflateBound(&zs, (uLong)raw.size()) + 16 + 4);
-    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
-    zs.next_out = chunk.data() + head; zs.avail_out = (uInt)(chunk.size() - head - 4);
+    if (cap < head + deflateBound(&zs, (uLong)raw_len) + 16 + 4) { deflateEnd(&zs); return false; }
+    zs.next_in = raw; zs.avail_in = (uInt)raw_len;
+    zs.next_out = chunk + head; zs.avail_out = (uInt)(cap - head - 4);
     const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
     const bool ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0);
-    const size_t n = head - 8 + (chunk.size() - head - 4 - zs.avail_out);  // chunk data bytes
+    const size_t n = head - 8 + (cap - head - 4 - zs.avail_out);  // chunk data bytes
     deflateEnd(&zs);
     if (!ok || n > 0x7fffffffu) return false;
-    chunk.resize(8 + n + 4);
     chunk[0] = (uint8_t)(n >> 24); chunk[1] = (uint8_t)(n >> 16); chunk[2] = (uint8_t)(n >> 8); chunk[3] = (uint8_t)n;
-    memcpy(chunk.data() + 4, "IDAT", 4);
+    memcpy(chunk + 4, "IDAT", 4);
     if (first) { chunk[8] = 0x78; chunk[9] = 0x5e; }  // zlib header: deflate, 32 KB window, check bits
-    const uint32_t crc = (uint32_t)crc32(0, chunk.data() + 4, (uInt)(n + 4));
-    uint8_t* t = chunk.data() + 8 + n;
+    const uint32_t crc = (uint32_t)crc32(0, chunk + 4, (uInt)(n + 4));
+    uint8_t* t = chunk + 8 + n;
     t[0] = (uint8_t)(crc >> 24); t[1] = (uint8_t)(crc >> 16); t[2] = (uint8_t)(crc >> 8); t[3] = (uint8_t)crc;
+    chunk_len = 8 + n + 4;
     return true;
 }
 
 bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int zlevel) {
     if (w <= 0 || h <= 0 || !rgba) { err = "empty image"; return false; }
     // At 4K-in the RGBA output is 299 MB: a single-threaded filter + deflate would dwarf the GPU time (SURVEY.md 8(f)
-    // item 2).  Row bands of ~2 MB are filtered, deflated and wrapped as IDAT chunks by a pool of worker threads that
+    // item 2).  Row bands of 1-2 MB are filtered, deflated and wrapped as IDAT chunks by a pool of worker threads that
     // take them in order; this thread writes each chunk as soon as all before it are out, so compression, CRC and the
     // file write overlap and nothing is concatenated in memory.
     const size_t stride = (size_t)w * 4, bytes = stride * h;
-    if (zlevel < 0) zlevel = bytes > ((size_t)8 << 20) ? 2 : 3;  // large images: a fast level (75 MB of pixels: level 1 / 2 / 3 / 6 = 31.6 / 30.6 / 29.2 / 27.0 MB in 265 / 270 / 370 / 1400 ms on 8 threads)
-    const int rows_per = (int)std::max<size_t>(1, ((size_t)2 << 20) / stride);
+    if (zlevel < 0) zlevel = 1;  // run-length + Huffman (encode_band)
+    // bands of 1-2 MB, their number a multiple of the worker count so that the last round of bands is a full one
+    const size_t cpus = usable_cpus();
+    const size_t per_thread = (bytes / cpus + ((size_t)3 << 19) - 1) / ((size_t)3 << 19);  // bands per worker at ~1.5 MB each
+    const size_t target = std::max<size_t>(1, std::min<size_t>((size_t)h, cpus * std::max<size_t>(1, per_thread)));
+    const int rows_per = bytes <= ((size_t)1 << 20) ? h : (int)(((size_t)h + target - 1) / target);
     const int nband = (h + rows_per - 1) / rows_per;
-    const int nthr = (int)std::min<size_t>(usable_cpus(), (size_t)nband);
+    const int nthr = (int)std::min<size_t>(cpus, (size_t)nband);
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { err = "cannot create file"; return false; }
     std::vector<uint8_t> head = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
@@ -520,7 +530,13 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
     chunk(head, "IHDR", ihdr, 13);
     bool ok = fwrite(head.data(), 1, head.size(), f) == head.size();
 
-    std::vector<std::vector<uint8_t>> parts(nband);
+    // One arena for all chunks, each band at its worst-case offset: `new[]` leaves the pages untouched, so only what the
+    // compressed data really covers is ever faulted in, and no allocation happens per band (a fresh process -- which the
+    // CLI always is -- would send each multi-MB vector through mmap / munmap).  Filter scratch is per worker, allocated once.
+    const size_t slot = 8 + 2 + (size_t)compressBound((uLong)((stride + 1) * rows_per)) + 64;
+    std::unique_ptr<uint8_t[]> arena(new (std::nothrow) uint8_t[slot * nband]);
+    if (!arena) { fclose(f); err = "out of memory"; return false; }
+    std::vector<size_t> part_len(nband, 0);
     std::vector<uLong> adl(nband);
     std::vector<size_t> rawlen(nband);
     std::vector<char> state(nband, 0);  // 0 pending, 1 done, 2 failed
@@ -528,12 +544,15 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
     std::condition_variable cv;
     std::atomic<int> next{0};
     auto worker = [&] {
+        std::unique_ptr<uint8_t[]> raw(new (std::nothrow) uint8_t[(stride + 1) * rows_per]), cand(new (std::nothrow) uint8_t[4 * stride]);
         for (;;) {
             const int b = next.fetch_add(1);
             if (b >= nband) return;
             const int y0 = b * rows_per, y1 = std::min(h, y0 + rows_per);
             bool good = false;
-            try { good = encode_band(rgba, w, y0, y1, b == 0, b == nband - 1, zlevel, parts[b], adl[b], rawlen[b]); } catch (...) { good = false; }
+            if (raw && cand)
+                good = encode_band(rgba, w, y0, y1, b == 0, b == nband - 1, zlevel, raw.get(), cand.get(), arena.get() + slot * b, slot, part_len[b],
+                                   adl[b], rawlen[b]);
             { std::lock_guard<std::mutex> lk(mu); state[b] = good ? 1 : 2; }
             cv.notify_all();
         }
@@ -546,10 +565,9 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return state[b] != 0; }); }
         if (state[b] == 2) failed = true;
         if (!failed && ok) {
-            ok = fwrite(parts[b].data(), 1, parts[b].size(), f) == parts[b].size();
+            ok = fwrite(arena.get() + slot * b, 1, part_len[b], f) == part_len[b];
             adler = adler32_combine(adler, adl[b], (z_off_t)rawlen[b]);
         }
-        std::vector<uint8_t>().swap(parts[b]);
     }
     for (auto& t : th) t.join();
     if (failed) { fclose(f); err = "deflate failed"; return false; }

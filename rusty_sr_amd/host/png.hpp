@@ -13,7 +13,8 @@ namespace srpng {
 struct Image { int w = 0, h = 0; std::vector<uint8_t> rgba; };
 bool decode_file(const std::string& path, Image& out, std::string& err);
 bool decode_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
-// zlevel < 0: by size (level 3 up to 8 MB of pixels, level 1 above)
+// zlevel > 0 (default): run-length matches + dynamic Huffman, the fast and -- on filtered continuous-tone pixels -- also
+// the smaller choice; zlevel == 0: zlib's general matcher at level 3
 bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int zlevel = -1);
 unsigned usable_cpus();  // affinity mask capped by the cgroup CPU quota
 // baseline JPEG (jpeg.cpp); binary PPM / PGM and uncompressed 24 / 32-bit BMP (png.cpp)
