@@ -132,11 +132,11 @@ int prepare_band(sr_ctx* c, const void* d_band, int h_band, int w, size_t px_byt
 int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, int w, void* d_out, hipStream_t s) {
     if (!d_out) return SR_E_INVALID;
     if (u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    if (c && c->comm_nranks > 1 && c->comm_local) return SR_E_COMM;  // the neighbours' rows are only known to sr_upscale_sharded_*_all
     BandGeom g;
     int rc = prepare_band(c, d_band, h_band, w, u8 ? (size_t)img_ch : 3 * sizeof(float), g, s);
     if (rc != SR_OK) return rc;
     if (c->comm_nranks > 1) {
-        if (c->comm_local) return SR_E_COMM;  // the neighbours' rows are only known to sr_upscale_sharded_*_all
         Rccl* R = rccl();
         if (!R) return SR_E_COMM;
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[0], s));
@@ -172,37 +172,45 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
     if (n > 1 && !local && !R) return SR_E_COMM;
     std::vector<BandGeom> g(n);
     const size_t px = u8 ? (size_t)img_ch : 3 * sizeof(float);
-    for (int k = 0; k < n; ++k) {
-        rc = prepare_band(ctxs[k], d_bands[k], h_bands[k], w, px, g[k], ctxs[k]->stream);
-        if (rc != SR_OK) return rc;
-    }
-    if (local) {
+    if (n > 1)
         for (int k = 0; k < n; ++k)
-            if (n > 1 && h_bands[k] < SR_HALO) return SR_E_HALO;
+            if (h_bands[k] < SR_HALO) return SR_E_HALO;  // a neighbour reads SR_HALO rows of every band
+    // From here on work is queued on the contexts' streams: whatever fails, every stream is drained before the call
+    // returns (the copies read the caller's buffers).
+    auto hip = [&](sr_ctx* c, hipError_t e) -> int {
+        if (e == hipSuccess) return SR_OK;
+        c->last_hip = (int)e;
+        return e == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP;
+    };
+    for (int k = 0; k < n && rc == SR_OK; ++k) rc = prepare_band(ctxs[k], d_bands[k], h_bands[k], w, px, g[k], ctxs[k]->stream);
+    if (rc == SR_OK && local) {
         // every context pulls its halos from the neighbours' bands -- caller buffers that are complete before this
         // (synchronous) call, so no cross-stream ordering is needed
         for (int k = 0; k < n && rc == SR_OK; ++k) {
             sr_ctx* c = ctxs[k];
             const size_t halo = (size_t)SR_HALO * g[k].row_bytes;
             char* ext = (char*)c->d_ext;
-            (void)hipSetDevice(c->device);
-            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[0], c->stream));
-            if (g[k].top)
-                HIPCHK(c, hipMemcpyPeerAsync(ext, c->device, (const char*)d_bands[k - 1] + (size_t)(h_bands[k - 1] - SR_HALO) * g[k].row_bytes,
-                                             ctxs[k - 1]->device, halo, c->stream));
-            if (g[k].bot)
-                HIPCHK(c, hipMemcpyPeerAsync(ext + (size_t)(g[k].top + h_bands[k]) * g[k].row_bytes, c->device, d_bands[k + 1],
-                                             ctxs[k + 1]->device, halo, c->stream));
-            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[1], c->stream));
+            rc = hip(c, hipSetDevice(c->device));
+            if (rc == SR_OK && c->profiling) rc = hip(c, hipEventRecord(c->ev_comm[0], c->stream));
+            if (rc == SR_OK && g[k].top)
+                rc = hip(c, hipMemcpyPeerAsync(ext, c->device, (const char*)d_bands[k - 1] + (size_t)(h_bands[k - 1] - SR_HALO) * g[k].row_bytes,
+                                               ctxs[k - 1]->device, halo, c->stream));
+            if (rc == SR_OK && g[k].bot)
+                rc = hip(c, hipMemcpyPeerAsync(ext + (size_t)(g[k].top + h_bands[k]) * g[k].row_bytes, c->device, d_bands[k + 1],
+                                               ctxs[k + 1]->device, halo, c->stream));
+            if (rc == SR_OK && c->profiling) rc = hip(c, hipEventRecord(c->ev_comm[1], c->stream));
         }
-    } else if (n > 1) {
-        NCCLCHK(ctxs[0], R->GroupStart());
+    } else if (rc == SR_OK && n > 1) {
+        ncclResult_t gs = R->GroupStart();
+        if (gs != ncclSuccess) { ctxs[0]->last_nccl = (int)gs; rc = SR_E_COMM; }
         for (int k = 0; k < n && rc == SR_OK; ++k) {
             (void)hipSetDevice(ctxs[k]->device);
             rc = post_exchange(ctxs[k], R, d_bands[k], h_bands[k], g[k], ctxs[k]->stream);
         }
-        const ncclResult_t ge = R->GroupEnd();
-        if (rc == SR_OK && ge != ncclSuccess) { ctxs[0]->last_nccl = (int)ge; rc = SR_E_COMM; }
+        if (gs == ncclSuccess) {
+            const ncclResult_t ge = R->GroupEnd();
+            if (rc == SR_OK && ge != ncclSuccess) { ctxs[0]->last_nccl = (int)ge; rc = SR_E_COMM; }
+        }
     }
     for (int k = 0; k < n && rc == SR_OK; ++k)
         rc = sr_run_stack(ctxs[k], ctxs[k]->d_ext, u8, img_ch, 1, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, ctxs[k]->stream);
