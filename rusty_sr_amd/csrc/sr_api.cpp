@@ -844,6 +844,17 @@ int check_context_set(sr_ctx* const* ctxs, int n_ctx) {
     return SR_OK;
 }
 
+// A share on its own host thread -- or, should the system refuse another thread, right here: no exception may cross the C ABI
+// with joinable threads behind it.
+template <class F>
+void spawn_or_run(std::vector<std::thread>& th, F fn) {
+    try {
+        th.emplace_back(fn);
+    } catch (const std::exception&) {
+        fn();
+    }
+}
+
 }  // namespace
 
 int sr_check_context_set(sr_ctx* const* ctxs, int n_ctx) { return check_context_set(ctxs, n_ctx); }
@@ -906,7 +917,7 @@ static int run_multi(sr_ctx* const* ctxs, int n_ctx, const void* in, bool img_u8
     std::vector<int> rc(parts, SR_OK);
     std::vector<std::thread> th;
     for (int k = 0; k < parts; ++k)
-        th.emplace_back([&, k] { rc[k] = run_host(ctxs[k], in, img_u8, img_ch, Deal{0, 1, 1}, h, w, out, out_u8, lo[k], hi[k]); });
+        spawn_or_run(th, [&, k] { rc[k] = run_host(ctxs[k], in, img_u8, img_ch, Deal{0, 1, 1}, h, w, out, out_u8, lo[k], hi[k]); });
     for (auto& t : th) t.join();
     for (int k = 0; k < parts; ++k)
         if (rc[k] != SR_OK) return rc[k];
@@ -934,7 +945,7 @@ static int run_batch_multi(sr_ctx* const* ctxs, int n_ctx, const void* in, bool 
     std::vector<int> rc(used, SR_OK);
     std::vector<std::thread> th;
     for (int k = 0; k < used; ++k)
-        th.emplace_back([&, k] { rc[k] = run_host(ctxs[k], in, img_u8, img_ch, Deal{k, used, (n - k + used - 1) / used}, h, w, out, out_u8); });
+        spawn_or_run(th, [&, k] { rc[k] = run_host(ctxs[k], in, img_u8, img_ch, Deal{k, used, (n - k + used - 1) / used}, h, w, out, out_u8); });
     for (auto& t : th) t.join();
     for (int k = 0; k < used; ++k)
         if (rc[k] != SR_OK) return rc[k];
