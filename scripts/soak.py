@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Soak: random shapes, batches and band halos through the pipe / column kernels against the first-form kernels (an
+independent code path, bit-identical by construction), interleaved so that every call changes the workspace geometry, plus
+repeated 1080p calls that must reproduce themselves bit for bit (a missed vmcnt / barrier shows up as a flicker).
+    python scripts/soak.py [seconds]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def soak(budget, seed=None):
+    import torch
+    import rusty_sr_amd as r
+    params = r.rsr.builtin("imagenet")
+    rng = np.random.default_rng(int(time.time()) & 0xffff if seed is None else seed)
+    t_end = time.time() + budget
+    stats = {"shapes": 0, "repeats": 0, "bands": 0}
+    bad = []
+    for prec in ("f32", "split_f16"):
+        a, b = r.Engine(params, precision=prec), r.Engine(params, precision=prec)
+        b.set_experiment("pipe", "none")
+        big = torch.from_numpy(rng.integers(0, 256, (1, 1080, 1920, 3), dtype=np.uint8)).cuda()
+        first = a.upscale_rgba8_dev(big).clone()
+        t_prec = time.time() + (t_end - time.time()) / (2 if prec == "f32" else 1)
+        while time.time() < t_prec:
+            n = int(rng.choice([1, 1, 1, 2, 3]))
+            h, w = int(rng.integers(1, 700)), int(rng.integers(1, 1000))
+            if rng.random() < 0.15:
+                h, w = int(rng.integers(700, 1400)), int(rng.integers(1000, 2200))
+            if rng.random() < 0.1:
+                h, w = int(rng.integers(1, 12)), int(rng.integers(1, 4000))
+            px = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+            ga, gb = a.upscale_rgba8_dev(px), b.upscale_rgba8_dev(px)
+            if not torch.equal(ga, gb):
+                bad.append((prec, "shape", n, h, w))
+            stats["shapes"] += 1
+            if n == 1 and h > 30:  # a band of it with halos must equal the same rows of the whole
+                y0 = int(rng.integers(7, h - 15))
+                y1 = int(rng.integers(y0 + 1, h - 7))
+                band = a.upscale_band_rgba8_dev(px[0, y0 - 7:y1 + 7].contiguous(), 7, 7)
+                if not torch.equal(band, ga[0, 3 * y0:3 * y1]):
+                    bad.append((prec, "band", h, w, y0, y1))
+                stats["bands"] += 1
+            for _ in range(3):
+                if not torch.equal(a.upscale_rgba8_dev(big), first):
+                    bad.append((prec, "repeat 1080p"))
+                stats["repeats"] += 1
+        a.close()
+        b.close()
+    return stats, bad
+
+
+if __name__ == "__main__":
+    stats, bad = soak(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
+    print("soak:", stats, "mismatches:", bad[:10], flush=True)
+    sys.exit(1 if bad else 0)
