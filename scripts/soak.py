@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak: random shapes, batches and band halos through the pipe / column kernels against the first-form kernels (an
-independent code path, bit-identical by construction), interleaved so that every call changes the workspace geometry, plus
+independent code path, bit-identical by construction), interleaved so that every call changes the workspace geometry, the
+host-pointer entry point (chunks and bands on two streams) against the device call, plus
 repeated 1080p calls that must reproduce themselves bit for bit (a missed vmcnt / barrier shows up as a flicker).
     python scripts/soak.py [seconds]"""
 import os
@@ -19,7 +20,7 @@ def soak(budget, seed=None):
     params = r.rsr.builtin("imagenet")
     rng = np.random.default_rng(int(time.time()) & 0xffff if seed is None else seed)
     t_end = time.time() + budget
-    stats = {"shapes": 0, "repeats": 0, "bands": 0}
+    stats = {"shapes": 0, "repeats": 0, "bands": 0, "host_calls": 0}
     bad = []
     for prec in ("f32", "split_f16"):
         a, b = r.Engine(params, precision=prec), r.Engine(params, precision=prec)
@@ -46,6 +47,16 @@ def soak(budget, seed=None):
                 if not torch.equal(band, ga[0, 3 * y0:3 * y1]):
                     bad.append((prec, "band", h, w, y0, y1))
                 stats["bands"] += 1
+            if stats["shapes"] % 4 == 0:  # the host-pointer entry point: chunks / bands on two streams and two workspaces
+                if rng.random() < 0.5:
+                    hh, ww = int(rng.integers(500, 1500)), int(rng.integers(1100, 2600))  # large enough to be cut into bands
+                    hp = rng.integers(0, 256, (1, hh, ww, 3), dtype=np.uint8)
+                else:
+                    hp = rng.integers(0, 256, (int(rng.integers(2, 40)), int(rng.integers(8, 300)), int(rng.integers(8, 300)), 3), dtype=np.uint8)
+                want = a.upscale_rgba8_dev(torch.from_numpy(hp).cuda()).cpu().numpy()
+                if not np.array_equal(a.upscale_rgba8(hp), want):
+                    bad.append((prec, "host", hp.shape))
+                stats["host_calls"] += 1
             for _ in range(3):
                 if not torch.equal(a.upscale_rgba8_dev(big), first):
                     bad.append((prec, "repeat 1080p"))

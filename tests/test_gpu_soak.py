@@ -15,6 +15,6 @@ pytestmark = pytest.mark.gpu
 def test_short_soak():
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import soak
-    stats, bad = soak.soak(8.0, seed=123)
+    stats, bad = soak.soak(10.0, seed=123)
     assert not bad, bad[:5]
-    assert stats["shapes"] > 50 and stats["repeats"] > 150 and stats["bands"] > 20, stats
+    assert stats["shapes"] > 40 and stats["repeats"] > 120 and stats["bands"] > 15 and stats["host_calls"] > 8, stats
