@@ -56,7 +56,7 @@ PNGLIB = os.path.join(HERE, "libsrpng.so")
 def build_host(force=False, verbose=False):
     """g++ -> rusty_sr_amd/bin/rusty_sr (the CLI with the reference's argv surface; links
     libsrhip.so via $ORIGIN/..) and rusty_sr_amd/libsrpng.so (the PNG codec alone, for tests)."""
-    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "png.cpp", "jpeg.cpp", "formats.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("main.cpp", "png.cpp", "jpeg.cpp", "formats.cpp", "rle_deflate.cpp")]
     deps = srcs + [os.path.join(HOST, "png.hpp"), os.path.join(HERE, "..", "include", "srhip.h"), LIB]
     if not force and os.path.exists(CLI) and os.path.exists(PNGLIB) and \
             all(os.path.getmtime(d) <= min(os.path.getmtime(CLI), os.path.getmtime(PNGLIB)) for d in deps):
@@ -64,7 +64,7 @@ def build_host(force=False, verbose=False):
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     res = os.path.join(HERE, "res")
     cmds = [
-        ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[1], srcs[2], srcs[3], "-lz", "-o", PNGLIB],
+        ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", *srcs[1:], "-lz", "-o", PNGLIB],
         ["g++", "-O3", "-std=c++17", "-pthread", f'-DSR_RES_DIR="{res}"', *srcs, "-L", HERE, "-lsrhip", "-lz",
          "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link," + "/opt/rocm/lib", "-o", CLI],
     ]
@@ -82,7 +82,7 @@ def build_sanitized(force=False, verbose=False):
     """g++ -fsanitize=address,undefined -> rusty_sr_amd/bin/srcodec_asan: the hand-written PNG / JPEG / PNM / BMP
     decoders under AddressSanitizer + UBSan, driven by tests/test_decoder_robustness.py with truncated and
     bit-flipped files."""
-    srcs = [os.path.join(HOST, f) for f in ("fuzz_main.cpp", "png.cpp", "jpeg.cpp", "formats.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("fuzz_main.cpp", "png.cpp", "jpeg.cpp", "formats.cpp", "rle_deflate.cpp")]
     deps = srcs + [os.path.join(HOST, "png.hpp")]
     if not force and os.path.exists(FUZZ) and all(os.path.getmtime(d) <= os.path.getmtime(FUZZ) for d in deps):
         return FUZZ

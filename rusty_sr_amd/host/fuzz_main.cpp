@@ -21,7 +21,12 @@ int main(int argc, char** argv) {
         const int w = atoi(argv[2]), h = atoi(argv[3]);
         std::vector<uint8_t> px((size_t)w * h * 4);
         uint32_t z = 12345;
-        for (auto& b : px) { z = z * 1664525u + 1013904223u; b = (uint8_t)(z >> 24); }
+        for (int y = 0; y < h; ++y)  // noise, flat and ramp rows in turn: literals, long runs and every filter type
+            for (int x = 0; x < w * 4; ++x) {
+                z = z * 1664525u + 1013904223u;
+                const int kind = (y / 3) % 4;
+                px[(size_t)y * w * 4 + x] = kind == 0 ? (uint8_t)(z >> 24) : kind == 1 ? (uint8_t)(y * 7) : kind == 2 ? (uint8_t)(x / 4 + y) : (uint8_t)((x / 4) * (y & 3) + (z >> 31));
+            }
         std::string err;
         if (!srpng::encode_file(argv[4], px.data(), w, h, err)) { printf("error: %s\n", err.c_str()); return 1; }
         srpng::Image img;

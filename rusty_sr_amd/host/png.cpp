@@ -471,21 +471,31 @@ static bool encode_band(const uint8_t* rgba, int w, int y0, int y1, bool first, 
     raw_len = (stride + 1) * (size_t)(y1 - y0);
     if (raw_len > 0xfffffff0u) return false;  // zlib's uInt counters: never truncate silently
     adler = adler32(adler32(0L, Z_NULL, 0), raw, (uInt)raw_len);
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    // Z_RLE (matches at distance 1 only: runs) + dynamic Huffman.  On filtered residuals of continuous-tone images longer
-    // LZ77 matches are rare and distort the literal statistics: measured on upscaled photographs and on the reference's
-    // cartoon output, RLE files are 3-20 % SMALLER than zlib levels 1-6 and deflate 1.5x faster than level 2 (13x level 6).
-    // zlevel <= 0 keeps the general matcher (level 3): flat synthetic images with repeating patterns want it.
-    if (deflateInit2(&zs, zlevel > 0 ? zlevel : 3, Z_DEFLATED, -15, 8, zlevel > 0 ? Z_RLE : Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    // Run-length matches + dynamic Huffman (rle_deflate.cpp; the choices of zlib's Z_RLE strategy).  On filtered residuals
+    // of continuous-tone images longer LZ77 matches are rare and distort the literal statistics: measured on upscaled
+    // photographs and on the reference's cartoon output such files are 3-20 % SMALLER than zlib levels 1-6.
+    // zlevel <= 0 -- or a band the fast coder cannot fit -- takes zlib's general matcher (level 3): flat synthetic
+    // images with repeating patterns want it.
     const size_t head = 8 + (first ? 2 : 0);
-    if (cap < head + deflateBound(&zs, (uLong)raw_len) + 16 + 4) { deflateEnd(&zs); return false; }
-    zs.next_in = raw; zs.avail_in = (uInt)raw_len;
-    zs.next_out = chunk + head; zs.avail_out = (uInt)(cap - head - 4);
-    const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
-    const bool ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0);
-    const size_t n = head - 8 + (cap - head - 4 - zs.avail_out);  // chunk data bytes
-    deflateEnd(&zs);
+    if (cap < head + 64) return false;
+    size_t n = 0;
+    bool ok = false;
+    if (zlevel > 0) {
+        const size_t got = rle_deflate(raw, raw_len, last, chunk + head, cap - head - 4);
+        if (got) { n = head - 8 + got; ok = true; }
+    }
+    if (!ok) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, 3, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        if (cap < head + deflateBound(&zs, (uLong)raw_len) + 16 + 4) { deflateEnd(&zs); return false; }
+        zs.next_in = raw; zs.avail_in = (uInt)raw_len;
+        zs.next_out = chunk + head; zs.avail_out = (uInt)(cap - head - 4);
+        const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+        ok = last ? rc == Z_STREAM_END : (rc == Z_OK && zs.avail_in == 0);
+        n = head - 8 + (cap - head - 4 - zs.avail_out);  // chunk data bytes
+        deflateEnd(&zs);
+    }
     if (!ok || n > 0x7fffffffu) return false;
     chunk[0] = (uint8_t)(n >> 24); chunk[1] = (uint8_t)(n >> 16); chunk[2] = (uint8_t)(n >> 8); chunk[3] = (uint8_t)n;
     memcpy(chunk + 4, "IDAT", 4);
@@ -533,7 +543,8 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
     // One arena for all chunks, each band at its worst-case offset: `new[]` leaves the pages untouched, so only what the
     // compressed data really covers is ever faulted in, and no allocation happens per band (a fresh process -- which the
     // CLI always is -- would send each multi-MB vector through mmap / munmap).  Filter scratch is per worker, allocated once.
-    const size_t slot = 8 + 2 + (size_t)compressBound((uLong)((stride + 1) * rows_per)) + 64;
+    const size_t band_raw = (stride + 1) * (size_t)rows_per;
+    const size_t slot = 8 + 2 + std::max((size_t)compressBound((uLong)band_raw), rle_deflate_bound(band_raw)) + 64;
     std::unique_ptr<uint8_t[]> arena(new (std::nothrow) uint8_t[slot * nband]);
     if (!arena) { fclose(f); err = "out of memory"; return false; }
     std::vector<size_t> part_len(nband, 0);

@@ -17,6 +17,9 @@ bool decode_memory(const uint8_t* data, size_t len, Image& out, std::string& err
 // the smaller choice; zlevel == 0: zlib's general matcher at level 3
 bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std::string& err, int zlevel = -1);
 unsigned usable_cpus();  // affinity mask capped by the cgroup CPU quota
+// rle_deflate.cpp: raw deflate with run-length matches + dynamic Huffman only (what the PNG encoder uses); 0 = cap too small
+size_t rle_deflate_bound(size_t n);
+size_t rle_deflate(const uint8_t* src, size_t n, bool last, uint8_t* dst, size_t cap);
 // baseline JPEG (jpeg.cpp); binary PPM / PGM and uncompressed 24 / 32-bit BMP (png.cpp)
 bool decode_jpeg_memory(const uint8_t* data, size_t len, Image& out, std::string& err);
 // image::open stand-in: picks the decoder from the file's magic bytes (PNG, JPEG, GIF, TIFF, BMP, ICO, PPM/PGM/PBM;

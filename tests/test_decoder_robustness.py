@@ -230,6 +230,6 @@ def test_hostile_jpeg_and_pnm_and_bmp_headers(harness, tmp_path):
 
 
 def test_encoder_round_trip_under_sanitizers(harness, tmp_path):
-    for w, h in ((1, 1), (37, 21), (513, 300), (4096, 33)):
+    for w, h in ((1, 1), (37, 21), (513, 300), (4096, 33), (1600, 1300)):
         r = subprocess.run([harness, "--roundtrip", str(w), str(h), str(tmp_path / "rt.png")], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and r.stdout.startswith("ok "), (w, h, r.stdout, r.stderr[-2000:])

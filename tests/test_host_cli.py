@@ -197,6 +197,52 @@ def test_gif_tiff_tga_ico_decode_like_pillow(tmp_path):
     assert dec(tmp_path / "x.tga") is None
 
 
+def test_rle_deflate_streams_inflate_with_zlib():
+    """rle_deflate.cpp, the PNG encoder's deflate (run-length matches + dynamic Huffman only): every stream must inflate to
+    its input with zlib -- empty and tiny inputs, runs around the 258-byte match limit, incompressible noise, a 256 KB block
+    edge, frequencies skewed enough to need the 15-bit length limit -- segments that end in a sync flush must concatenate,
+    and a destination that is too small must be refused (0), not overrun."""
+    import ctypes as C
+    import zlib
+    L = C.CDLL(PNGLIB)
+    L.srpng_rle_deflate_bound.restype = C.c_size_t
+    L.srpng_rle_deflate_bound.argtypes = [C.c_size_t]
+    L.srpng_rle_deflate.restype = C.c_size_t
+    L.srpng_rle_deflate.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+
+    def enc(data, last=True, cap=None):
+        n = len(data)
+        cap = cap or L.srpng_rle_deflate_bound(n)
+        dst = (C.c_uint8 * (cap + 64))(*([0xAA] * 0))
+        C.memset(dst, 0xAA, cap + 64)
+        src = (C.c_uint8 * max(n, 1)).from_buffer_copy(data if n else b"\0")
+        k = L.srpng_rle_deflate(src, n, 1 if last else 0, dst, cap)
+        assert bytes(dst[cap:cap + 64]) == b"\xaa" * 64, "wrote past the capacity it was given"
+        return bytes(dst[:k])
+
+    rng = np.random.default_rng(0)
+    fib = [1, 1]
+    while len(fib) < 30:
+        fib.append(fib[-1] + fib[-2])
+    cases = {"empty": b"", "one": b"x", "two": b"xy", "zeros3": bytes(3), "zeros": bytes(100000), "run259": b"a" * 259,
+             "run260": b"b" * 260, "run261": b"c" * 261, "run517": b"d" * 517,
+             "random": rng.integers(0, 256, 300000, dtype=np.uint8).tobytes(),
+             "low_entropy": rng.choice([0, 0, 0, 0, 1, 255, 2, 254], 500000).astype(np.uint8).tobytes(),
+             "block_edge": bytes(262144) + b"z" + bytes(262143),
+             "mixed_runs": b"".join(bytes([int(v)]) * int(r) for v, r in zip(rng.integers(0, 256, 3000), rng.integers(1, 600, 3000))),
+             "fibonacci": b"".join(bytes([i]) * min(f, 200000) for i, f in enumerate(fib))}
+    for name, data in cases.items():
+        z = enc(data)
+        assert zlib.decompress(z, -15) == data, name
+        joined = enc(data, last=False) + enc(data[::-1], last=True)
+        assert zlib.decompress(joined, -15) == data + data[::-1], name
+        ref = zlib.compressobj(1, zlib.DEFLATED, -15, 8, zlib.Z_RLE)
+        ref_len = len(ref.compress(data) + ref.flush())
+        assert len(z) <= ref_len * 1.05 + 16, (name, len(z), ref_len)     # the same format, about the same size
+    assert enc(cases["random"], cap=1000) == b""
+    assert enc(cases["random"], cap=len(cases["random"]) // 2) == b""
+
+
 def test_png_colour_types_depths_and_roundtrip(png, tmp_path):
     from PIL import Image
     rng = np.random.default_rng(0)
