@@ -115,7 +115,8 @@ int sr_reserve_f32(sr_ctx* ctx, int n, int h, int w);
 int sr_reserve_rgba8(sr_ctx* ctx, int in_channels, int n, int h, int w);
 
 /* The two host-pointer entry points above run upload / conv stack / download as a software
- * pipeline on three HIP streams: a batch goes in chunks of whole images, one large sr_net image
+ * pipeline on three HIP streams of the context's own (created on first need: a call that is one chunk uses one, the
+ * device-pointer entry points none): a batch goes in chunks of whole images, one large sr_net image
  * goes as row bands with SR_HALO halo rows (bit-identical to the undivided pass, see
  * sr_upscale_band_*).  Results do not depend on the setting; 0 = one upload, one pass, one
  * download.  The reference has no counterpart (its tensors never leave host memory,

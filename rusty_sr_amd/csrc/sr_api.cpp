@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -262,18 +263,28 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         for (size_t i = 0; i < n_params * sizeof(float); ++i) { hsh ^= pb[i]; hsh *= 1099511628211ull; }
         c->params_hash = hsh;
     }
+    // SRHIP_TRACE=1: where sr_create spends its time (a one-shot process pays it once per image)
+    const bool trace = getenv("SRHIP_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[srhip] sr_create: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     int rc = [&]() -> int {
         HIPCHK(c, hipSetDevice(device));
+        mark("hipSetDevice");
         hipDeviceProp_t prop;
         HIPCHK(c, hipGetDeviceProperties(&prop, device));
+        mark("hipGetDeviceProperties");
         snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
         c->cus = prop.multiProcessorCount;
         c->clock_mhz = prop.clockRate / 1000;
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+        // no stream yet: each costs 8-40 ms of start-up (a hardware queue), the device-pointer entry points run on the
+        // caller's streams, a host call of one chunk needs one stream and only a pipelined one all three (sr_ensure_streams)
         for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
+        mark("events");
 
         if (graph != SR_GRAPH_SR_NET) return SR_OK;  // parameter-free graphs need nothing else
         // ---- pack every parameter once, in the layouts the kernels read
@@ -336,10 +347,13 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
                 }
             c->off_bias[4] = push(eb);
         }
+        mark("weight packing (host)");
         for (auto& w : c->ws) HIPCHK(c, hipMalloc((void**)&w.d_queue, 5 * 8 * sizeof(int)));
 
         HIPCHK(c, hipMalloc((void**)&c->d_params, host.size() * sizeof(float)));
+        mark("hipMalloc x3");
         HIPCHK(c, hipMemcpy(c->d_params, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+        mark("parameter upload");
         return SR_OK;
     }();
     if (rc != SR_OK) {
@@ -366,7 +380,6 @@ void sr_destroy(sr_ctx* c) {
     for (auto& p : c->d_out) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pool) if (e) (void)hipEventDestroy(e);
-    if (c->copy_in) { (void)hipStreamSynchronize(c->copy_in); (void)hipStreamDestroy(c->copy_in); }
     if (c->copy_out) { (void)hipStreamSynchronize(c->copy_out); (void)hipStreamDestroy(c->copy_out); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -483,6 +496,17 @@ int ensure_features(sr_ctx* c, sr_ctx::Workspace& w, int n, int H, int W, int ti
 }
 
 }  // namespace
+
+// The context's own streams, created when first needed: `stream` for everything the library runs by itself, and for a
+// pipelined host call a second compute stream and the download stream.
+int sr_ensure_streams(sr_ctx* c, bool pipelined) {
+    if (!c->stream) HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (pipelined) {
+        if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (!c->copy_out) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+    }
+    return SR_OK;
+}
 
 int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return SR_OK;
@@ -747,6 +771,16 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     const std::vector<Chunk> plan = plan_chunks(c, deal, h, w, in_px, out_px, y_lo, y_hi, &in_order);
     const int nch = (int)plan.size();
     const int slots = nch > 1 ? 2 : 1;
+    {
+        const int rc = sr_ensure_streams(c, nch > 1);
+        if (rc != SR_OK) return rc;
+    }
+    // One chunk: upload, kernels and download in order on `stream`.  Several: chunk i uploads on the stream its kernels
+    // follow on (the other compute stream is busy with chunk i-1 meanwhile) -- or, when all chunks compute in order on
+    // `stream`, on the idle `stream2` -- and downloads on `copy_out`.
+    // (A dedicated upload stream was measured against this, profiles/r2_upload_stream_ab.txt: f32 1080p 0.7 % faster, split mode 2 %
+    // slower, 4K equal -- not worth a third hardware queue, 8-40 ms of start-up.)
+    hipStream_t down = nch > 1 ? c->copy_out : c->stream;
     size_t in_max = 0, out_max = 0;
     for (const Chunk& k : plan) { in_max = std::max(in_max, k.in_bytes); out_max = std::max(out_max, k.out_bytes); }
     for (int sl = 0; sl < slots; ++sl) {
@@ -764,14 +798,14 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     const char* src = (const char*)in;
     char* dst = (char*)out;
     // a chunk's images are contiguous on the device; in the caller's buffers they are in_step / out_step apart
-    auto copy_images = [&](const Chunk& k, bool up, int sl) -> int {
+    auto copy_images = [&](const Chunk& k, bool up, int sl, hipStream_t on) -> int {
         if (reserve) return SR_OK;
         const bool contiguous = k.n == 1 || (up ? k.in_step == k.in_bytes / k.n : k.out_step == k.out_bytes / k.n);
         const int pieces = contiguous ? 1 : k.n;
         const size_t in_img = k.in_bytes / (contiguous ? 1 : k.n), out_img = k.out_bytes / (contiguous ? 1 : k.n);
         for (int j = 0; j < pieces; ++j) {
-            if (up) HIPCHK(c, hipMemcpyAsync((char*)c->d_in[sl] + j * in_img, src + k.in_off + j * k.in_step, in_img, hipMemcpyHostToDevice, c->copy_in));
-            else HIPCHK(c, hipMemcpyAsync(dst + k.out_off + j * k.out_step, (const char*)c->d_out[sl] + j * out_img, out_img, hipMemcpyDeviceToHost, c->copy_out));
+            if (up) HIPCHK(c, hipMemcpyAsync((char*)c->d_in[sl] + j * in_img, src + k.in_off + j * k.in_step, in_img, hipMemcpyHostToDevice, on));
+            else HIPCHK(c, hipMemcpyAsync(dst + k.out_off + j * k.out_step, (const char*)c->d_out[sl] + j * out_img, out_img, hipMemcpyDeviceToHost, on));
         }
         return SR_OK;
     };
@@ -784,12 +818,13 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
         const Chunk& k = plan[i];
         const int sl = i % slots;
         hipStream_t cs = cstream(i);
-        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->copy_in, ev(i - 2, 3), 0));  // slot's previous reader
-        HIPCHK(c, hipEventRecord(ev(i, 0), c->copy_in));
-        int rc = copy_images(k, true, sl);
+        hipStream_t upl = (in_order && nch > 1) ? c->stream2 : cs;
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(upl, ev(i - 2, 3), 0));  // slot's previous reader
+        HIPCHK(c, hipEventRecord(ev(i, 0), upl));
+        int rc = copy_images(k, true, sl, upl);
         if (rc != SR_OK) return rc;
-        HIPCHK(c, hipEventRecord(ev(i, 1), c->copy_in));
-        HIPCHK(c, hipStreamWaitEvent(cs, ev(i, 1), 0));
+        HIPCHK(c, hipEventRecord(ev(i, 1), upl));
+        if (upl != cs) HIPCHK(c, hipStreamWaitEvent(cs, ev(i, 1), 0));
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(cs, ev(i - 2, 4), 0));   // slot's previous download
         HIPCHK(c, hipEventRecord(ev(i, 2), cs));
         rc = sr_run_stack(c, c->d_in[sl], img_u8, img_ch, k.n, k.h_ext, w, k.halo_top, k.halo_bot, c->d_out[sl],
@@ -799,10 +834,10 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
         return SR_OK;
     };
     auto issue_back = [&](int i) -> int {  // download of chunk i
-        HIPCHK(c, hipStreamWaitEvent(c->copy_out, ev(i, 3), 0));
-        const int rc = copy_images(plan[i], false, i % slots);
+        if (down != cstream(i)) HIPCHK(c, hipStreamWaitEvent(down, ev(i, 3), 0));
+        const int rc = copy_images(plan[i], false, i % slots, down);
         if (rc != SR_OK) return rc;
-        HIPCHK(c, hipEventRecord(ev(i, 4), c->copy_out));
+        HIPCHK(c, hipEventRecord(ev(i, 4), down));
         return SR_OK;
     };
     int rc = issue_front(0);
@@ -812,8 +847,8 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     }
     // drain everything before returning, ALSO on failure: copies into / out of the caller's buffers and kernels on
     // the context's stream must not be in flight once the call has returned
-    const hipError_t e1 = hipStreamSynchronize(c->copy_in), e2 = hipStreamSynchronize(c->stream), e4 = hipStreamSynchronize(c->stream2),
-                     e3 = hipStreamSynchronize(c->copy_out);
+    const hipError_t e1 = hipSuccess, e2 = hipStreamSynchronize(c->stream), e4 = nch > 1 ? hipStreamSynchronize(c->stream2) : hipSuccess,
+                     e3 = nch > 1 ? hipStreamSynchronize(c->copy_out) : hipSuccess;
     if (rc != SR_OK) return rc;
     HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e4); HIPCHK(c, e3);
     double h2d = 0, ker = 0, d2h = 0;

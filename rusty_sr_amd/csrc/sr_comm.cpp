@@ -182,7 +182,11 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
         c->last_hip = (int)e;
         return e == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP;
     };
-    for (int k = 0; k < n && rc == SR_OK; ++k) rc = prepare_band(ctxs[k], d_bands[k], h_bands[k], w, px, g[k], ctxs[k]->stream);
+    for (int k = 0; k < n && rc == SR_OK; ++k) {
+        rc = hip(ctxs[k], hipSetDevice(ctxs[k]->device));
+        if (rc == SR_OK) rc = sr_ensure_streams(ctxs[k], false);
+        if (rc == SR_OK) rc = prepare_band(ctxs[k], d_bands[k], h_bands[k], w, px, g[k], ctxs[k]->stream);
+    }
     if (rc == SR_OK && local) {
         // every context pulls its halos from the neighbours' bands -- caller buffers that are complete before this
         // (synchronous) call, so no cross-stream ordering is needed

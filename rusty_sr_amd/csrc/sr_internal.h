@@ -34,7 +34,7 @@ struct sr_ctx {
     // downloads while chunk i computes (run_host)
     void* d_in[2] = {nullptr, nullptr};  size_t in_cap[2] = {0, 0};
     void* d_out[2] = {nullptr, nullptr}; size_t out_cap[2] = {0, 0};
-    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipStream_t copy_out = nullptr;   // downloads of a pipelined host call (uploads ride on the compute streams)
     std::vector<hipEvent_t> pool;  // per-chunk timing / ordering events of run_host, grown on demand
     int pipeline = 1;              // 0: one upload, one pass, one download
     int last_chunks = 0;
@@ -75,4 +75,5 @@ struct sr_ctx {
 int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
                  void* d_out, bool out_u8, hipStream_t s, int slot = 0);
 int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes);
+int sr_ensure_streams(sr_ctx* c, bool pipelined);  // the context's own streams are created on first use
 void sr_comm_release(sr_ctx* c);  // sr_comm.cpp: destroy the communicator and its buffers (called by sr_destroy)
