@@ -255,6 +255,58 @@ def test_sharded_image_through_the_library_on_one_device(params, n, prec):
             e.close()
 
 
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+def test_feature_maps_beyond_four_gib(params, prec):
+    """Maximum sizes: a 6100 x 6200 image has 4.9 GB per 32-channel feature map, so the undivided device-resident pass
+    addresses rows more than 2^32 bytes from the start of a map (no other test does: 4K is 1.06 GB, the 64-image batch
+    2.1 GB).  Bands cut from below, across and above that line -- small workspaces, small offsets -- must equal the same
+    rows of the whole, and so must the host-pointer call (bands through two other workspaces)."""
+    import torch
+    import rusty_sr_amd as r
+    H, W = 6200, 6100
+    rng = np.random.default_rng(61)
+    px = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    eng = r.Engine(params["imagenet"], precision=prec)
+    small = r.Engine(params["imagenet"], precision=prec)
+    try:
+        d = torch.from_numpy(px).cuda()
+        whole = eng.upscale_rgba8_dev(d[None])[0]
+        pitch = (W + 31) // 32 * 32 + 4
+        line = (1 << 32) // 128 // pitch            # the row whose pixels sit 4 GiB into a map
+        assert 100 < line < H - 100
+        for y0, y1 in ((0, 40), (line - 30, line + 30), (H - 45, H), (H // 2, H // 2 + 16)):
+            a, b = max(0, y0 - 7), min(H, y1 + 7)
+            band = small.upscale_band_rgba8_dev(d[a:b].contiguous(), y0 - a, b - y1)
+            assert torch.equal(band, whole[3 * y0:3 * y1]), (y0, y1)
+        host = eng.upscale_rgba8(px)
+        assert np.array_equal(host, whole.cpu().numpy())
+    finally:
+        eng.close(); small.close()
+
+
+def test_output_beyond_four_gib(params):
+    """... and an 11 000 x 11 000 image: 15.5 GB per feature map, a 4.36 GB RGBA output (rows beyond 2^32 bytes), 121 M
+    pixels through the 32-bit tile arithmetic.  Device-resident, bands against the whole as above."""
+    import torch
+    import rusty_sr_amd as r
+    H = W = 11000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    d = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
+    eng = r.Engine(params["imagenet"])
+    small = r.Engine(params["imagenet"])
+    try:
+        whole = eng.upscale_rgba8_dev(d[None])[0]
+        assert whole.numel() > (1 << 32)
+        line = (1 << 32) // (3 * W * 4) // 3          # the input row whose output rows straddle 4 GiB
+        for y0, y1 in ((0, 24), (line - 20, line + 20), (H - 40, H)):
+            a, b = max(0, y0 - 7), min(H, y1 + 7)
+            band = small.upscale_band_rgba8_dev(d[a:b].contiguous(), y0 - a, b - y1)
+            assert torch.equal(band, whole[3 * y0:3 * y1]), (y0, y1)
+        assert bool((whole[..., 3] == 255).all())
+    finally:
+        eng.close(); small.close()
+
+
 @pytest.mark.skipif("_ndev() < 2")
 def test_contexts_on_other_devices(params):
     """device != 0: the > 64 KB dynamic-LDS attribute is per (kernel, device); a context on every device of the node
