@@ -93,7 +93,12 @@ int sr_num_params(int graph); /* graph.num_params() at factor 3; -1 for an unkno
  * those factors are checked against the CPU restatement only (UNPINNED). */
 int sr_num_params_factor(int factor); /* -1 unless 2 <= factor <= 4 */
 
-/* Replaces: graph.forward(n, vec![input], &params) (reference main.rs:171).
+/* Sizes: nothing but device memory limits an image.  One pass of the conv stack keeps four 32-channel f32 feature maps
+ * (512 B per input pixel) beside input and output: 1920x1080 1.1 GB, 3840x2160 4.3 GB, 11 000 x 11 000 62 GB (tested; byte
+ * offsets and outputs beyond 4 GiB are fine).  The host-pointer entry points cut large jobs into chunks / row bands, so their
+ * workspace is that of a band.  A failed allocation is SR_E_NOMEM and leaves the context usable.
+ *
+ * Replaces: graph.forward(n, vec![input], &params) (reference main.rs:171).
  * in : n*h*w*3 f32 in [0,1] (what img_to_data produced), host memory.
  * out: n*(3h)*(3w)*3 f32, pre-quantisation, host memory. */
 int sr_upscale_f32(sr_ctx* ctx, const float* in, int n, int h, int w, float* out);
