@@ -786,7 +786,15 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     for (int sl = 0; sl < slots; ++sl) {
         int rc = sr_ensure_buf(c, &c->d_in[sl], &c->in_cap[sl], in_max);
         if (rc == SR_OK) rc = sr_ensure_buf(c, &c->d_out[sl], &c->out_cap[sl], out_max);
-        if (rc != SR_OK) return rc;
+        if (rc != SR_OK) {  // a job that does not fit must not leave its partial staging buffers behind (they may be most of the device)
+            for (int k = 0; k < 2; ++k) {
+                if (c->d_in[k]) (void)hipFree(c->d_in[k]);
+                if (c->d_out[k]) (void)hipFree(c->d_out[k]);
+                c->d_in[k] = c->d_out[k] = nullptr;
+                c->in_cap[k] = c->out_cap[k] = 0;
+            }
+            return rc;
+        }
     }
     // events per chunk: 0 upload begins, 1 upload done, 2 kernels begin, 3 kernels done, 4 download done
     while (c->pool.size() < (size_t)nch * 5) {

@@ -65,6 +65,7 @@ struct sr_ctx {
     do {                                          \
         hipError_t e__ = (expr);                  \
         if (e__ != hipSuccess) {                  \
+            (void)hipGetLastError(); /* the runtime keeps the error until it is read: the next launch check must not find it */ \
             (ctx)->last_hip = (int)e__;           \
             return e__ == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP; \
         }                                         \

@@ -288,6 +288,11 @@ def test_reserve_allocates_and_warms_without_touching_results(params):
         np.testing.assert_array_equal(eng.upscale_f32(x), want32)
         eng.reserve(4, 64, 64)                       # another shape than the one that follows
         np.testing.assert_array_equal(eng.upscale_rgba8(px), want8)
+        # a job no device can hold: the allocation fails loudly (SR_E_NOMEM) and the context keeps working
+        with pytest.raises(r.SrError) as oom:
+            eng.reserve(1, 400000, 400000)
+        assert oom.value.status == r._lib.SR_E_NOMEM
+        np.testing.assert_array_equal(eng.upscale_rgba8(px), want8)
         with pytest.raises(r.SrError):
             eng.reserve(1, 0, 10)
         with pytest.raises(r.SrError):
