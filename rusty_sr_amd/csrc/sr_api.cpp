@@ -380,6 +380,7 @@ void sr_destroy(sr_ctx* c) {
     for (auto& p : c->d_out) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pool) if (e) (void)hipEventDestroy(e);
+    if (c->copy_in) { (void)hipStreamSynchronize(c->copy_in); (void)hipStreamDestroy(c->copy_in); }
     if (c->copy_out) { (void)hipStreamSynchronize(c->copy_out); (void)hipStreamDestroy(c->copy_out); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -778,8 +779,13 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     // One chunk: upload, kernels and download in order on `stream`.  Several: chunk i uploads on the stream its kernels
     // follow on (the other compute stream is busy with chunk i-1 meanwhile) -- or, when all chunks compute in order on
     // `stream`, on the idle `stream2` -- and downloads on `copy_out`.
-    // (A dedicated upload stream was measured against this, profiles/r2_upload_stream_ab.txt: f32 1080p 0.7 % faster, split mode 2 %
-    // slower, 4K equal -- not worth a third hardware queue, 8-40 ms of start-up.)
+    // A dedicated upload stream (a third hardware queue, 8-40 ms to create) lets chunk i+1 arrive while both compute streams
+    // are busy.  Measured A/B (profiles/r2_upload_stream_ab.txt): worth 1-2 % of an exact-f32 1080p call, nothing at 4K, and
+    // 2 % SLOWER in the split-half mode (whose calls are download-bound) -- so only exact-f32 contexts get one, and only from
+    // their second pipelined call on: a one-shot process never pays for it, a service does once.
+    if (nch > 1 && !reserve && c->precision == SR_PRECISION_F32 && ++c->pipelined_calls >= 2 && !c->copy_in)
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+    const bool own_upload = nch > 1 && c->copy_in && c->precision == SR_PRECISION_F32;
     hipStream_t down = nch > 1 ? c->copy_out : c->stream;
     size_t in_max = 0, out_max = 0;
     for (const Chunk& k : plan) { in_max = std::max(in_max, k.in_bytes); out_max = std::max(out_max, k.out_bytes); }
@@ -826,7 +832,7 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
         const Chunk& k = plan[i];
         const int sl = i % slots;
         hipStream_t cs = cstream(i);
-        hipStream_t upl = (in_order && nch > 1) ? c->stream2 : cs;
+        hipStream_t upl = own_upload ? c->copy_in : (in_order && nch > 1) ? c->stream2 : cs;
         if (i >= 2) HIPCHK(c, hipStreamWaitEvent(upl, ev(i - 2, 3), 0));  // slot's previous reader
         HIPCHK(c, hipEventRecord(ev(i, 0), upl));
         int rc = copy_images(k, true, sl, upl);
@@ -855,7 +861,7 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     }
     // drain everything before returning, ALSO on failure: copies into / out of the caller's buffers and kernels on
     // the context's stream must not be in flight once the call has returned
-    const hipError_t e1 = hipSuccess, e2 = hipStreamSynchronize(c->stream), e4 = nch > 1 ? hipStreamSynchronize(c->stream2) : hipSuccess,
+    const hipError_t e1 = own_upload ? hipStreamSynchronize(c->copy_in) : hipSuccess, e2 = hipStreamSynchronize(c->stream), e4 = nch > 1 ? hipStreamSynchronize(c->stream2) : hipSuccess,
                      e3 = nch > 1 ? hipStreamSynchronize(c->copy_out) : hipSuccess;
     if (rc != SR_OK) return rc;
     HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e4); HIPCHK(c, e3);

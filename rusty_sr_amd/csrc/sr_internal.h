@@ -34,7 +34,9 @@ struct sr_ctx {
     // downloads while chunk i computes (run_host)
     void* d_in[2] = {nullptr, nullptr};  size_t in_cap[2] = {0, 0};
     void* d_out[2] = {nullptr, nullptr}; size_t out_cap[2] = {0, 0};
-    hipStream_t copy_out = nullptr;   // downloads of a pipelined host call (uploads ride on the compute streams)
+    hipStream_t copy_out = nullptr;   // downloads of a pipelined host call
+    hipStream_t copy_in = nullptr;    // uploads: exact-f32 contexts, from their second pipelined call on (else on the compute streams)
+    int pipelined_calls = 0;
     std::vector<hipEvent_t> pool;  // per-chunk timing / ordering events of run_host, grown on demand
     int pipeline = 1;              // 0: one upload, one pass, one download
     int last_chunks = 0;
