@@ -362,7 +362,8 @@ bool decode_jpeg_memory(const uint8_t* d, size_t len, Image& out, std::string& e
         const std::vector<uint8_t>& pl = comp[i].plane;
         const int pw = comp[i].pw;
         auto at = [&](int x, int y) { x = x < 0 ? 0 : x >= cw ? cw - 1 : x; y = y < 0 ? 0 : y >= chh ? chh - 1 : y; return (int)pl[(size_t)y * pw + x]; };
-        const bool fx = rx == 2 && hmax % comp[i].h == 0, fy = ry == 2 && vmax % comp[i].v == 0;
+        bool fx = rx == 2 && hmax % comp[i].h == 0, fy = ry == 2 && vmax % comp[i].v == 0;
+        if (fx && cw <= 2) fx = fy = false;  // libjpeg (jdsample.c): the h2v1 / h2v2 triangle filters need more than two samples per row, else replication
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
                 const int sx = x * comp[i].h / hmax, sy = y * comp[i].v / vmax;
