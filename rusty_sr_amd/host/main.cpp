@@ -142,6 +142,13 @@ int main(int argc, char** argv) {
     fflush(stdout);
 
     if (devices.empty() || graph != SR_GRAPH_SR_NET) devices.assign(1, devices.empty() ? device : devices[0]);
+    {   // `.save()` picks the container from the extension (main.rs:175): refuse an unknown one before any work is spent on the picture
+        const size_t dot = pos[1].find_last_of('.');
+        std::string ext = dot == std::string::npos ? "" : pos[1].substr(dot + 1);
+        for (auto& ch : ext) ch = (char)tolower((unsigned char)ch);
+        if (ext != "png" && ext != "jpg" && ext != "jpeg" && ext != "bmp" && ext != "ppm")
+            die("Could not write output file (this build writes .png, .jpg, .bmp and .ppm)");
+    }
     // The input file decodes on a second thread while this one brings up the device and the contexts (HIP start-up
     // and the weight upload take longer than a 1080p PNG); failures are then reported in the reference's order --
     // the graph first (main.rs:160-162), the image after it (main.rs:164).
@@ -184,13 +191,6 @@ int main(int argc, char** argv) {
     sr_ctx* ctx = ctxs[0];
     if (!decoded) die("Error opening input image file. (" + err + ")");  // main.rs:164
     const double t_ready = ms_since(t_start);
-    {   // `.save()` picks the container from the extension (main.rs:175): refuse an unknown one BEFORE spending GPU time
-        const size_t dot = pos[1].find_last_of('.');
-        std::string ext = dot == std::string::npos ? "" : pos[1].substr(dot + 1);
-        for (auto& ch : ext) ch = (char)tolower((unsigned char)ch);
-        if (ext != "png" && ext != "jpg" && ext != "jpeg" && ext != "bmp" && ext != "ppm")
-            die("Could not write output file (this build writes .png, .jpg, .bmp and .ppm)");
-    }
     if (graph == SR_GRAPH_DOWNSAMPLE && (in.w < 3 || in.h < 3)) die("input image is smaller than one 3x3 pooling block");
 
     const int ow = graph == SR_GRAPH_DOWNSAMPLE ? in.w / 3 : in.w * 3, oh = graph == SR_GRAPH_DOWNSAMPLE ? in.h / 3 : in.h * 3;

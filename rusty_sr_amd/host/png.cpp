@@ -309,6 +309,8 @@ bool probe_image_size(const std::string& path, int& w, int& h) {
     if (!f) return false;
     std::vector<uint8_t> b(65536);
     b.resize(fread(b.data(), 1, b.size(), f));
+    fseek(f, 0, SEEK_END);
+    const long file_size = ftell(f);
     fclose(f);
     const size_t n = b.size();
     long W = 0, Hh = 0;
@@ -347,6 +349,9 @@ bool probe_image_size(const std::string& path, int& w, int& h) {
         }
     }
     if (W <= 0 || Hh <= 0 || W > (1 << 20) || Hh > (1 << 20) || (uint64_t)W * (uint64_t)Hh > kMaxPixels) return false;
+    // the caller sizes buffers with this before the decoder has seen the data: a header that promises more pixels than
+    // ~1100 per byte of file (deflate's limit; no real photograph comes near it) is left for the decoder to judge
+    if (file_size <= 0 || (uint64_t)W * (uint64_t)Hh > (uint64_t)file_size * 1100) return false;
     w = (int)W; h = (int)Hh;
     return true;
 }

@@ -132,6 +132,13 @@ def test_probe_reads_the_size_from_the_header_of_every_container(png, tmp_path):
         W, H = C.c_int(), C.c_int()
         assert L.srpng_probe_size(str(tmp_path / name).encode(), C.byref(W), C.byref(H)) == -1, name
     assert L.srpng_probe_size(str(tmp_path / "missing.png").encode(), C.byref(W), C.byref(H)) == -1
+    # a header that promises more pixels than the file could possibly hold is not believed (the CLI would page-lock
+    # gigabytes on its word before the decoder has judged the data)
+    import struct, zlib
+    ihdr = struct.pack(">IIBBBBB", 16000, 16000, 8, 6, 0, 0, 0)
+    chunk = lambda t, d: struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    (tmp_path / "liar.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(bytes(64))) + chunk(b"IEND", b""))
+    assert L.srpng_probe_size(str(tmp_path / "liar.png").encode(), C.byref(W), C.byref(H)) == -1
 
 
 def test_gif_tiff_tga_ico_decode_like_pillow(tmp_path):
