@@ -586,7 +586,7 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
         }
     }
     for (auto& t : th) t.join();
-    if (failed) { fclose(f); err = "deflate failed"; return false; }
+    if (failed) { fclose(f); remove(path.c_str()); err = "deflate failed"; return false; }  // no half-written file stays behind
     // the zlib trailer (Adler-32 of all filtered bytes) is known only now: a last four-byte IDAT chunk (IDAT data
     // concatenates across chunks, PNG spec 11.2.4)
     std::vector<uint8_t> tail;
@@ -595,7 +595,7 @@ bool encode_file(const std::string& path, const uint8_t* rgba, int w, int h, std
     chunk(tail, "IEND", nullptr, 0);
     ok = ok && fwrite(tail.data(), 1, tail.size(), f) == tail.size();
     ok = (fclose(f) == 0) && ok;
-    if (!ok) err = "short write";
+    if (!ok) { remove(path.c_str()); err = "short write"; }
     return ok;
 }
 
