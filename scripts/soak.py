@@ -20,11 +20,13 @@ def soak(budget, seed=None):
     params = r.rsr.builtin("imagenet")
     rng = np.random.default_rng(int(time.time()) & 0xffff if seed is None else seed)
     t_end = time.time() + budget
-    stats = {"shapes": 0, "repeats": 0, "bands": 0, "host_calls": 0}
+    stats = {"shapes": 0, "repeats": 0, "bands": 0, "host_calls": 0, "sharded": 0}
     bad = []
     for prec in ("f32", "split_f16"):
         a, b = r.Engine(params, precision=prec), r.Engine(params, precision=prec)
         b.set_experiment("pipe", "none")
+        group = [r.Engine(params, precision=prec) for _ in range(5)]   # one image sharded over k contexts (local transport)
+        group_k = 0
         big = torch.from_numpy(rng.integers(0, 256, (1, 1080, 1920, 3), dtype=np.uint8)).cuda()
         first = a.upscale_rgba8_dev(big).clone()
         t_prec = time.time() + (t_end - time.time()) / (2 if prec == "f32" else 1)
@@ -57,12 +59,26 @@ def soak(budget, seed=None):
                 if not np.array_equal(a.upscale_rgba8(hp), want):
                     bad.append((prec, "host", hp.shape))
                 stats["host_calls"] += 1
+            if stats["shapes"] % 5 == 0 and n == 1 and h >= 40:  # sr_upscale_sharded_*_all: random uneven bands, halos by peer copy
+                k = int(rng.integers(2, min(5, h // 8) + 1))
+                if k != group_k:
+                    r.comm_init_all(group[:k], transport="local")
+                    group_k = k
+                cuts = np.sort(rng.choice(np.arange(1, h // 7), size=k - 1, replace=False)) * 7
+                edges = [0] + [int(c) for c in cuts] + [h]
+                if min(e1 - e0 for e0, e1 in zip(edges[:-1], edges[1:])) >= 7:
+                    outs = r.upscale_sharded_all(group[:k], [px[0, e0:e1].contiguous() for e0, e1 in zip(edges[:-1], edges[1:])])
+                    if not torch.equal(torch.cat(outs), ga[0]):
+                        bad.append((prec, "sharded", h, w, edges))
+                    stats["sharded"] += 1
             for _ in range(3):
                 if not torch.equal(a.upscale_rgba8_dev(big), first):
                     bad.append((prec, "repeat 1080p"))
                 stats["repeats"] += 1
         a.close()
         b.close()
+        for e in group:
+            e.close()
     return stats, bad
 
 

@@ -17,4 +17,4 @@ def test_short_soak():
     import soak
     stats, bad = soak.soak(10.0, seed=123)
     assert not bad, bad[:5]
-    assert stats["shapes"] > 40 and stats["repeats"] > 120 and stats["bands"] > 15 and stats["host_calls"] > 8, stats
+    assert stats["shapes"] > 40 and stats["repeats"] > 120 and stats["bands"] > 15 and stats["host_calls"] > 8 and stats["sharded"] > 5, stats
