@@ -425,7 +425,7 @@ struct TileOffsets {
 
 template <int TH, int KS, int NW = 4>
 __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, const TileOffsets<TH, KS, NW>& off,
-                                           long img_stride, int pitch, int n, int y0, int x0, int wave, int lane) {
+                                           long img_stride, int pitch, int n, int y0, int x0, int wave, int /*lane*/) {
     using G = TileGeom<TH, KS>;
     const char* origin = uniform_ptr(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32);
 #pragma unroll
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, h = lane >> 5;
+    const int i = lane & 31;
     constexpr int NTAPS = 2 * ((KS0 * KS0 + 1) / 2 + (NSRC - 1) * 5) * NTN;  // ring chunks: one per (step, N-tile), see half_steps_*
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = tiles_per_img * a.n_img;
