@@ -24,12 +24,19 @@ struct Huff {
     uint8_t bits[17] = {0};
     uint8_t vals[256] = {0};
     int mincode[17], maxcode[18], valptr[17];
+    uint16_t fast[512];  // the next 9 bits -> (length << 8 | symbol) for codes of up to 9 bits, 0 otherwise
     bool present = false;
     void build() {
         int code = 0, k = 0;
+        memset(fast, 0, sizeof fast);
         for (int l = 1; l <= 16; ++l) {
             valptr[l] = k;
             mincode[l] = code;
+            if (l <= 9)
+                for (int j = 0; j < bits[l] && (code + j) < (1 << l); ++j) {
+                    const int first = (code + j) << (9 - l);
+                    for (int f = 0; f < (1 << (9 - l)); ++f) fast[first + f] = (uint16_t)(l << 8 | vals[(k + j) & 255]);
+                }
             code += bits[l];
             k += bits[l];
             maxcode[l] = bits[l] ? code - 1 : -1;
@@ -61,16 +68,35 @@ struct BitReader {
         }
     }
     int bit() { if (cnt == 0) fill(); const int r = buf >> 31; buf <<= 1; --cnt; return r; }
-    int bits(int n) { int r = 0; for (int i = 0; i < n; ++i) r = (r << 1) | bit(); return r; }
+    int bits(int n) {  // n <= 16
+        if (n == 0) return 0;
+        if (cnt < n) fill();
+        const int r = (int)(buf >> (32 - n));
+        buf <<= n; cnt -= n;
+        return r;
+    }
     void reset() { buf = 0; cnt = 0; hit_marker = false; }
 };
 
+// One Huffman symbol: the next 9 bits index a table that resolves every code of up to 9 bits (nearly all of them) in one
+// step; longer codes fall back to the canonical length-by-length search.  Consumes exactly the bits of the code.
 int decode_sym(BitReader& br, const Huff& h) {
-    int code = 0;
-    for (int l = 1; l <= 16; ++l) {
-        code = (code << 1) | br.bit();
-        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+    if (br.cnt < 16) br.fill();
+    const uint16_t e = h.fast[br.buf >> 23];
+    if (e) {
+        const int l = e >> 8;
+        br.buf <<= l; br.cnt -= l;
+        return e & 255;
     }
+    const int top = (int)(br.buf >> 16);
+    for (int l = 1; l <= 16; ++l) {
+        const int code = top >> (16 - l);
+        if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) {
+            br.buf <<= l; br.cnt -= l;
+            return h.vals[h.valptr[l] + code - h.mincode[l]];
+        }
+    }
+    br.buf <<= 16; br.cnt -= 16;  // no code matches: the 16 bits are spent, as they were bit by bit
     return -1;
 }
 int extend(int v, int t) { return t == 0 ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
@@ -86,23 +112,32 @@ void idct8x8(const float* in, uint8_t* out, int stride) {
             for (int u = 0; u < 8; ++u) c[x][u] = (u == 0 ? std::sqrt(0.125f) : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846f / 16.0f);
         init = true;
     }
+    // Most coefficients of most blocks are zero, and a zero term adds nothing: rows stop at their last non-zero coefficient,
+    // all-zero rows are skipped in the column pass.  Every remaining term is added in the same order: results unchanged.
     float tmp[64];
-    for (int y = 0; y < 8; ++y)
+    int live[8], nlive = 0;
+    for (int y = 0; y < 8; ++y) {
+        int last = -1;
+        for (int u = 0; u < 8; ++u) if (in[y * 8 + u] != 0.0f) last = u;
+        if (last < 0) { for (int x = 0; x < 8; ++x) tmp[y * 8 + x] = 0.0f; continue; }
+        live[nlive++] = y;
         for (int x = 0; x < 8; ++x) {
             float s = 0;
-            for (int u = 0; u < 8; ++u) s += c[x][u] * in[y * 8 + u];
+            for (int u = 0; u <= last; ++u) s += c[x][u] * in[y * 8 + u];
             tmp[y * 8 + x] = s;
         }
+    }
     for (int x = 0; x < 8; ++x)
         for (int y = 0; y < 8; ++y) {
             float s = 0;
-            for (int v = 0; v < 8; ++v) s += c[y][v] * tmp[v * 8 + x];
-            const int q = (int)std::lround(s + 128.0f);
-            out[y * stride + x] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+            for (int k = 0; k < nlive; ++k) s += c[y][live[k]] * tmp[live[k] * 8 + x];
+            const float v = s + 128.0f;
+            out[y * stride + x] = (uint8_t)(v <= 0.0f ? 0 : v >= 255.0f ? 255 : (int)(v + 0.5f));  // = lround + clamp
         }
 }
 
-uint8_t clamp8(float v) { const int q = (int)std::lround(v); return (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q); }
+// round half up on [0, 255] = std::lround there, without the libm call per sample
+inline uint8_t clamp8(float v) { return (uint8_t)(v <= 0.0f ? 0 : v >= 255.0f ? 255 : (int)(v + 0.5f)); }
 
 
 // One entropy-coded scan of any of the supported processes into the coefficient arrays (T.81 F.2 sequential,
@@ -361,25 +396,36 @@ bool decode_jpeg_memory(const uint8_t* d, size_t len, Image& out, std::string& e
         up[i].resize((size_t)W * H);
         const std::vector<uint8_t>& pl = comp[i].plane;
         const int pw = comp[i].pw;
-        auto at = [&](int x, int y) { x = x < 0 ? 0 : x >= cw ? cw - 1 : x; y = y < 0 ? 0 : y >= chh ? chh - 1 : y; return (int)pl[(size_t)y * pw + x]; };
         bool fx = rx == 2 && hmax % comp[i].h == 0, fy = ry == 2 && vmax % comp[i].v == 0;
         if (fx && cw <= 2) fx = fy = false;  // libjpeg (jdsample.c): the h2v1 / h2v2 triangle filters need more than two samples per row, else replication
-        for (int y = 0; y < H; ++y)
-            for (int x = 0; x < W; ++x) {
-                const int sx = x * comp[i].h / hmax, sy = y * comp[i].v / vmax;
-                int v;
-                if (fx && fy) {
-                    const int nx = sx + ((x & 1) ? 1 : -1), ny = sy + ((y & 1) ? 1 : -1);
-                    v = (9 * at(sx, sy) + 3 * at(nx, sy) + 3 * at(sx, ny) + at(nx, ny) + 8) >> 4;
-                } else if (fx) {
-                    v = (3 * at(sx, sy) + at(sx + ((x & 1) ? 1 : -1), sy) + ((x & 1) ? 2 : 1)) >> 2;
-                } else if (fy) {
-                    v = (3 * at(sx, sy) + at(sx, sy + ((y & 1) ? 1 : -1)) + 2) >> 2;
-                } else {
-                    v = at(sx, sy);
-                }
-                up[i][(size_t)y * W + x] = (uint8_t)v;
+        // per output column: the nearest sample and the next-nearest one (clamped to the valid samples), computed once
+        std::vector<int> sxs(W), nxs(W);
+        for (int x = 0; x < W; ++x) {
+            const int sx = std::min(x * comp[i].h / hmax, cw - 1);
+            int nx = sx + ((x & 1) ? 1 : -1);
+            nx = nx < 0 ? 0 : nx >= cw ? cw - 1 : nx;
+            sxs[x] = sx; nxs[x] = nx;
+        }
+        for (int y = 0; y < H; ++y) {
+            const int sy = std::min(y * comp[i].v / vmax, chh - 1);
+            int ny = sy + ((y & 1) ? 1 : -1);
+            ny = ny < 0 ? 0 : ny >= chh ? chh - 1 : ny;
+            const uint8_t* r0 = pl.data() + (size_t)sy * pw;
+            const uint8_t* r1 = pl.data() + (size_t)ny * pw;
+            uint8_t* o = up[i].data() + (size_t)y * W;
+            if (fx && fy) {
+                for (int x = 0; x < W; ++x)
+                    o[x] = (uint8_t)((9 * r0[sxs[x]] + 3 * r0[nxs[x]] + 3 * r1[sxs[x]] + r1[nxs[x]] + 8) >> 4);
+            } else if (fx) {
+                for (int x = 0; x < W; ++x) o[x] = (uint8_t)((3 * r0[sxs[x]] + r0[nxs[x]] + ((x & 1) ? 2 : 1)) >> 2);
+            } else if (fy) {
+                for (int x = 0; x < W; ++x) o[x] = (uint8_t)((3 * r0[sxs[x]] + r1[sxs[x]] + 2) >> 2);
+            } else if (rx == 1) {
+                memcpy(o, r0, (size_t)W);
+            } else {
+                for (int x = 0; x < W; ++x) o[x] = r0[sxs[x]];
             }
+        }
     }
     const bool ycc = ncomp == 3 && adobe_transform != 0;
     for (size_t p = 0; p < (size_t)W * H; ++p) {
