@@ -255,6 +255,52 @@ def test_sharded_image_through_the_library_on_one_device(params, n, prec):
             e.close()
 
 
+def test_contexts_are_independent_across_host_threads(params):
+    """include/srhip.h: a context is single-caller, distinct contexts may be driven from distinct threads.  Four threads,
+    each with its own context of the one device (two per arithmetic mode), hammer the host-pointer and the device-pointer
+    entry points with different shapes at once (ctypes releases the GIL inside the library); every result must equal the one
+    a lone context gives."""
+    import threading
+    import torch
+    import rusty_sr_amd as r
+    shapes = [(1, 300, 515), (2, 64, 64), (1, 523, 1100), (1, 40, 70), (3, 37, 129), (1, 700, 900)]
+    rng = np.random.default_rng(23)
+    imgs = [rng.integers(0, 256, sh + (3,), dtype=np.uint8) for sh in shapes]
+    want = {}
+    for prec in ("f32", "split_f16"):
+        e = r.Engine(params["imagenet"], precision=prec)
+        want[prec] = [e.upscale_rgba8(px) for px in imgs]
+        e.close()
+    errors = []
+
+    def worker(k):
+        prec = ("f32", "split_f16")[k % 2]
+        try:
+            e = r.Engine(params["imagenet"], precision=prec)
+            stream = torch.cuda.Stream()
+            for it in range(6):
+                for j in np.random.default_rng(k * 10 + it).permutation(len(imgs)):
+                    if (it + j + k) % 2:
+                        got = e.upscale_rgba8(imgs[j])
+                    else:
+                        with torch.cuda.stream(stream):
+                            got = e.upscale_rgba8_dev(torch.from_numpy(imgs[j]).cuda(), stream=stream)
+                            stream.synchronize()
+                        got = got.cpu().numpy()
+                    if not np.array_equal(got, want[prec][j]):
+                        errors.append((k, prec, it, shapes[j]))
+            e.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append((k, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+
+
 @pytest.mark.parametrize("prec", ["f32", "split_f16"])
 def test_feature_maps_beyond_four_gib(params, prec):
     """Maximum sizes: a 6100 x 6200 image has 4.9 GB per 32-channel feature map, so the undivided device-resident pass
