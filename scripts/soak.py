@@ -33,8 +33,8 @@ def soak(budget, seed=None):
         while time.time() < t_prec:
             n = int(rng.choice([1, 1, 1, 2, 3]))
             h, w = int(rng.integers(1, 700)), int(rng.integers(1, 1000))
-            if rng.random() < 0.15:
-                h, w = int(rng.integers(700, 1400)), int(rng.integers(1000, 2200))
+            if rng.random() < (0.6 if os.environ.get("SOAK_BIG") else 0.15):  # SOAK_BIG=1: mostly large frames (many rounds of tiles, stealing)
+                h, w = int(rng.integers(700, 2400 if os.environ.get("SOAK_BIG") else 1400)), int(rng.integers(1000, 4000 if os.environ.get("SOAK_BIG") else 2200))
             if rng.random() < 0.1:
                 h, w = int(rng.integers(1, 12)), int(rng.integers(1, 4000))
             px = torch.from_numpy(rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
