@@ -2,7 +2,7 @@
 // dynamic Huffman codes, nothing else.  zlib's Z_RLE strategy makes the same choices and -- on filtered residuals of
 // continuous-tone images, where longer LZ77 matches are rare and only distort the literal statistics -- already gives
 // smaller files than its general matcher (png.cpp encode_band); this encoder writes that format several times faster
-// because it does nothing general: one pass turns a block into tokens and a histogram, one builds the two code tables,
+// because it does nothing general: one pass counts a block's bytes and notes its runs, one builds the two code tables,
 // one writes the bits through a 64-bit buffer.  The output is a plain deflate stream any inflate reads
 // (tests/test_host_cli.py decodes it with zlib and Pillow).
 #include <algorithm>
@@ -105,29 +105,46 @@ const LenCode* length_table() {
     return t;
 }
 
-// one deflate block of src[0, n): tokens, tables, bits.  false (nothing written): the block would not fit before `end`.
-bool encode_block(const uint8_t* src, size_t n, bool final_block, BitSink& out, const uint8_t* end, std::vector<uint16_t>& tokens) {
+// one deflate block of src[0, n): runs and histogram, tables, bits.  false (nothing written): the block would not fit before `end`.
+// Most bytes of filtered pixels are literals, so they are never turned into tokens: the first pass only counts them (four
+// interleaved histograms: consecutive equal bytes would otherwise serialise on one counter) and notes where runs start;
+// the last pass walks the source again and emits literals straight from it.
+struct Run { uint32_t pos; uint32_t len; };  // len bytes equal to src[pos - 1], starting at pos (len >= 3)
+
+bool encode_block(const uint8_t* src, size_t n, bool final_block, BitSink& out, const uint8_t* end, std::vector<Run>& runs) {
     const LenCode* LT = length_table();
     uint32_t freq[286] = {0};
-    tokens.clear();
-    // tokens: < 256 literal, >= 0x8000 a run of (token & 0x1ff) bytes equal to the byte before it
+    uint32_t h4[4][256];
+    memset(h4, 0, sizeof h4);
+    runs.clear();
     size_t i = 0;
-    while (i < n) {
+    while (i + 3 < n) {
         const uint8_t b = src[i];
-        size_t j = i + 1;
-        while (j < n && src[j] == b) ++j;
-        size_t run = j - i;
-        tokens.push_back(b); ++freq[b];
-        --run;
-        while (run >= 3) {
-            size_t l = std::min<size_t>(run, 258);
-            if (run - l > 0 && run - l < 3) l = run - 3;  // leave a tail that is still a match
-            tokens.push_back((uint16_t)(0x8000 | l)); ++freq[257 + LT[l].sym];
-            run -= l;
+        uint32_t four;
+        memcpy(&four, src + i, 4);
+        if (four == b * 0x01010101u) {  // four equal bytes: a literal and a run of >= 3 (one rarely taken branch, no data-dependent chain)
+            size_t j = i + 4;
+            while (j < n && src[j] == b) ++j;
+            ++h4[0][b];
+            runs.push_back({(uint32_t)(i + 1), (uint32_t)(j - i - 1)});
+            i = j;
+        } else {
+            ++h4[i & 3][b];
+            ++i;
         }
-        for (; run > 0; --run) { tokens.push_back(b); ++freq[b]; }
-        i = j;
     }
+    for (; i < n; ++i) ++h4[0][src[i]];
+    for (int v = 0; v < 256; ++v) freq[v] = h4[0][v] + h4[1][v] + h4[2][v] + h4[3][v];
+    // a run goes out as matches of 3..258 bytes (never leaving a tail of 1 or 2)
+    auto for_each_match = [](uint32_t len, auto&& f) {
+        while (len >= 3) {
+            uint32_t l = len < 258 ? len : 258;
+            if (len - l > 0 && len - l < 3) l = len - 3;
+            f(l);
+            len -= l;
+        }
+    };
+    for (const Run& r : runs) for_each_match(r.len, [&](uint32_t l) { ++freq[257 + LT[l].sym]; });
     freq[256] = 1;
     uint8_t ll_len[286], d_len[30] = {0};
     huffman_lengths(freq, 286, 15, ll_len);
@@ -187,19 +204,30 @@ bool encode_block(const uint8_t* src, size_t n, bool final_block, BitSink& out, 
         out.put(cl_code[cl[k].sym], cl_len[cl[k].sym]);
         if (cl[k].extra_bits) out.put(cl[k].extra, cl[k].extra_bits);
     }
-    // literal code + length packed per byte value, so the hot loop is one load and one put
+    // literal code + length packed per byte value; two literals go out per put (2 x 15 bits fit the 32-bit window)
     uint32_t lit[256];
     for (int v = 0; v < 256; ++v) lit[v] = (uint32_t)ll_code[v] | (uint32_t)ll_len[v] << 16;
-    for (const uint16_t t : tokens) {
-        if (t < 256) {
-            out.put(lit[t] & 0xffff, (int)(lit[t] >> 16));
-        } else {
-            const LenCode& lc = LT[t & 0x1ff];
-            const int s = 257 + lc.sym;
-            // length code, its extra bits, and the 1-bit distance code (0) in one go: at most 15 + 5 + 1 bits
-            out.put((uint32_t)ll_code[s] | (uint32_t)lc.extra << ll_len[s], ll_len[s] + lc.extra_bits + 1);
+    auto literals = [&](size_t from, size_t to) {
+        size_t k = from;
+        for (; k + 1 < to; k += 2) {
+            const uint32_t a = lit[src[k]], b = lit[src[k + 1]];
+            const int la = (int)(a >> 16), lb = (int)(b >> 16);
+            out.put((a & 0xffff) | (b & 0xffff) << la, la + lb);
         }
+        if (k < to) out.put(lit[src[k]] & 0xffff, (int)(lit[src[k]] >> 16));
+    };
+    size_t pos = 0;
+    for (const Run& r : runs) {
+        literals(pos, r.pos);
+        for_each_match(r.len, [&](uint32_t l) {
+            const LenCode& lc = LT[l];
+            const int sy = 257 + lc.sym;
+            // length code, its extra bits, and the 1-bit distance code (0) in one go: at most 15 + 5 + 1 bits
+            out.put((uint32_t)ll_code[sy] | (uint32_t)lc.extra << ll_len[sy], ll_len[sy] + lc.extra_bits + 1);
+        });
+        pos = (size_t)r.pos + r.len;
     }
+    literals(pos, n);
     out.put(ll_code[256], ll_len[256]);
     return true;
 }
@@ -218,13 +246,12 @@ size_t rle_deflate(const uint8_t* src, size_t n, bool last, uint8_t* dst, size_t
     if (cap < 32) return 0;
     const uint8_t* end = dst + cap;
     BitSink out{dst};
-    std::vector<uint16_t> tokens;
-    tokens.reserve(std::min<size_t>(n, (size_t)1 << 18) + 16);
+    std::vector<Run> runs;
     const size_t block = (size_t)1 << 18;
     size_t pos = 0;
     do {
         const size_t m = std::min(block, n - pos);
-        if (!encode_block(src + pos, m, last && pos + m == n, out, end - 8, tokens)) return 0;
+        if (!encode_block(src + pos, m, last && pos + m == n, out, end - 8, runs)) return 0;
         pos += m;
     } while (pos < n);
     if (!last) {
