@@ -32,26 +32,36 @@ int paeth(int a, int b, int c) {
 }
 
 // undo PNG filtering in place: `rows` scanlines of `stride` bytes, each preceded by its filter byte.  One loop per
-// filter type with the first pixel (no left neighbour) peeled off, so the inner loops carry no tests.
-bool unfilter(uint8_t* d, int rows, size_t stride, int bpp, std::string& err) {
+// filter type with the first pixel (no left neighbour) peeled off, so the inner loops carry no tests; the bytes-per-pixel
+// count is a compile-time constant, so the B independent channel chains of Sub / Average / Paeth are unrolled side by side
+// (each byte depends on the byte B positions back: latency-bound when done one after the other).
+template <size_t B>
+bool unfilter_bpp(uint8_t* d, int rows, size_t stride, std::string& err) {
     const uint8_t* prev = nullptr;
-    const size_t B = (size_t)bpp, head = std::min(B, stride);
+    const size_t head = std::min(B, stride);
     for (int y = 0; y < rows; ++y) {
         uint8_t* line = d + (size_t)y * (stride + 1);
         const int ft = line[0];
         uint8_t* cur = line + 1;
         switch (ft) {
             case 0: break;
-            case 1:
-                for (size_t i = B; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - B]);
+            case 1: {
+                size_t i = B;
+                for (; i + B <= stride; i += B)
+                    for (size_t c = 0; c < B; ++c) cur[i + c] = (uint8_t)(cur[i + c] + cur[i + c - B]);
+                for (; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - B]);
                 break;
+            }
             case 2:
                 if (prev) for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]);
                 break;
             case 3:
                 if (prev) {
                     for (size_t i = 0; i < head; ++i) cur[i] = (uint8_t)(cur[i] + (prev[i] >> 1));
-                    for (size_t i = B; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + ((cur[i - B] + prev[i]) >> 1));
+                    size_t i = B;
+                    for (; i + B <= stride; i += B)
+                        for (size_t c = 0; c < B; ++c) cur[i + c] = (uint8_t)(cur[i + c] + ((cur[i + c - B] + prev[i + c]) >> 1));
+                    for (; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + ((cur[i - B] + prev[i]) >> 1));
                 } else {
                     for (size_t i = B; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + (cur[i - B] >> 1));
                 }
@@ -59,11 +69,21 @@ bool unfilter(uint8_t* d, int rows, size_t stride, int bpp, std::string& err) {
             case 4:
                 if (prev) {
                     for (size_t i = 0; i < head; ++i) cur[i] = (uint8_t)(cur[i] + prev[i]);  // paeth(0, b, 0) = b
-                    for (size_t i = B; i < stride; ++i) {
+                    auto one = [&](size_t i) {
+                        // the predictor as a running minimum (ties keep the earlier of a, b, c: the PNG rule) -- conditional
+                        // moves, where the textbook if-chain mispredicts on every other byte of a photograph
                         const int a = cur[i - B], bb = prev[i], c = prev[i - B];
                         const int pa = abs(bb - c), pb = abs(a - c), pc = abs(a + bb - 2 * c);
-                        cur[i] = (uint8_t)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c)));
-                    }
+                        int pred = a, best = pa;
+                        pred = pb < best ? bb : pred;
+                        best = pb < best ? pb : best;
+                        pred = pc < best ? c : pred;
+                        cur[i] = (uint8_t)(cur[i] + pred);
+                    };
+                    size_t i = B;
+                    for (; i + B <= stride; i += B)
+                        for (size_t c = 0; c < B; ++c) one(i + c);
+                    for (; i < stride; ++i) one(i);
                 } else {
                     for (size_t i = B; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - B]);  // paeth(a, 0, 0) = a
                 }
@@ -73,6 +93,18 @@ bool unfilter(uint8_t* d, int rows, size_t stride, int bpp, std::string& err) {
         prev = cur;
     }
     return true;
+}
+
+bool unfilter(uint8_t* d, int rows, size_t stride, int bpp, std::string& err) {
+    switch (bpp) {
+        case 1: return unfilter_bpp<1>(d, rows, stride, err);
+        case 2: return unfilter_bpp<2>(d, rows, stride, err);
+        case 3: return unfilter_bpp<3>(d, rows, stride, err);
+        case 4: return unfilter_bpp<4>(d, rows, stride, err);
+        case 6: return unfilter_bpp<6>(d, rows, stride, err);
+        case 8: return unfilter_bpp<8>(d, rows, stride, err);
+        default: err = "unsupported PNG pixel size"; return false;
+    }
 }
 
 struct Hdr { int w, h, depth, ctype, interlace; };
