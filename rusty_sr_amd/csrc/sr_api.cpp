@@ -436,7 +436,7 @@ int sr_host_alloc(void** out, size_t bytes) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SR_E_NO_DEVICE;
     const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
-    if (e != hipSuccess) { *out = nullptr; return e == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP; }
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return e == hipErrorOutOfMemory ? SR_E_NOMEM : SR_E_HIP; }
     return SR_OK;
 }
 
