@@ -67,3 +67,24 @@ def test_rust_host_speaks_like_the_cpp_host():
     for blob in ("imagenet.rsr", "imagenetlinear.rsr", "anime.rsr"):
         assert f'include_bytes!("../../rusty_sr_amd/res/{blob}")' in rs
         assert os.path.exists(os.path.join(ROOT, "rusty_sr_amd", "res", blob))
+
+
+def _extern_decls(text):
+    """The declarations of the first `extern "C" { ... }` block of `text`, comments and layout removed."""
+    block = text[text.index('extern "C" {') + len('extern "C" {'):]
+    block = block[:block.index("\n}")]
+    block = re.sub(r"//[^\n]*", "", block)
+    decls = [re.sub(r"\s+", " ", d).strip() for d in block.split(";")]
+    return [d for d in decls if d]
+
+
+def test_integration_md_shows_the_same_extern_block():
+    """The Rust block INTEGRATION.md shows a maintainer must parse and must BE rust_host/src/srhip.rs's block
+    (round 2 shipped it with two declarations pasted into the middle of a third)."""
+    md = _read(ROOT, "INTEGRATION.md")
+    rust_block = md[md.index("```rust") + len("```rust"):]
+    rust_block = rust_block[:rust_block.index("```")]
+    shown, real = _extern_decls(rust_block), _extern_decls(_read(RS, "srhip.rs"))
+    for d in shown:  # every declaration is one well-formed `pub fn name(args) [-> ret]`
+        assert re.fullmatch(r"pub fn sr_\w+\([^()]*\)( -> [\w*: ]+)?", d), d
+    assert shown == real
