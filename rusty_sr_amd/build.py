@@ -6,6 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrhip.so")
 SOURCES = ["sr_kernels.hip", "sr_api.cpp", "sr_comm.cpp"]
+DEVICE_ASM = os.path.join(HERE, "build", "temps", "sr_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
 HEADERS = ["sr_kernels.h", "sr_internal.h", os.path.join("..", "..", "include", "srhip.h")]
 
 
@@ -32,11 +33,19 @@ def build_lib(force=False, verbose=False):
         src, obj = os.path.join(CSRC, f), os.path.join(objdir, f + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + hdrs):
-            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", obj + f".{os.getpid()}.tmp"]
+            tmp = obj + f".{os.getpid()}.tmp"
+            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", tmp]
+            if f.endswith(".hip"):
+                # keep the device assembly of the kernels: scripts/check_async_regs.py lints it (tests/test_abi.py).  The
+                # compiler's temporaries go to build/temps/ (36 MB; listed in .gpurunignore, the GPU box has no use for them)
+                temps = os.path.join(objdir, "temps")
+                os.makedirs(temps, exist_ok=True)
+                tmp = os.path.join(temps, f + ".o")
+                cmd = [hipcc, "-save-temps=obj", *FLAGS, "-x", "hip", "-c", src, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            os.replace(obj + f".{os.getpid()}.tmp", obj)
+            os.replace(tmp, obj)
             relink = True
     if relink or _newer(LIB, objs):
         tmp = LIB + f".{os.getpid()}.tmp"

@@ -108,33 +108,6 @@ void pack_steps(std::vector<float>& dst, const float* w, int ks, int ntn, bool s
             }
 }
 
-// Weight stream of the split-half COLUMN form of the stage kernels (conv_stage_col_kernel): one 2 KB chunk per tap of one
-// 16-channel half -- [hi | lo] x [h 2][lane 32][8 halves], channel = 16 half + 8 h + e -- taps in kernel-COLUMN order
-// (kx outer, ky inner: a step of that kernel is one kernel column), half 0 of a source before its half 1.
-void pack_cols(std::vector<float>& dst, const float* w, int ks, int (*lane_channel)(int, int), int f) {
-    for (int half = 0; half < 2; ++half)
-        for (int kx = 0; kx < ks; ++kx)
-            for (int ky = 0; ky < ks; ++ky) {
-                const size_t base = dst.size();
-                dst.resize(base + 512, 0.0f);
-                _Float16* hp = (_Float16*)(dst.data() + base);
-                for (int j = 0; j < 32; ++j) {
-                    const int o = lane_channel(f, j);
-                    if (o < 0) continue;
-                    const float* src = w + ((size_t)o * ks * ks + ky * ks + kx) * 32 + 16 * half;
-                    for (int c = 0; c < 16; ++c) {
-                        _Float16 hi, lo;
-                        split_half_host(src[c], hi, lo);
-                        const int h = c / 8, e = c % 8;
-                        hp[(h * 32 + j) * 8 + e] = hi;
-                        hp[512 + (h * 32 + j) * 8 + e] = lo;
-                    }
-                }
-            }
-}
-int lane_ident(int, int j) { return j; }
-int lane_expand(int f, int j) { return expand_channel(f, 0, j); }
-
 // conv0 [32][5][5][3]: K packed per kernel row -- slot k = 3 kx + c (15 used of 16) -- as
 // [ky 5][jj 4][h 2][o 32][e 2] with k = 2 (2 jj + e) + h  (conv0_kernel: B[k][o] for MFMA j = 2 jj + e).
 void pack_conv0(std::vector<float>& dst, const float* w) {
@@ -249,11 +222,12 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     if (device < 0 || device >= ndev) return SR_E_INVALID;
     sr_ctx* c = new (std::nothrow) sr_ctx();
     if (!c) return SR_E_NOMEM;
+    sr_device_guard restore_device;
     c->device = device;
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[7][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"dbg", "SRHIP_DBG"}, {"cols", "SRHIP_COLS"},
+    static const char* const kSwitch[6][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
                                               {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
@@ -320,20 +294,6 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
             pack_lin(w, factor);  // f32 in both modes: the residual is the signal, it stays on the exact path
             off[4] = push(w);
         }
-        if (expand_tiles(factor) == 1) {  // column-form chunks of the split-half mode (one N-tile only: factor 2, 3)
-            w.clear(); pack_cols(w, params + L.conv1, 5, lane_ident, factor);
-            c->off_wc[1] = push(w);
-            w.clear(); pack_cols(w, params + L.conv2, 5, lane_ident, factor); pack_cols(w, params + L.conv5, 3, lane_ident, factor);
-            c->off_wc[2] = push(w);
-            w.clear(); pack_cols(w, params + L.conv3, 5, lane_ident, factor); pack_cols(w, params + L.conv6, 3, lane_ident, factor);
-            pack_cols(w, params + L.conv8, 3, lane_ident, factor);
-            c->off_wc[3] = push(w);
-            w.clear(); pack_cols(w, params + L.conv7, 3, lane_expand, factor); pack_cols(w, params + L.conv9, 3, lane_expand, factor);
-            pack_cols(w, params + L.conv10, 3, lane_expand, factor);
-            pack_lin(w, factor);
-            c->off_wc[4] = push(w);
-            c->have_cols = true;
-        }
         const size_t boff[4] = {L.f_bias, L.l_bias[0], L.l_bias[1], L.l_bias[2]};
         const size_t aoff[4] = {L.f_activ, L.l_activ[0], L.l_activ[1], L.l_activ[2]};
         for (int s = 0; s < 4; ++s) c->off_bias[s] = push(vec32(boff[s], 32));
@@ -366,6 +326,7 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
 
 void sr_destroy(sr_ctx* c) {
     if (!c) return;
+    sr_device_guard restore_device;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     sr_comm_release(c);
@@ -406,16 +367,14 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
             const char ch = strlen(v) == 5 ? v[k] : v[0];
             c->env_th[k] = ch == '4' ? 4 : (ch == '8' ? 8 : 0);
         }
-    } else if (!strcmp(key, "pipe")) { // "none": first form of the stage kernels everywhere
-        c->env_pipe = strcmp(v, "none") != 0;
+    } else if (!strcmp(key, "pipe")) { // "" automatic; "none": first form of the stage kernels everywhere; "all": pipe form also for small launches
+        c->env_pipe = !strcmp(v, "none") ? 0 : !strcmp(v, "all") ? 2 : 1;
     } else if (!strcmp(key, "bands")) {  // host pipeline: row bands of one large image ("" / "0": automatic)
         c->env_bands = *v ? atoi(v) : 0;
     } else if (!strcmp(key, "geo")) {  // "0": equal bands also where the host pipeline would shrink them geometrically
         c->env_geo = strcmp(v, "0") != 0;
-    } else if (!strcmp(key, "cols")) {  // "0": split-half mode runs the step form of the pipe kernel instead of the column form
-        c->env_cols = strcmp(v, "0") != 0;
-    } else if (!strcmp(key, "dbg")) {  // timing experiments that BREAK the results (StageArgs::dbg); never set outside scripts/
-        c->env_dbg = atoi(v);
+    } else if (!strcmp(key, "tail")) {  // how many 4-row tiles end a launch of 8-row tiles, in units of the resident workgroups ("" : automatic, "0": none)
+        c->env_tail = *v ? (float)atof(v) : -1.0f;
     } else if (!strcmp(key, "bw")) {   // tile-order column-block width in tiles; "" / negative: automatic, 0: plain row-major
         c->env_bw = *v ? atoi(v) : -1;
     } else {
@@ -524,6 +483,7 @@ int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
 int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top,
                  int halo_bot, void* d_out, bool out_u8, hipStream_t s, int slot) {
     if (!c || !d_img || !d_out || slot < 0 || slot > 1) return SR_E_INVALID;
+    sr_device_guard restore_device;
     sr_ctx::Workspace& ws = c->ws[slot];
     if (n <= 0 || H <= 0 || W <= 0) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
@@ -548,37 +508,76 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
     const int tiles_x = (W + 31) / 32;
     int rc = ensure_features(c, ws, n, H, W, tiles_x, s);
     if (rc != SR_OK) return rc;
-    // tile height: 8 rows when that still gives every CU two workgroups, else 4
-    const long tiles8 = (long)n * tiles_x * ((bot - top + 7) / 8);
-    const int th_all = tiles8 >= 2L * (c->cus > 0 ? c->cus : 256) ? 8 : 4;
-    int ths[5] = {th_all, th_all, th_all, th_all, th_all};
-    for (int k = 0; k < 5; ++k) if (c->env_th[k]) ths[k] = c->env_th[k];  // SRHIP_TH experiment override
+    const int cus = c->cus > 0 ? c->cus : 256;
+    const int resident = 2 * cus;  // workgroups of a stage kernel that fit the chip at once (2 per CU: 76-78 KB of LDS each)
     const float* P = c->d_params;
     const bool prof = c->profiling;
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
     float* feat[4];
     for (int k = 0; k < 4; ++k) feat[k] = ws.d_feat[k] + ((size_t)kFeatPad * ws.pitch + kFeatPad) * 32;
-    // 8-row tiles run the pipe form of the stage kernels (half tiles double-buffered, persistent), 4-row tiles (small
-    // images) the first form; the two are bit-identical.  SRHIP_PIPE=none forces the first form everywhere (A/B runs).
-    const bool pipe = c->env_pipe;
+    const int bw = c->env_bw >= 0 ? c->env_bw : kAutoBlockWidth;
+    // ---- plan every launch first: conv0 (the call's first launch) sets the tile-queue heads of the four stage kernels
+    struct Launch { int y0, y1, ty8, ty4, th, grid; bool pipe; } L[5];
+    for (int st = 0; st < 5; ++st) {
+        Launch& l = L[st];
+        l.y0 = std::max(0, top - margin[st]);
+        l.y1 = std::min(H, bot + margin[st]);
+        const int rows = l.y1 - l.y0;
+        // Tile classes of the launch (sr_kernels.h TileGrid): `ty8` rows of 8-row tiles, then `ty4` rows of 4-row tiles.
+        // Measured on MI355X (profiles/r3_tileplans_*, r3_queuefix_*; `rounds` = 8-row tiles per resident workgroup):
+        //  * exact f32, a SMALL launch (rounds < 2): 4-row tiles on the first form of the stage kernel -- one tile per
+        //    workgroup, no queue (256x256: 0.157 ms against 0.176-0.178 on either tile class of the pipe form);
+        //  * split-half mode, small launch: the pipe form all the same (256x256: 0.091 ms against 0.24), 8-row tiles while
+        //    they still give every CU one, else 4-row tiles;
+        //  * otherwise the pipe form on 8-row tiles, and in exact f32 the LAST tiles of every XCD's queue are 4-row tiles
+        //    (sr_set_experiment "tail") when the last round of 8-row tiles would be less than 70 % full: a persistent
+        //    launch ends when its slowest workgroup does, and half-size last tiles halve what the partly filled round
+        //    costs (8-way band of 3840x2160, 8.2 rounds: -2.3 %; 4-way, 16.2: -0.9 %; 1080p, 15.8 and 512x512, 2.0: none,
+        //    there they only cost their own 3-4 %).  The split-half mode pays 17 % per 4-row tile (its B operands are
+        //    re-read per tile row) and keeps 8-row tiles.
+        //  conv0 and the first form run one class.
+        const long tiles8 = (long)n * tiles_x * ((rows + 7) / 8);
+        const int forced = c->env_th[st];
+        const bool small_launch = tiles8 < 2L * resident;
+        const bool split = c->precision == SR_PRECISION_SPLIT_F16;
+        l.pipe = st > 0 && c->env_pipe != 0 && (c->env_pipe == 2 || !small_launch || split);
+        l.ty8 = (rows + 7) / 8; l.ty4 = 0;
+        if (forced == 4 || (!forced && small_launch && (!split || tiles8 < cus))) {
+            l.ty8 = 0; l.ty4 = (rows + 3) / 4;
+        } else if (!forced && l.pipe && !small_launch) {
+            const double rounds = (double)tiles8 / resident;
+            float tail = c->env_tail;
+            if (tail < 0.0f) tail = (!split && std::ceil(rounds) - rounds > 0.3) ? 0.75f : 0.0f;
+            if (tail > 0.0f) {
+                const long per_row = (long)n * tiles_x;
+                const int want = (int)((tail * resident + per_row - 1) / per_row);  // tile rows of small tiles
+                l.ty8 = std::max(0, (rows - 4 * want) / 8);
+                l.ty4 = std::max(0, (rows - 8 * l.ty8 + 3) / 4);
+            }
+        }
+        l.th = l.ty8 > 0 ? 8 : 4;  // the one class of conv0 / the first form
+        if (!l.pipe && l.ty8 > 0) { l.ty8 = (rows + 7) / 8; l.ty4 = 0; }
+        const int ntiles = n * tiles_x * (l.ty8 + l.ty4);
+        // the pipe form is persistent: one workgroup per resident slot, tiles from the queue; the first form one per tile
+        l.grid = l.pipe ? std::min(ntiles, resident) : ntiles;
+    }
+    static const bool trace_stages = [] { const char* e = getenv("SRHIP_TRACE"); return e && atoi(e) >= 2; }();
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
-        int y0 = top - margin[st], y1 = bot + margin[st];
-        if (y0 < 0) y0 = 0;
-        if (y1 > H) y1 = H;
-        const int th = ths[st];
-        const int tiles_y = (y1 - y0 + th - 1) / th;
-        const int nblk = n * tiles_x * tiles_y;
+        const Launch& l = L[st];
+        const int y0 = l.y0, y1 = l.y1;
         if (st == 0) {
+            const int tiles_y = (y1 - y0 + l.th - 1) / l.th;
             Conv0Args a{};
             a.img = d_img; a.wpack = P + c->off_w0; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
             a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
             a.pitch = ws.pitch; a.img_stride = ws.img_stride;
             a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
-            a.n_tiles = nblk;
+            a.n_tiles = n * tiles_x * tiles_y;
             a.queue_reset = ws.d_queue;
-            HIPCHK(c, sr_launch_conv0(a, th, c->precision, std::min(nblk, 8 * (c->cus > 0 ? c->cus : 256)), img_u8, s));
+            for (int k = 1; k < 5; ++k) a.queue_grid[k] = L[k].grid;
+            HIPCHK(c, sr_launch_conv0(a, l.th, c->precision, std::min(a.n_tiles, 8 * cus), img_u8, s));
         } else {
             StageArgs a{};
             float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
@@ -589,34 +588,25 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
                 case 3: a.src[0] = f; a.src[1] = l1; a.src[2] = l2; a.dst = l3; break;
                 case 4: a.src[0] = l1; a.src[1] = l2; a.src[2] = l3; a.img = d_img; a.out = d_out; break;
             }
-            const bool use_pipe = pipe && th == 8;
-            // split-half mode, pipe form, one N-tile: the column form of the kernel with its own chunk order
-            const bool use_cols = use_pipe && c->precision == SR_PRECISION_SPLIT_F16 && c->have_cols && c->env_cols;
-            a.wpack = P + (use_cols ? c->off_wc[st] : c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
+            a.wpack = P + (c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
             a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
             a.H = H; a.W = W; a.img_ch = img_ch;
-            a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+            a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x;
             a.n_img = n; a.queue = ws.d_queue + st * 8;
-            a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
-            set_tile_order(a, c->env_bw >= 0 ? c->env_bw : kAutoBlockWidth);
-            a.dbg = c->env_dbg;
-            // persistent kernels (the pipe form; the first form in split-half mode) get one workgroup per resident
-            // slot -- 2 per CU with 8-row tiles, 3 with 4-row tiles -- and pull tiles from the queue
-            int grid = nblk;
-            if (use_pipe || c->precision == SR_PRECISION_SPLIT_F16) {
-                int resident = (c->cus > 0 ? c->cus : 256) * (th == 8 ? 2 : 3);
-                if (c->env_dbg & 64) resident = (c->cus > 0 ? c->cus : 256);  // timing experiment: one workgroup per CU
-                if (grid > resident) grid = resident;
-            }
-            if (use_cols) {
-                HIPCHK(c, sr_launch_stage_cols(st, c->factor, a, grid, img_u8, out_u8, s));
-            } else if (use_pipe) {
-                HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, grid, img_u8, out_u8, s));
+            a.grid[0] = make_tile_grid(8, y0, l.ty8, tiles_x, n, bw);
+            a.grid[1] = make_tile_grid(4, y0 + 8 * l.ty8, l.ty4, tiles_x, n, bw);
+            if (l.pipe) {
+                HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, l.grid, img_u8, out_u8, s));
             } else {
-                HIPCHK(c, sr_launch_stage(st, c->factor, a, th, c->precision, grid, img_u8, out_u8, s));
+                HIPCHK(c, sr_launch_stage(st, c->factor, a, l.th, c->precision, l.grid, img_u8, out_u8, s));
             }
         }
         if (prof) HIPCHK(c, hipEventRecord(c->ev[st + 1], s));
+        if (trace_stages) {  // SRHIP_TRACE=2: which launch a hang or a fault belongs to
+            fprintf(stderr, "[srhip] stage %d launched: rows [%d,%d) th8 x%d th4 x%d grid %d %s ... ", st, l.y0, l.y1, l.ty8, l.ty4, l.grid, l.pipe ? "pipe" : "first");
+            const hipError_t e = hipStreamSynchronize(s);
+            fprintf(stderr, "%s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+        }
     }
     c->last_h = H; c->last_w = W;
     if (prof) {
@@ -761,6 +751,7 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
     if (c->graph == SR_GRAPH_DOWNSAMPLE && (h < 3 || w < 3)) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET && img_u8 != out_u8) return SR_E_INVALID;
+    sr_device_guard restore_device;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t in_px = img_u8 ? (size_t)img_ch : 3 * sizeof(float), out_px = out_u8 ? 4 : 3 * sizeof(float);
     if (y_hi < 0) y_hi = h;
@@ -1014,6 +1005,7 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
     if (!c || which < 0 || which > 3 || !out_host) return SR_E_INVALID;
     const size_t nf = (size_t)c->last_h * c->last_w * 32;
     if (nf == 0 || cap_floats < nf || !c->ws[0].d_feat[which]) return SR_E_INVALID;
+    sr_device_guard restore_device;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
     const float* src = c->ws[0].d_feat[which] + ((size_t)kFeatPad * c->ws[0].pitch + kFeatPad) * 32;

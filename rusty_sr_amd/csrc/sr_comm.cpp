@@ -36,6 +36,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -62,6 +63,7 @@ Rccl* rccl() {
         sym(r.CommInitRank, "ncclCommInitRank");
         sym(r.CommInitAll, "ncclCommInitAll");
         sym(r.CommDestroy, "ncclCommDestroy");
+        sym(r.CommAbort, "ncclCommAbort");
         sym(r.Send, "ncclSend");
         sym(r.Recv, "ncclRecv");
         sym(r.GroupStart, "ncclGroupStart");
@@ -80,6 +82,16 @@ Rccl* rccl() {
             return SR_E_COMM;                           \
         }                                               \
     } while (0)
+
+// An exchange that failed after some of its sends / receives were queued would leave them waiting for partners nobody
+// posted, and the stream drain behind them would never return.  ncclCommAbort ends whatever the communicator still has
+// in flight; the context then refuses sharded calls (SR_E_COMM) until a new sr_comm_init_*.
+void abort_comm(sr_ctx* c, Rccl* R) {
+    if (!c->comm) return;
+    if (R) (void)R->CommAbort((ncclComm_t)c->comm);
+    c->comm = nullptr;
+    c->comm_broken = true;
+}
 
 struct BandGeom {
     int top, bot, h_ext;
@@ -117,7 +129,7 @@ int post_exchange(sr_ctx* c, Rccl* R, const void* d_band, int h_band, const Band
 int prepare_band(sr_ctx* c, const void* d_band, int h_band, int w, size_t px_bytes, BandGeom& g, hipStream_t s) {
     if (!c || !d_band || h_band <= 0 || w <= 0) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET) return SR_E_INVALID;
-    if (c->comm_nranks > 1 && !c->comm && !c->comm_local) return SR_E_COMM;
+    if (c->comm_broken || (c->comm_nranks > 1 && !c->comm && !c->comm_local)) return SR_E_COMM;
     if (c->comm_nranks > 1 && h_band < SR_HALO) return SR_E_HALO;  // a neighbour reads SR_HALO rows of this band
     HIPCHK(c, hipSetDevice(c->device));
     g = band_geom(c, h_band, w, px_bytes);
@@ -133,6 +145,7 @@ int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, 
     if (!d_out) return SR_E_INVALID;
     if (u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
     if (c && c->comm_nranks > 1 && c->comm_local) return SR_E_COMM;  // the neighbours' rows are only known to sr_upscale_sharded_*_all
+    sr_device_guard restore_device;
     BandGeom g;
     int rc = prepare_band(c, d_band, h_band, w, u8 ? (size_t)img_ch : 3 * sizeof(float), g, s);
     if (rc != SR_OK) return rc;
@@ -143,8 +156,11 @@ int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, 
         NCCLCHK(c, R->GroupStart());
         rc = post_exchange(c, R, d_band, h_band, g, s);
         const ncclResult_t ge = R->GroupEnd();
-        if (rc != SR_OK) return rc;
-        NCCLCHK(c, ge);
+        if (rc != SR_OK || ge != ncclSuccess) {  // possibly half-posted: nothing of it may stay queued on the caller's stream
+            if (rc == SR_OK) c->last_nccl = (int)ge;
+            abort_comm(c, R);
+            return SR_E_COMM;
+        }
         if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[1], s));
     }
     rc = sr_run_stack(c, c->d_ext, u8, img_ch, 1, g.h_ext, w, g.top, g.bot, d_out, u8, s);
@@ -168,6 +184,7 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
     const bool local = ctxs[0]->comm_local;
     for (int k = 1; k < n; ++k)
         if (ctxs[k]->comm_local != local) return SR_E_INVALID;
+    sr_device_guard restore_device;
     Rccl* R = n > 1 && !local ? rccl() : nullptr;
     if (n > 1 && !local && !R) return SR_E_COMM;
     std::vector<BandGeom> g(n);
@@ -215,6 +232,10 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
             const ncclResult_t ge = R->GroupEnd();
             if (rc == SR_OK && ge != ncclSuccess) { ctxs[0]->last_nccl = (int)ge; rc = SR_E_COMM; }
         }
+        // a failure inside the group may have left some ranks' operations queued without partners: abort every
+        // communicator of the set, so that the drain below returns instead of waiting for them for ever
+        if (rc != SR_OK)
+            for (int k = 0; k < n; ++k) { (void)hipSetDevice(ctxs[k]->device); abort_comm(ctxs[k], R); }
     }
     for (int k = 0; k < n && rc == SR_OK; ++k)
         rc = sr_run_stack(ctxs[k], ctxs[k]->d_ext, u8, img_ch, 1, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, ctxs[k]->stream);
@@ -240,7 +261,7 @@ void sr_comm_release(sr_ctx* c) {
         if (Rccl* R = rccl()) (void)R->CommDestroy((ncclComm_t)c->comm);
         c->comm = nullptr;
     }
-    c->comm_rank = 0; c->comm_nranks = 1; c->comm_local = false;
+    c->comm_rank = 0; c->comm_nranks = 1; c->comm_local = false; c->comm_broken = false;
     if (c->d_ext) { (void)hipFree(c->d_ext); c->d_ext = nullptr; c->ext_cap = 0; }
     for (auto& e : c->ev_comm) if (e) { (void)hipEventDestroy(e); e = nullptr; }
 }
@@ -268,8 +289,9 @@ static int comm_events(sr_ctx* c) {
 int sr_comm_init_rank(sr_ctx* c, const uint8_t* id, size_t id_len, int rank, int nranks) {
     if (!c || nranks < 1 || rank < 0 || rank >= nranks) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET) return SR_E_INVALID;
-    sr_comm_release(c);
+    sr_device_guard restore_device;
     HIPCHK(c, hipSetDevice(c->device));
+    sr_comm_release(c);
     int rc = comm_events(c);
     if (rc != SR_OK) return rc;
     if (nranks > 1) {
@@ -292,19 +314,33 @@ int sr_comm_init_all(sr_ctx* const* ctxs, int n) {
     for (int k = 0; k < n; ++k)
         for (int j = 0; j < k; ++j)
             if (ctxs[j]->device == ctxs[k]->device) return SR_E_INVALID;  // RCCL: one rank per device
+    // All or nothing: whatever fails below, EVERY context of the set is left in the released state (rank 0 of 1, no
+    // communicator, single-device calls work as before) -- never some of them ranked and others not.
+    sr_device_guard restore_device;
     std::vector<int> devs(n);
+    auto release_all = [&]() {
+        for (int k = 0; k < n; ++k) { (void)hipSetDevice(ctxs[k]->device); sr_comm_release(ctxs[k]); }
+    };
+    release_all();
     for (int k = 0; k < n; ++k) {
-        sr_comm_release(ctxs[k]);
         devs[k] = ctxs[k]->device;
-        HIPCHK(ctxs[k], hipSetDevice(devs[k]));
-        rc = comm_events(ctxs[k]);
-        if (rc != SR_OK) return rc;
+        hipError_t e = hipSetDevice(devs[k]);
+        if (e == hipSuccess) rc = comm_events(ctxs[k]); else { (void)hipGetLastError(); ctxs[k]->last_hip = (int)e; rc = SR_E_HIP; }
+        if (rc != SR_OK) { release_all(); return rc; }
     }
     if (n > 1) {
         Rccl* R = rccl();
-        if (!R) return SR_E_COMM;
+        if (!R) { release_all(); return SR_E_COMM; }
         std::vector<ncclComm_t> comms(n, nullptr);
-        NCCLCHK(ctxs[0], R->CommInitAll(comms.data(), n, devs.data()));
+        const ncclResult_t r = R->CommInitAll(comms.data(), n, devs.data());
+        if (r != ncclSuccess) {
+            for (int k = 0; k < n; ++k) {  // RCCL may have created some of them before it failed
+                if (comms[k]) (void)R->CommAbort(comms[k]);
+                ctxs[k]->last_nccl = (int)r;
+            }
+            release_all();
+            return SR_E_COMM;
+        }
         for (int k = 0; k < n; ++k) ctxs[k]->comm = comms[k];
     }
     for (int k = 0; k < n; ++k) { ctxs[k]->comm_rank = k; ctxs[k]->comm_nranks = n; }
@@ -314,10 +350,11 @@ int sr_comm_init_all(sr_ctx* const* ctxs, int n) {
 int sr_comm_init_local(sr_ctx* const* ctxs, int n) {
     int rc = sr_check_context_set(ctxs, n);
     if (rc != SR_OK) return rc;
+    sr_device_guard restore_device;
     for (int k = 0; k < n; ++k) {
         if (ctxs[k]->graph != SR_GRAPH_SR_NET) return SR_E_INVALID;
-        sr_comm_release(ctxs[k]);
         HIPCHK(ctxs[k], hipSetDevice(ctxs[k]->device));
+        sr_comm_release(ctxs[k]);
         rc = comm_events(ctxs[k]);
         if (rc != SR_OK) return rc;
         for (int j : {k - 1, k + 1}) {  // direct xGMI access to the two neighbours (without it the copy is staged)
@@ -334,7 +371,9 @@ int sr_comm_init_local(sr_ctx* const* ctxs, int n) {
 }
 
 void sr_comm_destroy(sr_ctx* c) {
-    if (c) (void)hipSetDevice(c->device);
+    if (!c) return;
+    sr_device_guard restore_device;
+    (void)hipSetDevice(c->device);
     sr_comm_release(c);
 }
 

@@ -14,8 +14,6 @@ struct sr_ctx {
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
     size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
-    size_t off_wc[5] = {0};  // split-half column-form chunks (pack_cols)
-    bool have_cols = false, env_cols = true;
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;
@@ -45,11 +43,11 @@ struct sr_ctx {
     double total_ms = 0, stage_ms[5] = {0}, h2d_ms = 0, d2h_ms = 0;
     int last_h = 0, last_w = 0;
     int last_hip = 0;
-    // experiment switches, read once at sr_create (none changes results): SRHIP_TH, SRHIP_PIPE, SRHIP_BW
+    // experiment switches, read once at sr_create (none changes results): SRHIP_TH, SRHIP_PIPE, SRHIP_BW, SRHIP_TAIL
     int env_th[5] = {0, 0, 0, 0, 0};  // 0: automatic
-    bool env_pipe = true;
+    int env_pipe = 1;                 // 0: first form everywhere, 1: pipe form except for small launches, 2: pipe form everywhere
     int env_bw = -1;                  // tile-order column-block width in tiles (-1: automatic)
-    int env_dbg = 0;                  // StageArgs::dbg timing experiments (results invalid when non-zero)
+    float env_tail = -1.0f;           // 4-row tiles at the end of a launch, in resident workgroups (< 0: automatic 1.5, 0: none)
     int env_bands = 0;                // host pipeline: forced number of row bands (0: automatic)
     bool env_geo = true;              // host pipeline: geometric band plan where the call is compute-bound
     unsigned long long params_hash = 0;  // FNV-1a of the parameter vector: contexts of one sharded call must agree
@@ -61,6 +59,18 @@ struct sr_ctx {
     hipEvent_t ev_comm[2] = {nullptr, nullptr};
     double comm_ms = 0;
     int last_nccl = 0;
+    bool comm_broken = false;         // an exchange failed half-posted: the communicator was aborted, sharded calls return SR_E_COMM
+};
+
+// The library never leaves the calling thread on another device than it found it on: torch (and any HIP host) takes
+// "the current device" from hipGetDevice, and the one-process multi-GPU calls walk over every context's device.
+// Every extern "C" entry point that may call hipSetDevice holds one of these for its duration.
+struct sr_device_guard {
+    int saved = -1;
+    sr_device_guard() { if (hipGetDevice(&saved) != hipSuccess) { (void)hipGetLastError(); saved = -1; } }
+    ~sr_device_guard() { if (saved >= 0) (void)hipSetDevice(saved); }
+    sr_device_guard(const sr_device_guard&) = delete;
+    sr_device_guard& operator=(const sr_device_guard&) = delete;
 };
 
 #define HIPCHK(ctx, expr)                         \

@@ -29,9 +29,41 @@ struct Conv0Args {
     int tiles_x, tiles_y;
     int n_tiles;          // images * tiles_x * tiles_y; the grid may be smaller (workgroups loop over tiles)
     TileDiv div_tpi, div_tx;
-    int* queue_reset;     // the 5 x 8 tile-queue heads of this call's stage kernels: conv0 is the call's first launch and zeroes
+    int* queue_reset;     // the 5 x 8 tile-queue heads of this call's stage kernels: conv0 is the call's first launch and sets
                           // them (they are first read by stage 1, a later launch of the same stream) -- no memset node per call
+    int queue_grid[5];    // workgroups of each stage launch (entry 0 unused): head x of a stage starts at the number of its
+                          // workgroups b with b % 8 == x, whose first tile is entry b / 8 of queue x without an atomic
 };
+
+// One class of tiles of a stage launch: `tiles_y` tile rows of `th` image rows each (every tile 32 px wide), the first at
+// image row y0.  Tile ids of a class run over (image, tile row, tile column) in COLUMN-BLOCK order: blocks of `bw` tile
+// columns, each walked row by row (bw = 0: plain row-major).  Consecutive ids -- what one XCD's workgroups hold at a time --
+// then cover a few rows of one block instead of a slice of one long tile row, so the halo rows of vertically adjacent
+// tiles are still in that XCD's L2 when they are needed again (at 3840 px a tile row of one 32-channel map is 3.9 MB,
+// the L2 4 MB).  All divisions by launch constants are multiply-high forms (TileDiv).
+struct TileGrid {
+    int th, y0, tiles_y;
+    int ntiles;                        // n_img * tiles_x * tiles_y
+    TileDiv div_tpi;                   // tiles per image
+    int bw, nfull;                     // block width in tiles; number of full-width blocks (tiles_x / bw)
+    TileDiv div_tx, div_blk, div_bw, div_rem;  // divisors: tiles_x, bw * tiles_y, bw, tiles_x % bw (the last, narrower block)
+};
+inline TileGrid make_tile_grid(int th, int y0, int tiles_y, int tiles_x, int n_img, int bw) {
+    TileGrid g{};
+    g.th = th; g.y0 = y0; g.tiles_y = tiles_y; g.ntiles = n_img * tiles_x * tiles_y;
+    const TileDiv one{1u, 0u};
+    g.div_tpi = g.div_tx = g.div_blk = g.div_bw = g.div_rem = one;
+    if (tiles_y <= 0) return g;
+    g.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y));
+    g.div_tx = make_tile_div((uint32_t)tiles_x);
+    if (bw <= 0 || bw >= tiles_x) return g;  // row-major
+    g.bw = bw; g.nfull = tiles_x / bw;
+    g.div_blk = make_tile_div((uint32_t)(bw * tiles_y));
+    g.div_bw = make_tile_div((uint32_t)bw);
+    const int rem = tiles_x % bw;
+    g.div_rem = make_tile_div((uint32_t)(rem > 0 ? rem : 1));
+    return g;
+}
 
 struct StageArgs {
     const float* src[3];  // NHWC 32-channel feature maps, zero-bordered (pointer to pixel (0,0))
@@ -44,29 +76,16 @@ struct StageArgs {
     int H, W, img_ch;
     int pitch;            // feature-map row pitch in pixels (>= tiles_x*32 + 4)
     long img_stride;      // feature-map image stride in pixels
-    int y_begin, y_end;
-    int tiles_x, tiles_y;
-    int n_img;            // images in the batch (tiles = n_img * tiles_x * tiles_y)
-    TileDiv div_tpi, div_tx;  // tile id -> (image, tile row, tile column) without a hardware divide
-    int* queue;           // persistent form: 8 per-XCD tile-queue heads, zeroed before the launch
-    // Tile order inside an image: column blocks of `bw` tile columns, each walked row by row (bw = 0: plain
-    // row-major).  Consecutive tile ids -- what one XCD's workgroups hold at a time -- then cover a few rows of one
-    // block instead of a slice of one long tile row, so the halo rows of vertically adjacent tiles are still in
-    // that XCD's L2 when they are needed again (at 3840 px a tile row of one 32-channel map is 3.9 MB, the L2 4 MB).
-    int dbg;              // TIMING EXPERIMENTS ONLY (sr_set_experiment "dbg"; results are then wrong by design): bit 0 = gathers read
-                          // one contiguous KB per instruction instead of 64 pixel lines, bit 1 = no half-tile gathers at all,
-                          // bit 2 = no epilogue at all, bit 3 = (column form) no weight requests after the first two columns
-    int bw, nfull;                     // block width in tiles; number of full-width blocks (tiles_x / bw)
-    TileDiv div_blk, div_bw, div_rem;  // divisors: bw * tiles_y, bw, tiles_x % bw (the last, narrower block)
+    int y_begin, y_end;   // image rows this launch produces
+    int tiles_x;
+    int n_img;            // images in the batch
+    // The rows [y_begin, y_end) are cut into 8-row tiles (grid[0]) and, below them, 4-row tiles (grid[1]); either class
+    // may be empty.  The pipe kernel runs both in one launch, big tiles first: every XCD's queue is its run of big tiles
+    // followed by its run of small ones, so that the last tiles a launch hands out are half-size -- the spread of the
+    // workgroups' finishing times, which is what a launch loses at its end, halves.  The first kernel form runs one class.
+    TileGrid grid[2];
+    int* queue;           // persistent forms: 8 per-XCD tile-queue heads, set by conv0 (Conv0Args::queue_grid)
 };
-inline void set_tile_order(StageArgs& a, int bw) {
-    if (bw <= 0 || bw >= a.tiles_x) { a.bw = 0; a.nfull = 0; a.div_blk = a.div_bw = a.div_rem = TileDiv{1u, 0u}; return; }
-    a.bw = bw; a.nfull = a.tiles_x / bw;
-    a.div_blk = make_tile_div((uint32_t)(bw * a.tiles_y));
-    a.div_bw = make_tile_div((uint32_t)bw);
-    const int rem = a.tiles_x % bw;
-    a.div_rem = make_tile_div((uint32_t)(rem > 0 ? rem : 1));
-}
 
 // Feature maps live in HBM with a zero border so tile staging never tests bounds:
 // rows [-kFeatPad, H + kFeatPadBottom), columns [-kFeatPad, pitch - kFeatPad); kernels only
@@ -94,13 +113,10 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
 // prec: 0 = exact f32 (v_mfma_f32_32x32x2_f32), 1 = split-half (3 x v_mfma_f32_32x32x16_f16)
 hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool img_u8, hipStream_t s);
 // factor (2, 3 or 4) only matters for stage 4 (3 f^2 expand channels, depth-to-space x f)
+// first form: ONE tile class (th = 8: a.grid[0], th = 4: a.grid[1]), whole source tiles resident
 hipError_t sr_launch_stage(int stage, int factor, const StageArgs& a, int th, int prec, int nblk, bool img_u8, bool out_u8,
                            hipStream_t s);
-// "pipe" form of the stage kernels (half-tile double buffering, persistent; 8-row tiles, factor 2 / 3 only).
-// wpack must be in the pipe chunk order (sr_api.cpp pack_*_pipe); grid = co-resident workgroups.
+// "pipe" form of the stage kernels (half-tile double buffering, persistent): both tile classes of `a` in one launch;
+// grid = co-resident workgroups.
 hipError_t sr_launch_stage_pipe(int stage, int factor, const StageArgs& a, int prec, int grid, bool img_u8, bool out_u8,
                                 hipStream_t s);
-// Column form of the split-half stage kernels (conv_stage_col_kernel): one kernel COLUMN of one 16-channel half per barrier
-// (30 / 18 MFMAs per wave), operands of the next column read from LDS under the MFMAs of this one, weights through a ring of
-// ten 2 KB tap slots (waves 0-1 request them, waves 2-3 request the half-tile gathers).  wpack: sr_api.cpp pack_cols.
-hipError_t sr_launch_stage_cols(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s);

@@ -30,10 +30,11 @@
 //  * weights are pre-packed on the host into 4 KB chunks, one per STEP (two taps x 16 input channels), in the
 //    exact order the B-operand ds_read_b128 wants, and streamed by LDS-DMA through a 5-slot ring four steps
 //    ahead of use, one barrier per step;
-//  * stages 1-4 come in two forms that share the matrix loops, the step order and the weight chunks and are
-//    bit-identical: the PIPE form (conv_stage_pipe_kernel: half tiles double-buffered in LDS, gather DMA of
-//    the next half / the next tile's first half spread under the current half's MFMAs, persistent) for 8-row
-//    tiles, and the FIRST form (conv_stage_kernel: whole source tile resident) for small images (4-row tiles);
+//  * stages 1-4 run the PIPE form (conv_stage_pipe_kernel: half tiles double-buffered in LDS, gather DMA of the
+//    next half / the next tile's first half spread under the current half's MFMAs, persistent, 8-row tiles and,
+//    at the end of every XCD's queue, 4-row tiles).  The FIRST form (conv_stage_kernel: whole source tile
+//    resident, one tile class per launch) shares the matrix loops, the step order and the weight chunks, is
+//    bit-identical, and is kept as the in-library cross-check (sr_set_experiment "pipe" = "none");
 //  * LDS per workgroup 76-78 KB -> 2 workgroups per CU;
 //  * a second arithmetic mode (split-half: activations and weights as hi + lo/2048 half pairs, three
 //    v_mfma_f32_32x32x16_f16 per product, f32 accumulation) runs the same structure on the f16 matrix cores;
@@ -59,47 +60,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// Optional per-workgroup phase timestamps for scripts/timeline.hip (never compiled
-// into the product library).
-#ifdef SR_TIMELINE
-// Slots per workgroup: 0 wall clock at the first tile, 1..8 phase stamps (s_memtime) SUMMED over the tiles the
-// workgroup processed, relative to each tile's stamp 1 (so slot[k1] - slot[k0] = total time between the two
-// marks); 9 wall clock at the end, 10 where it ran (XCC_ID << 32 | HW_ID), 11 wall clock at kernel entry,
-// 12 tiles processed.
-__device__ long long* g_tl;
-#define TL_DECL() long long tl_s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tl_n = 0
-#define TL(k) do { if ((k) == 0) { if (tl_n == 0 && threadIdx.x == 0) g_tl[(size_t)blockIdx.x * 16] = (long long)wall_clock64(); } \
-    else { tl_s[(k)] = (long long)__builtin_readcyclecounter(); \
-           if ((k) == 7) { for (int j_ = 1; j_ < 9; ++j_) tl_c[j_] += tl_s[j_] - tl_s[1]; ++tl_n; } } } while (0)
-#define TL_BEGIN() do { if (threadIdx.x == 0) g_tl[(size_t)blockIdx.x * 16 + 11] = (long long)wall_clock64(); } while (0)
-#define TL_END() do { if (threadIdx.x == 0) { g_tl[(size_t)blockIdx.x * 16 + 9] = (long long)wall_clock64(); \
-    g_tl[(size_t)blockIdx.x * 16 + 10] = ((long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32) | \
-        (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); \
-    for (int j_ = 1; j_ < 9; ++j_) g_tl[(size_t)blockIdx.x * 16 + j_] = tl_c[j_]; g_tl[(size_t)blockIdx.x * 16 + 12] = tl_n; } } while (0)
-#else
-#define TL_DECL() do {} while (0)
-#define TL(k) do {} while (0)
-#define TL_BEGIN() do {} while (0)
-#define TL_END() do {} while (0)
-#endif
-
 namespace {
 
 constexpr int kThreads = 256;
-#ifndef SR_SPLIT_WAVES
-#define SR_SPLIT_WAVES 4
-#endif
-// Timing experiments that BREAK the results on purpose (StageArgs::dbg, scripts/dbg_exp.py, scripts/pmc_quick.sh) exist only in
-// builds with -DSR_EXPERIMENTS (scripts/build_variant.sh dbg -DSR_EXPERIMENTS): in the product every one of these tests is a
-// compile-time false -- a wave-uniform branch per MFMA slot is not free (measured: the column loop lost 10 % to them).
-#ifdef SR_EXPERIMENTS
-#define SR_DBG(a, bit) (((a).dbg & (bit)) != 0)
-#else
-#define SR_DBG(a, bit) false
-#endif
-#ifndef SR_SPLIT_INTERLEAVE
-#define SR_SPLIT_INTERLEAVE 1  // split-half step loop: operand reads / DMA requests interleaved 1:1 with the MFMAs (0: all in front)
-#endif
 constexpr int kTW = 32;            // tile width = one MFMA M-tile of pixels
 constexpr int kChunkFloats = 1024; // one tap: 32 cin x 32 cout
 constexpr int kRingSlots = 5;      // 4 KB weight chunks: one being read, up to four in flight
@@ -149,22 +112,22 @@ __device__ __forceinline__ int tile_div(int t, TileDiv d) {  // see make_tile_di
     return (int)((__umulhi((uint32_t)t, d.m) + (uint32_t)t) >> d.s);
 }
 
-// Tile id within the launch -> (image, tile column, tile row): see StageArgs::bw.  Scalar ALU only.
-__device__ __forceinline__ void tile_coords(const StageArgs& a, int t, int& n, int& tx, int& ty) {
-    const int tpi = a.tiles_x * a.tiles_y;
-    n = tile_div(t, a.div_tpi);
+// Tile id within a tile class -> (image, tile column, tile row): see TileGrid.  Scalar ALU only.
+__device__ __forceinline__ void tile_coords(const TileGrid& g, int tiles_x, int t, int& n, int& tx, int& ty) {
+    const int tpi = tiles_x * g.tiles_y;
+    n = tile_div(t, g.div_tpi);
     const int r = t - n * tpi;
-    if (a.bw == 0) {
-        ty = tile_div(r, a.div_tx);
-        tx = r - ty * a.tiles_x;
+    if (g.bw == 0) {
+        ty = tile_div(r, g.div_tx);
+        tx = r - ty * tiles_x;
     } else {
-        int b = tile_div(r, a.div_blk);
-        if (b > a.nfull) b = a.nfull;
-        const int rr = r - b * a.bw * a.tiles_y;
-        const bool full = b < a.nfull;
-        const int w = full ? a.bw : a.tiles_x - a.nfull * a.bw;
-        ty = full ? tile_div(rr, a.div_bw) : tile_div(rr, a.div_rem);
-        tx = b * a.bw + (rr - ty * w);
+        int b = tile_div(r, g.div_blk);
+        if (b > g.nfull) b = g.nfull;
+        const int rr = r - b * g.bw * g.tiles_y;
+        const bool full = b < g.nfull;
+        const int w = full ? g.bw : tiles_x - g.nfull * g.bw;
+        ty = full ? tile_div(rr, g.div_bw) : tile_div(rr, g.div_rem);
+        tx = b * g.bw + (rr - ty * w);
     }
 }
 
@@ -272,7 +235,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     // tile -> XCD mapping does not matter here (measured: no change in kernel time either way)
     for (int k = tid; k < 5 * 8 * 64; k += kThreads) s_w[k] = a.wpack[k];
     if (tid < 16) s_x[NPIX * 3 + tid] = 0.f;
-    if (blockIdx.x == 0 && tid < 40) a.queue_reset[tid] = 0;  // visible to the later launches by stream order
+    // the tile-queue heads of this call's four stage kernels: entry b / 8 of queue b % 8 belongs to workgroup b of that launch
+    // without asking (queue_first), so a head starts at the number of such workgroups; visible to the later launches by stream order
+    if (blockIdx.x == 0 && tid < 40) a.queue_reset[tid] = (a.queue_grid[tid >> 3] - (tid & 7) + 7) >> 3;
     // img_to_data (main.rs:170) is u8 / 255 with a true division; one table entry per byte value replaces
     // ~10 VALU instructions per sample (the f32 MFMA shares the vector ALU)
     __shared__ float s_lut[256];
@@ -653,7 +618,6 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
 #pragma unroll
       for (int nt = 0; nt < NTN; ++nt) {
         const bool last = p == NP - 1 && nt == NTN - 1;
-#if SR_SPLIT_INTERLEAVE
         // Two waves share a SIMD's matrix pipe.  With all of a step's operand reads and DMA requests in front of its
         // 12 MFMAs the two fall into lockstep (both read, then both multiply) and the pipe idles through every read
         // phase.  So each wave keeps the pipe busy on its own: one operand read of the NEXT step (or one DMA request)
@@ -686,25 +650,6 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
                 for (int m = 0; m < 3 * T; ++m) after_mfma();
             }
         }
-#else
-        sm.begin_step();
-        // (with two N-tiles the same taps run again on the next chunk: everything is found in `cur`)
-        if (!last) load(nxt, cur, p, nt + 1 < NTN ? p : p + 1, sm.slot() == kRingSlots - 1 ? 0 : sm.slot() + 1);
-        if (nt == 0) { sm.piece(2 * p); sm.piece(2 * p + 1); }  // two gather instructions per step
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ts = 0; ts < 2; ++ts) {
-            if (2 * p + ts < NT) {
-#pragma unroll
-                for (int m = 0; m < T; ++m) accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bh[ts], accm[nt * T + m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bl[ts], accx[nt * T + m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < T; ++m) accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[ts][m], cur.bh[ts], accx[nt * T + m], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         sm.template end_step<1>(last);
         cur = nxt;
       }
@@ -878,45 +823,45 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
     }
 }
 
-// Dynamic tile queue for the persistent form.  The tiles are cut into 8 contiguous
-// runs, one per XCD (the dispatcher places block b on XCD b % 8: neighbouring tiles
-// share halo rows in that XCD's L2); each run has a head counter in HBM (zeroed by
-// the host before the launch).  A workgroup pulls from its own XCD's run and, once
-// that is exhausted, steals from the others.
+// Dynamic tile queue of the persistent forms.  A launch has `nbig` 8-row tiles and `nsmall` 4-row tiles (either may be
+// 0).  Each class is cut into 8 contiguous runs, one per XCD (the dispatcher places block b on XCD b % 8: neighbouring
+// tiles share halo rows in that XCD's L2); an XCD's queue is its run of big tiles followed by its run of small ones, with
+// one head counter in HBM (zeroed before the launch).  A workgroup pulls from its own XCD's queue and, once that is
+// exhausted, steals from the others.  Returned: a big tile's id t as t, a small tile's as nbig + t, -1 when all is gone.
 __device__ __forceinline__ void run_of_xcd(int x, int ntiles, int& start, int& count) {
     const int q = ntiles >> 3, r = ntiles & 7;
     count = q + (x < r ? 1 : 0);
     start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
 }
-__device__ __forceinline__ int queue_resolve(int* queue, int xcd, int ntiles, int idx) {
+__device__ __forceinline__ int queue_slot(int x, int nbig, int nsmall, int idx) {
     int start, count;
-    run_of_xcd(xcd, ntiles, start, count);
+    run_of_xcd(x, nbig, start, count);
     if (idx < count) return start + idx;
-    for (int k = 1; k < 8; ++k) {  // steal (tail of the launch only)
-        const int x = (xcd + k) & 7;
-        run_of_xcd(x, ntiles, start, count);
-        const int j = atomicAdd(&queue[x], 1);
-        if (j < count) return start + j;
-    }
-    return -1;
+    idx -= count;
+    run_of_xcd(x, nsmall, start, count);
+    return idx < count ? nbig + start + idx : -1;
 }
-
-// PERSIST = false: one workgroup per tile (grid = tiles, XCD-remapped).  Best for the
-// exact-f32 mode, where a tile lasts ~45 us and persistent forms measured 4 % slower.
-// PERSIST = true: grid = co-resident workgroups, tiles pulled from the queue, and the
-// next tile's DMA is requested before the current tile's epilogue.  Best for the
-// split-half mode, whose tiles last ~14 us: with one tile per workgroup 30 % of the
-// workgroup slots sat empty between a retire and the next dispatch.
-template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, bool PERSIST, int NW, int FACTOR = 3>
-__global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv_stage_kernel(StageArgs a) {
-    TL_BEGIN();
-    TL_DECL();
+__device__ __forceinline__ int queue_total(int x, int nbig, int nsmall) {
+    int start, cb, cs;
+    run_of_xcd(x, nbig, start, cb);
+    run_of_xcd(x, nsmall, start, cs);
+    return cb + cs;
+}
+// Workgroup b's FIRST tile needs no atomic: it is entry b / 8 of queue b % 8, and the heads start at the number of
+// workgroups that own such an entry (conv0, the call's first launch, writes them: Conv0Args::queue_grid).
+__device__ __forceinline__ int queue_first(int block, int nbig, int nsmall) { return queue_slot(block & 7, nbig, nsmall, block >> 3); }
+// First form of the stage kernels: ONE workgroup per tile (grid = tiles of one class, XCD-remapped), the whole source
+// tile resident in LDS, sources staged one after the other.  It is what small launches of the exact-f32 mode run (no
+// queue, nothing to amortise: 256x256 is one round of 4-row tiles) and the in-library cross-check of the pipe form
+// (sr_set_experiment "pipe" = "none"): same matrix loops, same step order, same weight chunks, bit-identical results.
+template <int TH, int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, int FACTOR = 3>
+__global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
     // Two workgroups share each SIMD.  A wave streaming MFMAs is the older one and wins every
     // arbitration, leaving the other workgroup's prologue / staging / epilogue code roughly one
     // issue slot per MFMA.  The matrix stream only needs one slot per 64 cycles, so everything
     // that is not the tap loop runs at raised priority -- from the first instruction on.
     __builtin_amdgcn_s_setprio(3);
-    constexpr int T = TH / NW;  // tile rows per wave
+    constexpr int NW = 4, T = TH / NW;  // tile rows per wave
     // The final stage has 3 f^2 expand channels (network.rs:37).  They are laid out in whole RGB
     // triples, 10 per 32-lane N-tile (so the u8 packing never straddles tiles): f = 2, 3 -> 1 tile,
     // f = 4 -> 16 triples -> 2 tiles.
@@ -925,15 +870,12 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* tile = smem;
     char* ring = smem + 8 * G0::PLANE;  // KS0 >= 3: the first source has the largest tile
-    volatile int* s_next = (volatile int*)(ring + kRingBytes);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31;
     constexpr int NTAPS = 2 * ((KS0 * KS0 + 1) / 2 + (NSRC - 1) * 5) * NTN;  // ring chunks: one per (step, N-tile), see half_steps_*
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int ntiles = tiles_per_img * a.n_img;
-    const int xcd = blockIdx.x & 7;
+    const TileGrid& grid = a.grid[TH == 8 ? 0 : 1];  // this form runs one tile class per launch
     float bias[NTN];
 #pragma unroll
     for (int nt = 0; nt < NTN; ++nt) bias[nt] = a.bias[nt * 32 + i];
@@ -943,89 +885,48 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
     TileOffsets<TH, 3, NW> off3;
     off0.init(a.pitch, wave, lane);
     if constexpr (NSRC >= 2) off3.init(a.pitch, wave, lane);
-    // request everything the first phase of tile `t` needs: weight chunks 0..3 and the first source tile
-    int n = 0, x0 = 0, y0 = 0;
-    auto request_tile = [&](int t) {
-        int tx, ty;
-        tile_coords(a, t, n, tx, ty);
-        x0 = tx * kTW; y0 = a.y_begin + ty * TH;
+    // everything the first phase needs: weight chunks 0..3 and the first source tile
+    int n, tx, ty;
+    tile_coords(grid, a.tiles_x, xcd_remap(blockIdx.x, gridDim.x), n, tx, ty);
+    const int x0 = tx * kTW, y0 = grid.y0 + ty * TH;
 #pragma unroll
-        for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
-        stage_tile<TH, KS0, NW>(tile, a.src[0], off0, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+    for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
+    stage_tile<TH, KS0, NW>(tile, a.src[0], off0, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+
+    f32x16 acc[NTN * T], accx[PREC == 1 ? NTN * T : 1];  // accx: the cross products of the split-half mode, x2048
+#pragma unroll
+    for (int m = 0; m < NTN * T; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[m][r] = 0.f;
+            if constexpr (PREC == 1) accx[m][r] = 0.f;
+        }
+    int gtap = 0, slot = 0;
+    auto taps = [&](auto ks_tag) {
+        constexpr int KS = decltype(ks_tag)::value;
+        source_steps<TH, KS, T, NTN, PREC>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
     };
-
-    int cur;
-    if constexpr (PERSIST) {
-        if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
-        __syncthreads();
-        cur = __builtin_amdgcn_readfirstlane(*s_next);  // uniform by construction; tells the compiler so (SGPR tile coordinates)
-        if (cur < 0) return;
-    } else {
-        cur = xcd_remap(blockIdx.x, gridDim.x);
-    }
-    request_tile(cur);
-
-    while (true) {
-        const int tn = n, tx0 = x0, ty0 = y0;  // this tile (request_tile below overwrites n, x0, y0)
-        f32x16 acc[NTN * T], accx[PREC == 1 ? NTN * T : 1];  // accx: the cross products of the split-half mode, x2048
-#pragma unroll
-        for (int m = 0; m < NTN * T; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[m][r] = 0.f;
-                if constexpr (PREC == 1) accx[m][r] = 0.f;
-            }
-        int gtap = 0, slot = 0;
-        auto taps = [&](auto ks_tag) {
-            constexpr int KS = decltype(ks_tag)::value;
-            source_steps<TH, KS, T, NTN, PREC>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
-        };
-        TL(0); TL(1);
-        ring_barrier<0>();  // every wave's tile + weight DMAs (and earlier stores) have landed
-        int pulled = 0;     // ask for the next tile now; the answer is looked at after this source's taps
-        if constexpr (PERSIST) { if (tid == 0) pulled = atomicAdd(&a.queue[xcd], 1); }
-        __builtin_amdgcn_s_setprio(0);
-        TL(2);
-        taps(std::integral_constant<int, KS0>{});
-        if constexpr (PERSIST) { if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, pulled); }
-        TL(3);
-        if constexpr (NSRC >= 2) {
-            __builtin_amdgcn_s_setprio(3);
-            stage_tile<TH, 3, NW>(tile, a.src[1], off3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
-            ring_barrier<0>();
-            __builtin_amdgcn_s_setprio(0);
-            TL(4);
-            taps(std::integral_constant<int, 3>{});
-            TL(5);
-        }
-        if constexpr (NSRC >= 3) {
-            __builtin_amdgcn_s_setprio(3);
-            stage_tile<TH, 3, NW>(tile, a.src[2], off3, a.img_stride, a.pitch, tn, ty0, tx0, wave, lane);
-            ring_barrier<0>();
-            __builtin_amdgcn_s_setprio(0);
-            taps(std::integral_constant<int, 3>{});
-        }
+    ring_barrier<0>();  // every wave's tile + weight DMAs have landed
+    __builtin_amdgcn_s_setprio(0);
+    taps(std::integral_constant<int, KS0>{});
+    if constexpr (NSRC >= 2) {
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (FINAL) {
-            lin_taps<TH, T, IMG_U8, NW * 64, NTN>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, tn, ty0, tx0, wave, lane, tid);
-            if constexpr (PERSIST) __syncthreads();  // everybody is done reading the image tile / lin weights
-        }
-        TL(6);
-        bool more_tiles = false;
-        if constexpr (PERSIST) {
-            // the LDS tile and ring are free (last tap's barrier): request the next tile's
-            // weights and first source NOW so the DMA runs under this tile's epilogue
-            if constexpr (NSRC == 1 && !FINAL) __syncthreads();  // publish s_next (later sources' barriers do it otherwise)
-            cur = __builtin_amdgcn_readfirstlane(*s_next);
-            more_tiles = cur >= 0;
-            if (more_tiles) request_tile(cur);
-        }
-        TL(8);
-        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, tn, tx0, ty0, wave, lane);
-        TL(7);
-        if (!more_tiles) break;
+        stage_tile<TH, 3, NW>(tile, a.src[1], off3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+        ring_barrier<0>();
+        __builtin_amdgcn_s_setprio(0);
+        taps(std::integral_constant<int, 3>{});
     }
-    TL_END();
+    if constexpr (NSRC >= 3) {
+        __builtin_amdgcn_s_setprio(3);
+        stage_tile<TH, 3, NW>(tile, a.src[2], off3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+        ring_barrier<0>();
+        __builtin_amdgcn_s_setprio(0);
+        taps(std::integral_constant<int, 3>{});
+    }
+    __builtin_amdgcn_s_setprio(3);
+    if constexpr (FINAL)
+        lin_taps<TH, T, IMG_U8, NW * 64, NTN>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
+    stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1035,7 +936,14 @@ __global__ __launch_bounds__(NW * 64, TH == 8 ? (NW == 8 ? 4 : 2) : 3) void conv
 // but the epilogue is left outside the matrix stream: no staging waits between sources, no prologue per
 // tile (persistent workgroups, tiles from the per-XCD queue).  A step = two taps of one half = one 4 KB
 // weight chunk = 32 f32 / 12 f16 MFMAs per wave, same size as a whole tap of the first form.
-// 8-row tiles, 4 waves; 4-row tiles (small images) run the first form.
+//
+// One launch runs BOTH tile classes of StageArgs: 8-row tiles (two tile rows per wave) and, after them in every
+// XCD's queue, 4-row tiles (one row per wave).  What a launch loses at its end is the spread of its workgroups'
+// finishing times -- measured on MI355X (profiles/r3_band_profile_baseline_*.jsonl): half a tile time per launch,
+// 35-50 us for the 5x5 stages whatever the image size -- so the last tiles handed out are half-size.  A small tile
+// lives in the first rows of the same LDS buffers (same plane stride, same row pitch TWH: its pixel p sits where the
+// big tile's pixel p does), so the two tile bodies differ in nothing but T, the rows per wave, and the number of
+// gather groups requested; both sum in the same order as the first form, so all forms stay bit-identical.
 // ---------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier(int pending) {  // s_waitcnt vmcnt(pending) lgkmcnt(0); s_barrier
@@ -1051,9 +959,11 @@ __device__ __forceinline__ void wait_vm_barrier(int pending) {  // s_waitcnt vmc
 
 template <int KS>
 struct HalfTile {
-    using G = TileGeom<8, KS>;
+    using G = TileGeom<8, KS>;                           // LDS geometry: always that of the 8-row tile
+    static constexpr int NG_SMALL = TileGeom<4, KS>::NG; // gather groups that cover a 4-row tile (+halo)
     static constexpr int BYTES = 4 * G::PLANE;
     static constexpr int STEPS = (KS * KS + 1) / 2;
+    static_assert(TileGeom<4, KS>::TWH == G::TWH, "a small tile is the top of a big one");
     uint32_t off[G::NG];  // gather offset of tile pixel 64 g + lane (same for every wave: wave w moves plane w)
     __device__ __forceinline__ void init(int pitch, int lane) {
 #pragma unroll
@@ -1063,31 +973,28 @@ struct HalfTile {
             off[g] = (uint32_t)(prow * pitch + pcol) * 128u;
         }
     }
+    // 16-byte channel group wave `wave` moves for half `khalf`: f32 map = 8 groups of 4 channels; split map = 4 groups of
+    // hi halves then 4 of lo halves (8 channels each)
+    template <int PREC>
+    static __device__ __forceinline__ int chunk_of(int khalf, int wave) {
+        return PREC == 0 ? 4 * khalf + wave : (wave < 2 ? 2 * khalf + wave : 4 + 2 * khalf + (wave - 2));
+    }
     // request half `khalf` of the tile at (n, y0, x0) of `src` into the LDS buffer `buf`: G::NG DMAs per wave
-    template <int PREC, int G0 = 0, int G1 = G::NG>
+    template <int PREC>
     __device__ __forceinline__ void stage(uint32_t buf, const float* __restrict__ src, int khalf, long img_stride, int pitch,
                                           int n, int y0, int x0, int wave) const {
-        // 16-byte channel group this wave moves: f32 map = 8 groups of 4 channels; split map = 4 groups of hi
-        // halves then 4 of lo halves (8 channels each)
-        const int chunk = PREC == 0 ? 4 * khalf + wave : (wave < 2 ? 2 * khalf + wave : 4 + 2 * khalf + (wave - 2));
-        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) + chunk * 16);
+        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) +
+                                         chunk_of<PREC>(khalf, wave) * 16);
         const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + wave * G::PLANE);
 #pragma unroll
-        for (int g = G0; g < G1 && g < G::NG; ++g) lds_dma16<0>(origin, off[g], dst + g * 1024);
-    }
-    // the same for an explicit LDS plane of the split-half map (0, 1: hi halves of channel groups 2 khalf, 2 khalf + 1; 2, 3: lo)
-    __device__ __forceinline__ void stage_plane(int g, int plane, uint32_t buf, const float* __restrict__ src, int khalf, long img_stride,
-                                                int pitch, int n, int y0, int x0) const {
-        const int chunk = plane < 2 ? 2 * khalf + plane : 4 + 2 * khalf + (plane - 2);
-        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) + chunk * 16);
-        lds_dma16<0>(origin, off[g], __builtin_amdgcn_readfirstlane(buf + plane * G::PLANE + g * 1024));
+        for (int g = 0; g < G::NG; ++g) lds_dma16<0>(origin, off[g], dst + g * 1024);
     }
     // one gather instruction of that request: pixel group g (64 tile pixels) of this wave's plane
     template <int PREC>
     __device__ __forceinline__ void stage_one(int g, uint32_t buf, const float* __restrict__ src, int khalf, long img_stride,
                                               int pitch, int n, int y0, int x0, int wave) const {
-        const int chunk = PREC == 0 ? 4 * khalf + wave : (wave < 2 ? 2 * khalf + wave : 4 + 2 * khalf + (wave - 2));
-        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) + chunk * 16);
+        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) +
+                                         chunk_of<PREC>(khalf, wave) * 16);
         lds_dma16<0>(origin, off[g], __builtin_amdgcn_readfirstlane(buf + wave * G::PLANE + g * 1024));
     }
 };
@@ -1124,8 +1031,7 @@ __device__ __forceinline__ void step_request(StepStream& st, char* ring, const f
     }
     st.q[kRingAhead - 1] = st.issued;  // nothing requested: nothing newer to wait for either
 }
-// End of a step: chunk gs + EXTRA (numbered after the shift in step_request: q[EXTRA - 1 + 1]...) -- see below.
-// On return chunk gs + 1 + EXTRA has landed; with `tile` also every half-tile DMA issued so far.
+// End of a step.  On return chunk gs + 1 + EXTRA has landed; with `tile` also every half-tile DMA issued so far.
 template <int EXTRA>
 __device__ __forceinline__ void step_advance(StepStream& st, bool tile) {
     // after this step's step_request, q[k] is the request of chunk gs + 1 + k
@@ -1136,15 +1042,14 @@ __device__ __forceinline__ void step_advance(StepStream& st, bool tile) {
     st.slot = st.slot == kRingSlots - 1 ? 0 : st.slot + 1;
 }
 
-// What a half's steps should request on the side: half `khalf` of the tile at (n, y0, x0) of `src` into `buf`,
-// two gather instructions per step.  active = false: nothing (last half of the last tile).
+// What a half's steps should request on the side: the first `ng` gather groups of half `khalf` of the tile at
+// (n, y0, x0) of `src` into `buf`.  ng = 0: nothing (last half of the last tile).
 struct HalfRequest {
-    bool active;
+    int ng;
     uint32_t buf;
     const float* src;
     int khalf, n, y0, x0;
 };
-
 
 __device__ __forceinline__ void wait_vm(int pending) {  // s_waitcnt vmcnt(pending), pending any value (>= 16: waits for all)
     switch (pending) {
@@ -1156,19 +1061,19 @@ __device__ __forceinline__ void wait_vm(int pending) {  // s_waitcnt vmcnt(pendi
     }
 }
 
-// Final stage of the pipe form: the input pixels the bilinear taps need (a (8+2) x (32+2) tile, edge-replicated
+// Final stage of the pipe form: the input pixels the bilinear taps need (a (TH+2) x (32+2) tile, edge-replicated
 // coordinates: LinearInterp clamps indices) are requested at the start of the tile's LAST half and parked in
 // registers, so that their latency runs under that half's matrix work.  Inline-asm loads: the compiler would
 // otherwise wait for them with vmcnt(0), i.e. for every DMA of the next tile too; here the wait is numbered like
-// all the others (StepStream).  Every thread loads two pixels (the second one clamped when it has none).
-template <bool IMG_U8>
+// all the others (StepStream).  A thread loads up to two pixels (an 8-row tile has 340, a 4-row tile 204).
+template <bool IMG_U8, int TH>
 struct LinPrefetch {
-    static constexpr int TWH = kTW + 2, THH = 8 + 2, NPIX = THH * TWH;
-    uint32_t raw[2][3];
+    static constexpr int TWH = kTW + 2, THH = TH + 2, NPIX = THH * TWH, PER = (NPIX + 255) / 256;
+    uint32_t raw[PER][3];
     int seq;
     __device__ __forceinline__ void issue(const StageArgs& a, int n, int y0, int x0, int tid, StepStream& st) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int p = min(tid + 256 * k, NPIX - 1);
             const int py = p / TWH, px = p - py * TWH;
             const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
@@ -1185,14 +1090,14 @@ struct LinPrefetch {
                 asm volatile("global_load_dword %0, %1, off offset:8" : "=v"(raw[k][2]) : "v"(q) : "memory");
             }
         }
-        st.issued += 6;
+        st.issued += 3 * PER;
         seq = st.issued;
     }
     // wait for the pixels, convert (img_to_data: u8 / 255, true division) and write the [pixel][4] tile
     __device__ __forceinline__ void store(float* s_x, int tid, const StepStream& st) {
         wait_vm(st.issued - seq);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int p = tid + 256 * k;
             if (p < NPIX) {
                 f32x4 v;
@@ -1208,8 +1113,58 @@ struct LinPrefetch {
     }
 };
 
+// A workgroup's dealings with the tile queue, kept out of the matrix stream's way.  HIP's atomicAdd() is followed at once
+// by s_waitcnt vmcnt(0) (the compiler needs the value for its cross-lane combining) -- at the start of every tile that
+// drained the weight ring and parked wave 0 for a memory round trip while the other waves waited at the first barrier.
+// Here the next tile's index is requested by ONE inline-asm returning atomic at the tile's start, numbered like every
+// other request (StepStream), and looked at three steps before half 0 ends, when it has long returned.  Only when this
+// XCD's queue has run dry does wave 0 read all eight heads (one load, lanes 0-7) and, at the end of the half, try those
+// queues that still showed tiles: the tail of a launch costs no round of seven failing atomics per workgroup.
+struct QueueState {      // meaningful in wave 0
+    uint32_t pulled;     // lane 0: what the atomic on this XCD's head returned
+    uint32_t heads;      // lanes 0-7: snapshot of the eight heads
+    int seq_pull, seq_snap;
+    int own;             // the tile `pulled` stands for, -1: this XCD's queue is exhausted
+};
+__device__ __forceinline__ void queue_pull_async(const StageArgs& a, int xcd, int wave, int lane, StepStream& st, QueueState& qs) {
+    if (wave != 0) return;
+    if (lane == 0) {
+        const int* p = a.queue + xcd;
+        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(qs.pulled) : "v"(p), "v"(1u) : "memory");
+    }
+    qs.seq_pull = ++st.issued;
+}
+__device__ __forceinline__ void queue_presolve(const StageArgs& a, int xcd, int wave, int lane, StepStream& st, QueueState& qs) {
+    if (wave != 0) return;
+    wait_vm(st.issued - qs.seq_pull);
+    const int idx = __builtin_amdgcn_readfirstlane((int)qs.pulled);
+    qs.own = queue_slot(xcd, a.grid[0].ntiles, a.grid[1].ntiles, idx);
+    if (qs.own < 0) {
+        const int* p = a.queue + (lane & 7);
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(qs.heads) : "v"(p) : "memory");
+        qs.seq_snap = ++st.issued;
+    }
+}
+// the next tile's number (or -1) into the mailbox; called before the barrier that ends half 0
+__device__ __forceinline__ void queue_publish(const StageArgs& a, int xcd, int wave, int lane, StepStream& st, QueueState& qs, volatile int* mailbox) {
+    if (wave != 0) return;
+    int t = qs.own;
+    if (t < 0) {
+        const int nbig = a.grid[0].ntiles, nsmall = a.grid[1].ntiles;
+        wait_vm(st.issued - qs.seq_snap);
+        for (int k = 1; k < 8 && t < 0; ++k) {
+            const int x = (xcd + k) & 7;
+            if ((int)__builtin_amdgcn_readlane((int)qs.heads, x) >= queue_total(x, nbig, nsmall)) continue;  // heads only grow: nothing there
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&a.queue[x], 1);
+            t = queue_slot(x, nbig, nsmall, __builtin_amdgcn_readfirstlane(j));
+        }
+    }
+    if (lane == 0) *mailbox = t;
+}
+
 // Stream of the pipe form: chunks through the ring with sequence-numbered waits, plus a piece of the next half
-// tile in each of the first four steps; the first half of a tile also publishes the next tile's number.
+// tile in each of the first steps; the first half of a tile also publishes the next tile's number.
 template <int PREC, int KSN>
 struct PipeStream {
     StepStream& st;
@@ -1218,29 +1173,35 @@ struct PipeStream {
     const StageArgs& a;
     char* ring;
     int wave, lane;
-    volatile int* mailbox;  // non-null: write queue_resolve(...) there before the last step's barrier
-    int xcd, ntiles, pulled;
-    __device__ __forceinline__ void begin_step() { step_request(st, ring, a.wpack, wave, lane); }
-    // gather instruction number g of the half tile being requested (compile-time after unrolling)
+    volatile int* mailbox;  // non-null (half 0): the next tile's number goes there before the last step's barrier
+    int xcd;
+    QueueState& qs;
+    int snap_step;          // half 0: the step at which the queue's answer is looked at
+    int step_no;
+    __device__ __forceinline__ void begin_step() {
+        step_request(st, ring, a.wpack, wave, lane);
+        if (mailbox) {
+            if (step_no == snap_step) queue_presolve(a, xcd, wave, lane, st, qs);
+            ++step_no;
+        }
+    }
+    // gather instruction number g of the half tile being requested (g compile-time after unrolling)
     __device__ __forceinline__ void piece(int g) {
-        if (g < HalfTile<KSN>::G::NG && rq.active && !SR_DBG(a, 2)) {
+        if (g < HalfTile<KSN>::G::NG && g < rq.ng) {
             htn.template stage_one<PREC>(g, rq.buf, rq.src, rq.khalf, a.img_stride, a.pitch, rq.n, rq.y0, rq.x0, wave);
             st.tile_seq = ++st.issued;
         }
     }
     __device__ __forceinline__ int slot() const { return st.slot; }
     template <int EXTRA> __device__ __forceinline__ void end_step(bool last) {
-        if (last && mailbox && threadIdx.x == 0) *mailbox = queue_resolve(a.queue, xcd, ntiles, pulled);
+        if (last && mailbox) queue_publish(a, xcd, wave, lane, st, qs, mailbox);
         step_advance<EXTRA>(st, last);
     }
 };
 
 template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, int FACTOR = 3>
 __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
-    TL_BEGIN();
-    TL_DECL();
     __builtin_amdgcn_s_setprio(3);
-    constexpr int TH = 8, T = 2;
     constexpr int NTN = FINAL ? (FACTOR * FACTOR + 9) / 10 : 1;  // N-tiles of the node (expand at factor 4: 48 channels = 2)
     using H0 = HalfTile<KS0>;
     using H3 = HalfTile<3>;
@@ -1256,8 +1217,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31;
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int ntiles = tiles_per_img * a.n_img;
+    const int nbig = a.grid[0].ntiles, nsmall = a.grid[1].ntiles;
     const int xcd = blockIdx.x & 7;
     float bias[NTN];
 #pragma unroll
@@ -1267,32 +1227,30 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     H3 h3;
     h0.init(a.pitch, lane);
     if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
-    if (SR_DBG(a, 1)) {  // timing experiment: what would contiguous gathers cost?
-#pragma unroll
-        for (int g = 0; g < H0::G::NG; ++g) h0.off[g] = (uint32_t)(g * 64 + lane) * 16u;
-        if constexpr (NSRC >= 2) {
-#pragma unroll
-            for (int g = 0; g < H3::G::NG; ++g) h3.off[g] = (uint32_t)(g * 64 + lane) * 16u;
-        }
-    }
 
-    auto coords = [&](int t, int& n, int& x0, int& y0) {
+    // combined tile id (queue_resolve) -> image, tile origin, tile class
+    auto coords = [&](int t, int& n, int& x0, int& y0, bool& small) {
         int tx, ty;
-        tile_coords(a, t, n, tx, ty);
-        x0 = tx * kTW; y0 = a.y_begin + ty * TH;
+        small = t >= nbig;
+        if (small) {
+            tile_coords(a.grid[1], a.tiles_x, t - nbig, n, tx, ty);
+            y0 = a.grid[1].y0 + ty * 4;
+        } else {
+            tile_coords(a.grid[0], a.tiles_x, t, n, tx, ty);
+            y0 = a.grid[0].y0 + ty * 8;
+        }
+        x0 = tx * kTW;
     };
 
-    if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
-    if constexpr (FINAL) {
+    if constexpr (FINAL) {  // (read after the tile's steps, many barriers later)
         const float* wlin = a.wpack + (size_t)NSTEPS * kChunkFloats;
         for (int k = tid; k < 9 * NTN * 128; k += 256) s_wlin[k] = wlin[k];
     }
-    __syncthreads();
-    int cur = __builtin_amdgcn_readfirstlane(*s_next);
-    if (cur < 0) return;
+    const int first = queue_first(blockIdx.x, nbig, nsmall);
+    if (first < 0) return;
     int n, x0, y0;
-    coords(cur, n, x0, y0);
-    LinPrefetch<IMG_U8> linpx;
+    bool small;
+    coords(first, n, x0, y0, small);
     // first tile only: its first half and the first weight chunks are requested here; every later tile finds
     // them already on the way (requested by the last half / the last steps of the tile before)
     h0.template stage<PREC>(lds0, a.src[0], 0, a.img_stride, a.pitch, n, y0, x0, wave);
@@ -1305,7 +1263,13 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     // half 0 and chunk 0 (split: and 1) are in; the later chunks may still be in flight
     wait_vm_barrier<0>(st.issued - (NG0 + 1 + (PREC == 1 ? 1 : 0)));
 
-    while (true) {
+    int nn = 0, nx0 = 0, ny0 = 0;  // the tile after this one (known from half 1 on)
+    bool nsmall_tile = false;
+
+    // One tile: T tile rows per wave (2: an 8-row tile, 1: a 4-row tile in the first rows of the same buffers).
+    auto tile_body = [&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        constexpr int TH = 4 * T;
         f32x16 acc[NTN * T], accx[PREC == 1 ? NTN * T : 1];
 #pragma unroll
         for (int m = 0; m < NTN * T; ++m)
@@ -1314,11 +1278,13 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
                 acc[m][r] = 0.f;
                 if constexpr (PREC == 1) accx[m][r] = 0.f;
             }
-        TL(0); TL(1);
-        int pulled = 0;
-        if (tid == 0) pulled = atomicAdd(&a.queue[xcd], 1);  // the answer is looked at by the end of half 0
-        int nn = 0, nx0 = 0, ny0 = 0, next = -1;
+        // (local to the tile ON PURPOSE: the registers the asynchronous atomic / load return into must not be live across the
+        // tile loop's merge of the two tile bodies -- the compiler then copies them right after the asm statement, i.e. before
+        // the data has arrived; it cannot know these asm outputs land later)
+        QueueState qs{0u, 0u, 0, 0, -1};
+        queue_pull_async(a, xcd, wave, lane, st, qs);  // the answer is looked at towards the end of half 0
         st.have_next = false;  // not known yet: nothing of the next tile is requested before half 1
+        LinPrefetch<IMG_U8, TH> linpx;
         auto do_half = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int src = j >> 1;
@@ -1327,29 +1293,28 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             const uint32_t other = lds0 + ((j + 1) & 1) * HB;
             const char* hb = smem + (j & 1) * HB;
             if constexpr (j == 1) {  // the mailbox was published before the barrier that ended half 0
-                next = __builtin_amdgcn_readfirstlane(*s_next);
+                const int next = __builtin_amdgcn_readfirstlane(*s_next);
                 st.have_next = next >= 0;
-                if (st.have_next) coords(next, nn, nx0, ny0);
+                if (st.have_next) coords(next, nn, nx0, ny0, nsmall_tile);
             }
-            // half j+1 of this tile, or the next tile's half 0, goes into the buffer half j-1 has just left
+            // half j+1 of this tile, or the next tile's half 0, goes into the buffer half j-1 has just left; a 4-row tile
+            // needs only the first NG_SMALL gather groups of it
             HalfRequest rq;
-            if constexpr (j + 1 < NH) rq = HalfRequest{true, other, a.src[(j + 1) >> 1], (j + 1) & 1, n, y0, x0};
-            else rq = HalfRequest{st.have_next, other, a.src[0], 0, nn, ny0, nx0};
+            if constexpr (j + 1 < NH) rq = HalfRequest{T == 2 ? HalfTile<KSN>::G::NG : HalfTile<KSN>::NG_SMALL, other, a.src[(j + 1) >> 1], (j + 1) & 1, n, y0, x0};
+            else rq = HalfRequest{!st.have_next ? 0 : nsmall_tile ? HalfTile<KSN>::NG_SMALL : HalfTile<KSN>::G::NG, other, a.src[0], 0, nn, ny0, nx0};
             if constexpr (FINAL && j == NH - 1) linpx.issue(a, n, y0, x0, tid, st);
             const HalfTile<KSN>* htn;
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
             using GJ = TileGeom<8, KSJ>;
-            PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring, wave, lane, j == 0 ? s_next : nullptr, xcd, ntiles, pulled};
+            constexpr int STEPS_J = HalfTile<KSJ>::STEPS * NTN;
+            PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring, wave, lane, j == 0 ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0};
             if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN>(acc, hb, ring, sm, wave, lane);
             else half_steps_h<GJ::TWH, GJ::PLANE, 2, KSJ, T, NTN>(acc, accx, hb, ring, sm, wave, lane);
         };
         do_half(std::integral_constant<int, 0>{});
         do_half(std::integral_constant<int, 1>{});
-        TL(2);
         if constexpr (NH > 2) { do_half(std::integral_constant<int, 2>{}); do_half(std::integral_constant<int, 3>{}); }
-        TL(3);
         if constexpr (NH > 4) { do_half(std::integral_constant<int, 4>{}); do_half(std::integral_constant<int, 5>{}); }
-        TL(4);
         if constexpr (FINAL) {
             // bilinear residual: the image tile goes into the buffer the last half has just left (buffer 1)
             float* s_x = (float*)(smem + HB);
@@ -1362,315 +1327,17 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
             asm volatile("" ::: "memory");
         }
-        TL(5); TL(6); TL(8);
-        if (!SR_DBG(a, 4))  // timing experiment (bit 2): no epilogue at all
         stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
-        TL(7);
-        if (!st.have_next) break;
-        n = nn; x0 = nx0; y0 = ny0;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
-    TL_END();
-}
-
-// ---------------------------------------------------------------------------
-// Stage kernel, COLUMN form (split-half mode, 8-row tiles, one N-tile).  Same tiles, same half tiles, same double
-// buffering and persistent queue as the pipe form; what changes is the unit of work between two workgroup barriers.
-// Measured on the step form (rocprofv3 SQ counters, 1080p): a wave spent 33 % of its cycles parked at s_waitcnt /
-// s_barrier and the f16 matrix pipe was 52-57 % busy -- with the half-tile gathers and the epilogue removed still only
-// 58-66 %: twelve 32-cycle MFMAs between two synchronisation points cannot cover the synchronisation itself.  Here
-//  * a step is one kernel COLUMN of one 16-channel half: 5 (3) taps x 2 rows x 3 products = 30 (18) MFMAs per wave and
-//    barrier, and the 6 (4) tile rows a column touches are read once for all its taps;
-//  * the operands of column c+1 (rows of the same half tile, weight fragments of whatever comes next -- also across half
-//    and tile boundaries) are read from LDS into the registers column c frees, one ds_read_b128 in the shadow of each MFMA,
-//    so nothing is waited for at the barrier;
-//  * weights travel as 2 KB tap chunks ([hi | lo], sr_api.cpp pack_cols) through two banks of five slots: at the start of
-//    column c the taps of column c+2 are requested into the bank column c has just vacated (all slot numbers are
-//    compile-time constants: a first version with a modulo-10 ring spent 25 scalar instructions per MFMA on them);
-//  * DMA roles are split by wave: waves 0-1 request weights only (L2 hits, needed one column later), waves 2-3 the
-//    half-tile gathers only (HBM latency, needed at the end of the half).  Loads retire in order on a wave's VM counter,
-//    so a wave that issued both had its per-step weight wait held up by gathers that were not due for a dozen steps.
-// Tap order (kernel-column-major), product order and half order equal the step form's, so results are bit-identical.
-// ---------------------------------------------------------------------------
-constexpr int kColSlots = 10;
-constexpr int kColRingBytes = kColSlots * 2048;
-
-template <int NSRC, int KS0>
-struct ColPlan {  // compile-time schedule of a tile: halves j (wrapping into the next tile), columns c
-    static constexpr int NH = 2 * NSRC;
-    static constexpr int ks(int j) { return (j % NH) < 2 ? KS0 : 3; }
-    static constexpr int tap0(int j) { int t = 0; for (int k = 0; k < j; ++k) t += ks(k) * ks(k); return t; }
-    static constexpr int ntaps() { return tap0(NH); }
-    static constexpr int ncols() { int c = 0; for (int j = 0; j < NH; ++j) c += ks(j); return c; }
-    static constexpr int col_half(int c) { int j = 0; while (c >= ks(j)) { c -= ks(j); ++j; } return j; }
-    static constexpr int col_kx(int c) { int j = 0; while (c >= ks(j)) { c -= ks(j); ++j; } return c; }
-    static constexpr int col_ks(int c) { return ks(col_half(c)); }
-    static constexpr int col_tap0(int c) { return tap0(col_half(c)) + col_kx(c) * col_ks(c); }
-};
-
-// Operand reads of the NEXT column, in issue order.  kind 0: tile row `idx` (hi / lo pixels), kind 1: weight fragment of tap
-// `idx`; `earliest` = number of this column's MFMAs that must have been issued first (the registers the read lands in are
-// those of an operand that dies there; the first six use spare registers and go out at once).
-struct ColItem { int kind, idx, lo, earliest; };
-__host__ __device__ constexpr ColItem col_item(int KS, int KSN, bool same_half, int k) {
-    int n = 0;
-    if (same_half) {
-        for (int r = KS; r >= KS - 1; --r)
-            for (int lo = 0; lo < 2; ++lo) { if (n == k) return {0, r, lo, 0}; ++n; }
-    }
-    for (int lo = 0; lo < 2; ++lo) { if (n == k) return {1, KSN - 1, lo, 0}; ++n; }
-    const int m = (KS > KSN ? KS : KSN) - 1;
-    for (int ky = 0; ky < m; ++ky) {
-        const int e = 6 * ((ky < KS - 1 ? ky : KS - 2) + 1);
-        if (ky < KSN - 1) for (int lo = 0; lo < 2; ++lo) { if (n == k) return {1, ky, lo, e}; ++n; }
-        if (same_half && ky < KS - 1) for (int lo = 0; lo < 2; ++lo) { if (n == k) return {0, ky, lo, e}; ++n; }
-    }
-    return {2, 0, 0, 0};
-}
-__host__ __device__ constexpr int col_item_count(int KS, int KSN, bool same_half) { return (same_half ? 2 * (KS + 1) : 0) + 2 * KSN; }
-// items [first, first + count) go out after MFMA number q (0-based) of the column: at most `cap` per MFMA, none before its time
-__host__ __device__ constexpr int col_items_before(int KS, int KSN, bool same_half, int q, int cap) {
-    const int total = col_item_count(KS, KSN, same_half);
-    int done = 0;
-    for (int s = 0; s < q; ++s) {
-        int c = 0;
-        while (c < cap && done < total && col_item(KS, KSN, same_half, done).earliest <= s + 1) { ++done; ++c; }
-    }
-    return done;
-}
-
-template <typename F, int... C>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, C...>) { (f(std::integral_constant<int, C>{}), ...); }
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int FACTOR = 3>
-__global__ __launch_bounds__(256, 2) void conv_stage_col_kernel(StageArgs a) {
-    constexpr int TH = 8, T = 2;
-    using P = ColPlan<NSRC, KS0>;
-    using H0 = HalfTile<KS0>;
-    using H3 = HalfTile<3>;
-    constexpr int HB = H0::BYTES;
-    constexpr int NH = P::NH, NCOLS = P::ncols(), NTAPS = P::ntaps();
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ring = smem + 2 * HB;
-    volatile int* s_next = (volatile int*)(ring + kColRingBytes);
-    float* s_wlin = (float*)(ring + kColRingBytes + 16);
-    const uint32_t lds0 = lds_addr(smem), ring_lds = lds_addr(ring);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, h = lane >> 5;
-    const bool weight_wave = wave < 2;  // waves 0, 1: weight DMA (hi / lo KB of every tap); waves 2, 3: gathers (planes 0-1 / 2-3)
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int ntiles = tiles_per_img * a.n_img;
-    const int xcd = blockIdx.x & 7;
-    float bias[1] = {a.bias[i]};
-    const float beta = FINAL ? 0.f : a.beta[i];
-    H0 h0;
-    H3 h3;
-    h0.init(a.pitch, lane);
-    if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
-
-    auto coords = [&](int t, int& n, int& x0, int& y0) {
-        int tx, ty;
-        tile_coords(a, t, n, tx, ty);
-        x0 = tx * kTW; y0 = a.y_begin + ty * TH;
     };
-    if (tid == 0) *s_next = queue_resolve(a.queue, xcd, ntiles, atomicAdd(&a.queue[xcd], 1));
-    if constexpr (FINAL) {
-        const float* wlin = a.wpack + (size_t)NTAPS * 512;
-        for (int k = tid; k < 9 * 128; k += 256) s_wlin[k] = wlin[k];
-    }
-    __syncthreads();
-    int cur_tile = __builtin_amdgcn_readfirstlane(*s_next);
-    if (cur_tile < 0) return;
-    int n, x0, y0;
-    coords(cur_tile, n, x0, y0);
-    LinPrefetch<IMG_U8> linpx;
 
-    // The ring is two banks of five 2 KB tap slots; column c keeps its taps in bank c & 1 (a tile has an even number of
-    // columns, so the parity runs on across tiles).  While column c executes from registers, bank (c+1) & 1 holds the taps
-    // of column c+1 (being read) and bank c & 1 -- column c's own, already consumed -- receives the taps of column c+2.
-    auto request_tap = [&](int bank, int t, int g) {  // this wave's KB (hi or lo) of tap g (tile-relative; >= NTAPS: next tile's)
-        const char* src = (const char*)a.wpack + (size_t)(g % NTAPS) * 2048 + (wave & 1) * 1024;
-        lds_dma16<0>(uniform_ptr(src), (uint32_t)(lane * 16), __builtin_amdgcn_readfirstlane(ring_lds + (5 * bank + t) * 2048 + (wave & 1) * 1024));
-    };
-    // first tile only: half 0 (every wave moves its plane) and the weights of the first two columns
-    h0.template stage<1>(lds0, a.src[0], 0, a.img_stride, a.pitch, n, y0, x0, wave);
-    if (weight_wave) {
-        static_for<P::col_ks(0)>([&](auto tc) { request_tap(0, decltype(tc)::value, decltype(tc)::value); });
-        static_for<P::col_ks(1)>([&](auto tc) { constexpr int g1 = P::col_tap0(1) + decltype(tc)::value; request_tap(1, decltype(tc)::value, g1); });
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    const int wlane = (h * 32 + i) * 16;
-    const char* ring_lane = ring + wlane;
-    // operand registers of two columns (parity of the column number): weight fragments of up to 5 taps, pixels of up to 6 rows
-    f16x8 bh[2][5], bl[2][5], ah[2][6], al[2][6];
-    // fragment of tap g (tile-relative) -> b?[par][t]; par, t, lo are compile-time at every call site (after inlining the
-    // array indices are constants, so the operand arrays live in registers)
-    auto read_b = [&](int par, int t, bool lo) __attribute__((always_inline)) {  // tap t of the column of parity par
-        const char* p = ring_lane + (5 * par + t) * 2048 + (lo ? 1024 : 0);
-        if (lo) bl[par][t] = *(const f16x8*)p; else bh[par][t] = *(const f16x8*)p;
-    };
-    static_for<KS0>([&](auto tc) { constexpr int t = decltype(tc)::value; read_b(0, t, false); read_b(0, t, true); });
-    // (every later column finds its fragments prefetched by the column before it; these reads must have returned in EVERY wave
-    // before column 0's first weight request may overwrite the slots they came from)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
+    int budget = nbig + nsmall;  // no workgroup can be handed more tiles than the launch has: a bound on the loop, whatever happens
     while (true) {
-        f32x16 acc[T], accx[T];
-#pragma unroll
-        for (int m = 0; m < T; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[m][r] = 0.f; accx[m][r] = 0.f; }
-        int pulled = 0;
-        // the next tile's number: asked for now, looked at by the end of half 0 -- by a thread of a GATHERING wave, whose next
-        // vmcnt(0) is the end of the half (a weight wave would wait for the atomic's round trip at the end of this column)
-        if (tid == 128) pulled = atomicAdd(&a.queue[xcd], 1);
-        int nn = 0, nx0 = 0, ny0 = 0, next = -1;
-        bool have_next = false;
-        const char* g_org[2] = {nullptr, nullptr};
-        uint32_t g_dst[2] = {0, 0};
-
-        static_for<NCOLS>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int j = P::col_half(c), kx = P::col_kx(c), KS = P::col_ks(c), par = c & 1;
-            constexpr int KSN = P::col_ks(c + 1), KS2 = P::col_ks(c + 2);
-            constexpr bool same_half = kx + 1 < KS;          // the next column reads the same half tile
-            constexpr bool last_of_half = !same_half;
-            using GJ = TileGeom<8, KS>;
-            constexpr int TWH = GJ::TWH, PS = GJ::PLANE;
-            const char* hb = smem + (j & 1) * HB;
-            const char* abase = hb + h * PS + ((wave * T) * TWH + i) * 16;
-            if constexpr (kx == 0) {
-                if constexpr (j == 1) {  // the mailbox was published before the barrier that ended half 0
-                    next = __builtin_amdgcn_readfirstlane(*s_next);
-                    have_next = next >= 0;
-                    if (have_next) coords(next, nn, nx0, ny0);
-                }
-                if constexpr (FINAL && j == NH - 1) {
-                    StepStream dummy{};
-                    linpx.issue(a, n, y0, x0, tid, dummy);
-                }
-                // the half tile landed with the barrier that ended the previous column: its first column's rows
-                if (!SR_DBG(a, 128))  // (bit 7: timing experiment without these exposed reads)
-                static_for<KS + 1>([&](auto rc) {
-                    constexpr int r = decltype(rc)::value;
-                    ah[par][r] = *(const f16x8*)(abase + (r * TWH) * 16);
-                    al[par][r] = *(const f16x8*)(abase + (r * TWH) * 16 + 2 * PS);
-                });
-            }
-            // what this column requests on the side
-            constexpr int jr = j + 1;                           // the half whose gathers go out during half j ...
-            constexpr int KSR = P::ks(jr);                      // (jr == NH: half 0 of the next tile)
-            constexpr int NGR = HalfTile<KSR>::G::NG;
-            if constexpr (kx == 0) {
-                // a gathering wave moves two LDS planes of that half: their source origins and LDS bases, once per half
-                // (scalar registers; a request is then s_mov m0 + one global_load_lds)
-                const float* gsrc = a.src[(jr % NH) >> 1];
-                const int tn = jr < NH ? n : nn, ty0 = jr < NH ? y0 : ny0, tx0 = jr < NH ? x0 : nx0;
-                const char* tile0 = (const char*)(gsrc + ((size_t)tn * a.img_stride + (long)(ty0 - KSR / 2) * a.pitch + (tx0 - KSR / 2)) * 32);
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    const int plane = 2 * (wave & 1) + pl;      // waves 2, 3 -> planes 0-1, 2-3
-                    const int chunk = plane < 2 ? 2 * (jr & 1) + plane : 4 + 2 * (jr & 1) + (plane - 2);
-                    g_org[pl] = uniform_ptr(tile0 + chunk * 16);
-                    g_dst[pl] = __builtin_amdgcn_readfirstlane(lds0 + ((j + 1) & 1) * HB + plane * HalfTile<KSR>::G::PLANE);
-                }
-            }
-            constexpr int issue_cols = KS - 1;                  // ... spread over all but the last column of half j
-            constexpr int PPC = (2 * NGR + issue_cols - 1) / issue_cols;
-            const bool gather_on = !SR_DBG(a, 2) && (jr < NH || have_next);
-            const bool weights_on = (c + 2 < NCOLS || have_next) && !SR_DBG(a, 8);
-            constexpr int NITEMS = col_item_count(KS, KSN, same_half);
-            constexpr int CAP = NITEMS > 6 * KS - 2 ? 2 : 1;
-
-            // after MFMA number q of the column: this wave's DMA request number q (they need the lead), then the operand reads
-            // of the next column that are due -- all indices compile-time constants (registers, not scratch)
-            auto aux = [&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-#ifndef SR_COL_NO_DMA_CODE  // (A/B build switch: the column loop without any DMA code -- timing experiment only)
-                // This column's DMA requests, ALL of them behind the first MFMA and behind ONE role branch: a wave-uniform branch per
-                // MFMA slot (the first version) cost the loop 10 % of its cycles, an EXEC-masked branch-free form three times that
-                // (the matrix pipe drains before EXEC may change).
-                if constexpr (q == 0) {
-                    if (weight_wave) {
-                        if (weights_on) static_for<KS2>([&](auto tc) {
-                            constexpr int t = decltype(tc)::value, g2 = (P::col_tap0(c + 2) + t) % NTAPS;  // forced compile-time
-                            request_tap(par, t, g2);
-                        });
-                    } else if constexpr (kx < issue_cols) {
-                        if (gather_on) static_for<PPC>([&](auto ec) {
-                            constexpr int e = kx * PPC + decltype(ec)::value;  // piece number within this wave's 2 * NGR
-                            if constexpr (e < 2 * NGR) {
-                                constexpr int pl = e / NGR, g = e % NGR;
-                                if constexpr (KSR == KS0) lds_dma16<0>(g_org[pl], h0.off[g], g_dst[pl] + g * 1024);
-                                else lds_dma16<0>(g_org[pl], h3.off[g], g_dst[pl] + g * 1024);
-                            }
-                        });
-                    }
-                }
-#endif
-                constexpr int first = col_items_before(KS, KSN, same_half, q, CAP), last = col_items_before(KS, KSN, same_half, q + 1, CAP);
-                if (!SR_DBG(a, 32))  // (bit 5: timing experiment without the operand reads -- the MFMAs then run on stale registers)
-                static_for<last - first>([&](auto kc) {
-                    constexpr int k = first + decltype(kc)::value;
-                    constexpr ColItem it = col_item(KS, KSN, same_half, k);
-                    if constexpr (it.kind == 0) {
-                        const char* p = abase + (it.idx * TWH + kx + 1) * 16 + (it.lo ? 2 * PS : 0);
-                        if constexpr (it.lo) al[par ^ 1][it.idx] = *(const f16x8*)p; else ah[par ^ 1][it.idx] = *(const f16x8*)p;
-                    } else {
-                        read_b(par ^ 1, it.idx, it.lo);
-                    }
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<KS>([&](auto kyc) {
-                constexpr int ky = decltype(kyc)::value;
-                static_for<T>([&](auto mc) { constexpr int m = decltype(mc)::value;
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[par][ky + m], bh[par][ky], acc[m], 0, 0, 0); aux(std::integral_constant<int, 6 * ky + m>{}); });
-                static_for<T>([&](auto mc) { constexpr int m = decltype(mc)::value;
-                    accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[par][ky + m], bl[par][ky], accx[m], 0, 0, 0); aux(std::integral_constant<int, 6 * ky + 2 + m>{}); });
-                static_for<T>([&](auto mc) { constexpr int m = decltype(mc)::value;
-                    accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[par][ky + m], bh[par][ky], accx[m], 0, 0, 0); aux(std::integral_constant<int, 6 * ky + 4 + m>{}); });
-            });
-            static_assert(col_items_before(KS, KSN, same_half, 6 * KS, CAP) == NITEMS, "every operand of the next column is requested");
-            // end of the column: the weights of column c+2 (requested at its start) have landed; at the end of a half also
-            // the next half tile; every LDS read of this column has returned before anybody overwrites what it read
-            if constexpr (j == 0 && last_of_half) { if (tid == 128) *s_next = queue_resolve(a.queue, xcd, ntiles, pulled); }
-            if (weight_wave || last_of_half) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!SR_DBG(a, 16)) __builtin_amdgcn_s_barrier();  // (bit 4: timing experiment without the column barrier)
-            asm volatile("" ::: "memory");
-        });
-
-        if constexpr (FINAL) {
-            // bilinear residual: the image tile goes into the buffer the last half has just left (buffer 1)
-            float* s_x = (float*)(smem + HB);
-            StepStream dummy{};
-            linpx.seq = 0;
-            linpx.store(s_x, tid, dummy);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            lin_mfma<TH, T, 1>(acc, s_x, s_wlin, wave, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
-            asm volatile("" ::: "memory");
-        }
-        if (!SR_DBG(a, 4))
-        stage_epilogue<TH, T, 1, FINAL, OUT_U8, 1, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
-        if (!have_next) break;
-        n = nn; x0 = nx0; y0 = ny0;
+        if (small) tile_body(std::integral_constant<int, 1>{});
+        else tile_body(std::integral_constant<int, 2>{});
+        if (!st.have_next || --budget <= 0) break;
+        n = nn; x0 = nx0; y0 = ny0; small = nsmall_tile;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
+    // (nothing is in flight towards LDS here: the last tile requested no successor; s_endpgm waits for the stores)
 }
 
 // ---------------------------------------------------------------------------
@@ -1786,7 +1453,7 @@ hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------
 template <int TH, int KS0>
 static constexpr size_t stage_lds_bytes() {
-    return 8 * (size_t)TileGeom<TH, KS0>::PLANE + kRingBytes + 16;  // + next-tile mailbox
+    return 8 * (size_t)TileGeom<TH, KS0>::PLANE + kRingBytes;
 }
 
 template <int TH, int PREC>
@@ -1808,7 +1475,7 @@ hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool 
 // host threads (sr_upscale_*_multi, sr_upscale_sharded_*_all), so the "already configured" set is keyed on both
 // and guarded by a mutex.
 template <typename K>
-static hipError_t launch_with_lds(K kern, const StageArgs& a, int nblk, size_t lds, hipStream_t s, int nthreads = kThreads) {
+static hipError_t launch_with_lds(K kern, const StageArgs& a, int nblk, size_t lds, hipStream_t s) {
     static std::mutex mu;
     static std::set<std::pair<const void*, int>> configured;
     int dev = 0;
@@ -1823,24 +1490,21 @@ static hipError_t launch_with_lds(K kern, const StageArgs& a, int nblk, size_t l
             configured.insert(key);
         }
     }
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(nthreads), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(kThreads), lds, s, a);
     return hipGetLastError();
 }
 
 template <int TH, int PREC>
 static hipError_t launch_stage_t(int stage, int factor, const StageArgs& a, int nblk, bool img_u8, bool out_u8,
                                  hipStream_t s) {
-    // waves per workgroup.  8 (one tile row per wave, 4 waves per SIMD) was measured for the
-    // split-half mode: 5 % slower than 4 (B-operand reuse halves), so SR_SPLIT_WAVES stays 4.
-    constexpr int NWAVES = (PREC == 1 && TH == 8) ? SR_SPLIT_WAVES : 4;
     switch (stage) {
-        case 1: return launch_with_lds(conv_stage_kernel<TH, 1, 5, false, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 5>(), s, NWAVES * 64);
-        case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 5>(), s, NWAVES * 64);
-        case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false, PREC, PREC == 1, NWAVES>, a, nblk, stage_lds_bytes<TH, 5>(), s, NWAVES * 64);
+        case 1: return launch_with_lds(conv_stage_kernel<TH, 1, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 2: return launch_with_lds(conv_stage_kernel<TH, 2, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
+        case 3: return launch_with_lds(conv_stage_kernel<TH, 3, 5, false, false, false, PREC>, a, nblk, stage_lds_bytes<TH, 5>(), s);
         case 4:
 #define SR_FINAL(F)                                                                                                          \
-            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC, PREC == 1, NWAVES, F>, a, nblk, stage_lds_bytes<TH, 3>(), s, NWAVES * 64); \
-            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC, PREC == 1, NWAVES, F>, a, nblk, stage_lds_bytes<TH, 3>(), s, NWAVES * 64); \
+            if (img_u8 && out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, true, true, PREC, F>, a, nblk, stage_lds_bytes<TH, 3>(), s); \
+            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_kernel<TH, 3, 3, true, false, false, PREC, F>, a, nblk, stage_lds_bytes<TH, 3>(), s); \
             return hipErrorInvalidValue;
             if (factor == 3) { SR_FINAL(3) }
             if (factor == 2) { SR_FINAL(2) }
@@ -1851,7 +1515,7 @@ static hipError_t launch_stage_t(int stage, int factor, const StageArgs& a, int 
     }
 }
 
-// Pipe form (8-row tiles, factor <= 3): grid = co-resident workgroups, LDS = two half tiles + ring + mailbox.
+// Pipe form (both tile classes of the launch): grid = co-resident workgroups, LDS = two half tiles + ring + mailbox.
 template <int PREC>
 static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s) {
     constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kRingBytes + 16;
@@ -1873,27 +1537,6 @@ static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a,
     }
     return hipErrorInvalidValue;
 }
-// Column form (split-half mode, 8-row tiles, factor <= 3): LDS = two half tiles + tap ring + mailbox (+ bilinear weights).
-hipError_t sr_launch_stage_cols(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s) {
-    constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kColRingBytes + 16;
-    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kColRingBytes + 16 + 9 * 128 * sizeof(float);
-    switch (stage) {
-        case 1: return launch_with_lds(conv_stage_col_kernel<1, 5, false, false, false>, a, grid, lds5, s);
-        case 2: return launch_with_lds(conv_stage_col_kernel<2, 5, false, false, false>, a, grid, lds5, s);
-        case 3: return launch_with_lds(conv_stage_col_kernel<3, 5, false, false, false>, a, grid, lds5, s);
-        case 4:
-#define SR_FINAL(F)                                                                                                          \
-            if (img_u8 && out_u8) return launch_with_lds(conv_stage_col_kernel<3, 3, true, true, true, F>, a, grid, lds3, s); \
-            if (!img_u8 && !out_u8) return launch_with_lds(conv_stage_col_kernel<3, 3, true, false, false, F>, a, grid, lds3, s); \
-            return hipErrorInvalidValue;
-            if (factor == 3) { SR_FINAL(3) }
-            if (factor == 2) { SR_FINAL(2) }
-#undef SR_FINAL
-            return hipErrorInvalidValue;
-    }
-    return hipErrorInvalidValue;
-}
-
 hipError_t sr_launch_stage_pipe(int stage, int factor, const StageArgs& a, int prec, int grid, bool img_u8, bool out_u8, hipStream_t s) {
     return prec == 0 ? launch_stage_pipe_t<0>(stage, factor, a, grid, img_u8, out_u8, s)
                      : launch_stage_pipe_t<1>(stage, factor, a, grid, img_u8, out_u8, s);

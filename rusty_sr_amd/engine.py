@@ -133,9 +133,11 @@ class Engine:
 
     # ---- device-memory entry points (torch tensors on this GPU) ------------
     @staticmethod
-    def _stream_ptr(stream=None):
+    def _stream_ptr(stream=None, device=None):
+        """The stream to launch on: the caller's, else torch's current stream OF THE TENSOR'S DEVICE (not of whatever device
+        happens to be current in this thread: a process that drives several GPUs may be elsewhere)."""
         import torch
-        s = stream if stream is not None else torch.cuda.current_stream()
+        s = stream if stream is not None else torch.cuda.current_stream(device)
         return C.c_void_p(s.cuda_stream)
 
     def upscale_f32_dev(self, x, out=None, stream=None):
@@ -145,7 +147,7 @@ class Engine:
         if out is None:
             out = torch.empty((n,) + self._out_hw(h, w) + (3,), dtype=torch.float32, device=x.device)
         _lib.check(self._L.sr_upscale_f32_dev(self._ctx, C.c_void_p(x.data_ptr()), n, h, w,
-                                              C.c_void_p(out.data_ptr()), self._stream_ptr(stream)), self._ctx)
+                                              C.c_void_p(out.data_ptr()), self._stream_ptr(stream, x.device)), self._ctx)
         return out
 
     def upscale_rgba8_dev(self, px, out=None, stream=None):
@@ -155,7 +157,7 @@ class Engine:
         if out is None:
             out = torch.empty((n,) + self._out_hw(h, w) + (4,), dtype=torch.uint8, device=px.device)
         _lib.check(self._L.sr_upscale_rgba8_dev(self._ctx, C.c_void_p(px.data_ptr()), c, n, h, w,
-                                                C.c_void_p(out.data_ptr()), self._stream_ptr(stream)), self._ctx)
+                                                C.c_void_p(out.data_ptr()), self._stream_ptr(stream, px.device)), self._ctx)
         return out
 
     def upscale_band_f32_dev(self, x_ext, halo_top, halo_bot, out=None, stream=None):
@@ -169,7 +171,7 @@ class Engine:
         if out is None:
             out = torch.empty((self.factor * hb, self.factor * w, 3), dtype=torch.float32, device=x_ext.device)
         _lib.check(self._L.sr_upscale_band_f32_dev(self._ctx, C.c_void_p(x_ext.data_ptr()), h_ext, w, halo_top,
-                                                   halo_bot, C.c_void_p(out.data_ptr()), self._stream_ptr(stream)),
+                                                   halo_bot, C.c_void_p(out.data_ptr()), self._stream_ptr(stream, x_ext.device)),
                    self._ctx)
         return out
 
@@ -184,7 +186,7 @@ class Engine:
             out = torch.empty((self.factor * hb, self.factor * w, 4), dtype=torch.uint8, device=px_ext.device)
         _lib.check(self._L.sr_upscale_band_rgba8_dev(self._ctx, C.c_void_p(px_ext.data_ptr()), c, h_ext, w,
                                                      halo_top, halo_bot, C.c_void_p(out.data_ptr()),
-                                                     self._stream_ptr(stream)), self._ctx)
+                                                     self._stream_ptr(stream, px_ext.device)), self._ctx)
         return out
 
     # ---- sharded image: RCCL communicator inside libsrhip (include/srhip.h sr_comm_*) ----------
@@ -222,10 +224,10 @@ class Engine:
             out = torch.empty((self.factor * hb, self.factor * w, 4 if u8 else 3), dtype=band.dtype, device=band.device)
         if u8:
             st = self._L.sr_upscale_sharded_rgba8_dev(self._ctx, C.c_void_p(band.data_ptr()), c, hb, w, C.c_void_p(out.data_ptr()),
-                                                      self._stream_ptr(stream))
+                                                      self._stream_ptr(stream, band.device))
         else:
             st = self._L.sr_upscale_sharded_f32_dev(self._ctx, C.c_void_p(band.data_ptr()), hb, w, C.c_void_p(out.data_ptr()),
-                                                    self._stream_ptr(stream))
+                                                    self._stream_ptr(stream, band.device))
         _lib.check(st, self._ctx)
         return out
 

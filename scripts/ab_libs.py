@@ -48,7 +48,7 @@ H, W = map(int, a.hw.split("x"))
 res = {l: [] for l in a.libs}
 for rnd in range(a.rounds):
     for lib in a.libs:
-        path, *envs = lib.split("@")  # lib.so@SRHIP_COLS=0@SRHIP_BW=8 ...
+        path, *envs = lib.split("@")  # lib.so@SRHIP_TAIL=0@SRHIP_BW=8 ...
         env = dict(os.environ, SRHIP_LIB=os.path.abspath(path), **dict(e.split("=", 1) for e in envs))
         r = subprocess.run([sys.executable, "-c", CHILD, a.prec, str(H), str(W), str(a.reps)], env=env, capture_output=True, text=True, timeout=300)
         if r.returncode != 0:

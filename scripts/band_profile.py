@@ -6,7 +6,9 @@ one rank of `sr_upscale_sharded_*` computes after the exchange) this prints, per
 tiles per resident workgroup slot, fill of the last round, time (HIP events inside libsrhip, median), and the time the
 same rows would take at the undivided frame's rate.  Device-resident, u8 in / RGBA8 out.
 
-    python scripts/band_profile.py [prec] [reps] [--once WAYS]     (--once: just run that band a few times, for rocprofv3)
+    python scripts/band_profile.py [prec] [reps] [--tails] [--once WAYS]     (--once: just run that band a few times, for rocprofv3;
+    --tails: also two other lengths of the 4-row tail)
+Per band three tile plans are timed: the automatic one (8-row tiles ended by 4-row tiles), 8-row tiles only, 4-row tiles only.
 """
 import json
 import os
@@ -35,9 +37,10 @@ def main():
     img = synth_u8(3, HC, WC)
     cus = eng.device_info()["compute_units"]
 
-    def run(ways, th=None):
+    def run(ways, th=None, tail=""):
         if th is not None:
             eng.set_experiment("th", th)
+            eng.set_experiment("tail", tail)
         if ways == 1:
             ext, top, bot, rows = img, 0, 0, HC
         else:
@@ -81,26 +84,29 @@ def main():
     full = run(1)
     per_row = [full["stage_ms"][s] / HC for s in range(5)]
     print(json.dumps({"full_frame": full}))
+    variants = [("", ""), ("8", "")] + ([("", t) for t in ("0.75", "3")] if "--tails" in sys.argv else [])
     for ways in (2, 4, 8):
-        for th in ("", "4"):
-            b = run(ways, th)
+        for th, tail in variants:
+            b = run(ways, th, tail)
             slots = 2 * cus
             rowsx = []
             for s in range(5):
                 thh = 4 if th == "4" else 8
-                tiles = ((b["stage_rows"][s] + thh - 1) // thh) * (WC // 32)
+                tiles = ((b["stage_rows"][s] + thh - 1) // thh) * (WC // 32)  # (mixed launches: counted as 8-row tiles)
                 ideal = per_row[s] * b["rows"]
                 rowsx.append({"stage": s, "rows": b["stage_rows"][s], "tiles": tiles, "tiles_per_slot": round(tiles / slots, 2),
                               "ms": b["stage_ms"][s], "ms_at_frame_rate_own_rows": round(ideal, 4),
                               "ratio": round(b["stage_ms"][s] / ideal, 3),
                               "tflops": round(2 * MAC[s] * b["stage_rows"][s] * WC / (b["stage_ms"][s] / 1e3) / 1e12, 1)})
-            b["th"] = th or "auto"
+            b["th"] = th or "mixed"
+            b["tail"] = tail or "auto"
             b["ideal_ms"] = round(full["wall_ms"] / ways, 4)
             b["wall_over_ideal"] = round(b["wall_ms"] / b["ideal_ms"], 4)
             b["useful_tflops"] = round(2 * sum(MAC) * b["rows"] * WC / (b["wall_ms"] / 1e3) / 1e12, 1)
             b["stages"] = rowsx
             print(json.dumps(b))
     eng.set_experiment("th", "")
+    eng.set_experiment("tail", "")
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build an A/B variant of libsrhip.so with extra -D flags:  scripts/build_variant.sh NAME -DSR_SPLIT_INTERLEAVE=0 ...
+# Build an A/B variant of libsrhip.so with extra -D flags:  scripts/build_variant.sh NAME -DSOME_SWITCH=1 ...
 # -> exp/libsrhip_NAME.so (select it with SRHIP_LIB=exp/libsrhip_NAME.so).  Only the kernel object is rebuilt.
 set -e
 cd "$(dirname "$0")/.."

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One SQ counter pass over scripts/run_once.py for a few variants (env assignments), per-kernel averages.
-#   scripts/pmc_quick.sh OUTTAG PREC "ENV1" "ENV2" ...      e.g.  scripts/pmc_quick.sh dbg split_f16 "SRHIP_DBG=0" "SRHIP_DBG=2"
+#   scripts/pmc_quick.sh OUTTAG PREC "ENV1" "ENV2" ...      e.g.  scripts/pmc_quick.sh tail f32 "SRHIP_TAIL=0" "SRHIP_TAIL=1.5"
 export TMPDIR=/tmp
 TAG=$1; PREC=$2; shift 2
 for V in "$@"; do

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Minimal driver for rocprofv3: a few device-resident passes of one workload.
-    python scripts/run_once.py [prec] [HxW] [reps]      (SRHIP_LIB / SRHIP_DBG / SRHIP_BW select variants)"""
+    python scripts/run_once.py [prec] [HxW] [reps]      (SRHIP_LIB / SRHIP_BW / SRHIP_TH / SRHIP_TAIL select variants)"""
 import os
 import sys
 

@@ -143,3 +143,18 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(c),
                            "-L", lib_dir, "-lsrhip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib",
                            "-o", str(tmp_path / "abi")])
+
+
+def test_async_asm_results_are_not_read_before_their_wait():
+    """The kernels issue a few VMEM instructions from inline asm whose results arrive later (the tile queue's returning
+    atomic, the head snapshot, the last stage's pixel prefetch); the compiler cannot know and may read such a register at
+    once.  build_lib keeps the device assembly; scripts/check_async_regs.py lints it."""
+    import subprocess
+    import sys
+    from rusty_sr_amd.build import DEVICE_ASM as asm, build_lib
+    build_lib()
+    if not os.path.exists(asm):  # an object built before this check existed
+        build_lib(force=True)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_async_regs.py"), asm], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "asynchronous asm results checked, 0 read too early" in res.stdout and not res.stdout.startswith("0 ")

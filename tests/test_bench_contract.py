@@ -40,6 +40,11 @@ def test_bench_single_gpu_contract():
     for key in ("config_A", "config_C", "config_D", "host_call"):
         assert key in d and "error" not in d[key], (key, d.get(key))
     assert d["config_C"]["scaling"] == "strong" and len(d["config_C"]["roofline_frac_per_rank"]) == 1
+    prev = d["config_C"]["band_preview"]  # what one rank of a 2- / 4- / 8-way split of config C does per frame, on this GPU
+    for ways in (2, 4, 8):
+        e = prev[f"{ways}_way"]
+        assert e["rows"] == 2160 // ways and e["ms_per_band"] > 0 and 0 < e["useful_roofline_frac"] < 1
+    assert 0 < d["config_A"]["whole_call_frac"] < 1
     assert d["config_D"]["images_per_rank"] == 64 and d["config_D"]["data_path_collectives"] == 0 and "host_pipelined" in d["config_D"]
 
 
@@ -57,6 +62,7 @@ def test_bench_two_rank_rehearsal():
     c, dd = d["config_C"], d["config_D"]
     assert "error" not in c and "error" not in dd, (c, dd)
     assert c["scaling"] == "strong" and len(c["roofline_frac_per_rank"]) == 2 and [p["rows"] for p in c["per_rank"]] == [1080, 1080]
+    assert "WEAK scaling" in d["metric"] and "config_C" in d["metric"] and "speedup_vs_n1" in c
     assert abs(c["value"] - 9 * 2160 * 3840 / 1e6 / (c["ms_per_step"] / 1e3)) / c["value"] < 1e-3
     assert dd["images_per_rank"] == 32 and dd["data_path_collectives"] == 0
     assert abs(dd["value"] - 64 * 9 * 512 * 512 / 1e6 / (dd["ms_per_step"] / 1e3)) / dd["value"] < 1e-3

@@ -1,0 +1,37 @@
+"""One image over every visible GPU from a plain C99 process (tests/c/comm_smoke.c): no torch, no Python in the process that
+owns the RCCL communicator.  On a one-GPU box the RCCL leg prints "skipped: 1 device" and the peer-copy leg runs with two
+contexts of device 0; on a multi-GPU box this is the first thing to look at when a sharded run misbehaves, because nothing
+here depends on torch's RCCL instance."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def _build(tmp_path):
+    exe = tmp_path / "comm_smoke"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "comm_smoke.c"), "-L", os.path.join(ROOT, "rusty_sr_amd"), "-lsrhip", "-L", "/opt/rocm/lib",
+           "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "rusty_sr_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_comm_smoke_compiles_as_c99(tmp_path):
+    from rusty_sr_amd.build import build_lib
+    build_lib()
+    assert os.path.exists(_build(tmp_path))
+
+
+@pytest.mark.gpu
+def test_comm_smoke_runs(tmp_path):
+    exe = _build(tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([str(exe), os.path.join(ROOT, "rusty_sr_amd", "res", "imagenet.rsr")], capture_output=True, text=True,
+                         timeout=600, env=env)
+    print(res.stdout)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.rstrip().endswith("comm_smoke ok")
+    assert "bit-identical" in res.stdout

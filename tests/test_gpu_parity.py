@@ -371,13 +371,15 @@ def test_host_pipeline_batch_chunks(engines, params):
 
 
 def test_pipe_form_equals_first_form_bit_for_bit(engines, params):
-    """The two forms of the stage kernels (conv_stage_pipe_kernel: half tiles double-buffered, persistent;
-    conv_stage_kernel: whole tile resident) share step order and weight chunks, so they must agree bit for
-    bit -- on ragged shapes, on batches, with few tiles per workgroup, for both tile heights of the first
-    form, and for any tile order (column-block width).  sr_set_experiment is the library's A/B switch."""
+    """The two forms of the stage kernels (conv_stage_pipe_kernel: half tiles double-buffered, persistent, 8-row tiles and
+    4-row tiles in one launch; conv_stage_kernel: whole tile resident, one tile class) share step order and weight chunks,
+    so they must agree bit for bit -- on ragged shapes, on batches, with few tiles per workgroup, for either tile height
+    alone, for every mix of the two (the "tail" of 4-row tiles), and for any tile order (column-block width).
+    sr_set_experiment is the library's A/B switch."""
     eng = engines["imagenet"]
     rng = np.random.default_rng(5)
-    shapes = [(1, 8, 32), (1, 9, 33), (2, 40, 70), (1, 64, 1024), (3, 37, 129), (1, 130, 700), (1, 300, 515), (1, 2000, 40), (1, 16, 3000)]
+    shapes = [(1, 8, 32), (1, 9, 33), (2, 40, 70), (1, 64, 1024), (3, 37, 129), (1, 130, 700), (1, 300, 515), (1, 2000, 40), (1, 16, 3000),
+              (1, 250, 2080), (2, 333, 640)]
     try:
         for (n, h, w) in shapes:
             px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
@@ -390,6 +392,22 @@ def test_pipe_form_equals_first_form_bit_for_bit(engines, params):
                 eng.set_experiment("bw", bw)
                 np.testing.assert_array_equal(eng.upscale_f32(x), pipe32, err_msg=f"tile order bw={bw} {(n, h, w)}")
             eng.set_experiment("bw", "")
+            eng.set_experiment("th", "4")  # the pipe form on 4-row tiles only
+            np.testing.assert_array_equal(eng.upscale_f32(x), pipe32, err_msg=f"pipe form, 4-row tiles {(n, h, w)}")
+            np.testing.assert_array_equal(eng.upscale_rgba8(px), pipe8, err_msg=f"pipe form, 4-row tiles, u8 {(n, h, w)}")
+            for k in range(4):
+                np.testing.assert_array_equal(feats[k], eng.read_feature(k, h, w), err_msg=f"feature {k}, 4-row tiles {(n, h, w)}")
+            eng.set_experiment("th", "")   # automatic: both classes in one launch, for several tail lengths
+            for tail in ("", "0.01", "0.3", "4"):
+                eng.set_experiment("tail", tail)
+                np.testing.assert_array_equal(eng.upscale_f32(x), pipe32, err_msg=f"mixed tiles, tail={tail!r} {(n, h, w)}")
+                np.testing.assert_array_equal(eng.upscale_rgba8(px), pipe8, err_msg=f"mixed tiles, u8, tail={tail!r} {(n, h, w)}")
+                for bw in ("0", "3"):
+                    eng.set_experiment("bw", bw)
+                    np.testing.assert_array_equal(eng.upscale_f32(x), pipe32, err_msg=f"mixed tiles, tail={tail!r}, bw={bw} {(n, h, w)}")
+                eng.set_experiment("bw", "")
+            eng.set_experiment("tail", "")
+            eng.set_experiment("th", "8")
             eng.set_experiment("pipe", "none")
             first32 = eng.upscale_f32(x)
             np.testing.assert_array_equal(pipe32, first32, err_msg=str((n, h, w)))
@@ -399,12 +417,14 @@ def test_pipe_form_equals_first_form_bit_for_bit(engines, params):
             eng.set_experiment("th", "4")
             np.testing.assert_array_equal(eng.upscale_f32(x), first32, err_msg="tile height 4 vs 8")
             eng.set_experiment("th", "")
-            eng.set_experiment("pipe", "all")
+            eng.set_experiment("pipe", "")  # the library's own choice of form and tile plan
+            np.testing.assert_array_equal(eng.upscale_f32(x), first32, err_msg=f"automatic plan {(n, h, w)}")
+            np.testing.assert_array_equal(eng.upscale_rgba8(px), pipe8, err_msg=f"automatic plan, u8 {(n, h, w)}")
             if n * h * w <= 40 * 70 * 2:
                 assert np.abs(pipe32 - oracle.forward(params["imagenet"], x)).max() < TIGHT
     finally:
-        for key in ("th", "pipe", "bw"):
-            eng.set_experiment(key, "" if key != "pipe" else "all")
+        for key in ("th", "pipe", "bw", "tail"):
+            eng.set_experiment(key, "")
 
 
 def test_bilinear_and_downsample_graphs(params):
