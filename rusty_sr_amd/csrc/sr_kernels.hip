@@ -792,31 +792,58 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
                 const f32x16& av = acc[nt * T + m];
                 const size_t opx = ((size_t)n * h_band * FACTOR + (size_t)(y - a.y_begin) * FACTOR + dy) * OW +
                                    FACTOR * (x0 + 4 * h) + dx;
+                // Every EXEC change in here costs matrix-pipe time (the pipe drains first), so a full-width tile computes all
+                // sixteen values on every lane and stores them inside ONE lane-masked region; only the image's last tile column
+                // tests each pixel.
                 if constexpr (!OUT_U8) {
                     float* base = (float*)a.out + opx * 3 + c;
                     if (full_x) {
-                        for_each_acc_row([&](int r, int row) { if (valid) base[row * FACTOR * 3] = __fadd_rn(av[r], bias[nt]); });
+                        float v[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            const f32x2 s = f32x2{av[r], av[r + 1]} + f32x2{bias[nt], bias[nt]};
+                            v[r] = s.x; v[r + 1] = s.y;
+                        }
+                        if (valid) for_each_acc_row([&](int r, int row) { base[row * FACTOR * 3] = v[r]; });
                     } else {
                         for_each_acc_row([&](int r, int row) {
                             if (valid && x0 + 4 * h + row < a.W) base[row * FACTOR * 3] = __fadd_rn(av[r], bias[nt]);
                         });
                     }
                 } else {
-                    // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255.  Every lane shifts its byte to
-                    // its place in the pixel (8 c bits); the lane holding R then ORs in the two lanes above it with row_shl
-                    // DPP moves -- pure VALU (a __shfl_down is a ds_bpermute: LDS crossbar + an lgkmcnt wait per row)
+                    // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255.  v_cvt_pk_u8_f32 saturates to
+                    // [0, 255] and drops the byte into place c of the pixel in one instruction, but it rounds to nearest even
+                    // (scripts/experiments/probe_cvt_pk_u8.hip), so it is fed the floor, an integer: clamp, convert and shift
+                    // are then one instruction instead of three.  The lane holding R carries alpha in its `old` operand and ORs
+                    // in the two lanes above it with row_shl DPP moves -- pure VALU (a __shfl_down is a ds_bpermute: LDS
+                    // crossbar + an lgkmcnt wait per row).
                     uint32_t* base = (uint32_t*)a.out + opx;
                     const bool writer = valid && c == 0;
-                    const uint32_t sh = 8u * (uint32_t)c;
-                    for_each_acc_row([&](int r, int row) {
-                        float q = floorf(__fadd_rn(__fmul_rn(255.0f, __fadd_rn(av[r], bias[nt])), 0.5f));
-                        q = fminf(fmaxf(q, 0.0f), 255.0f);
-                        const uint32_t qs = (uint32_t)q << sh;
-                        const uint32_t g = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qs, 0x101, 0xF, 0xF, true);  // row_shl:1
-                        const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qs, 0x102, 0xF, 0xF, true);  // row_shl:2
-                        if (writer && (full_x || x0 + 4 * h + row < a.W))
-                            base[row * FACTOR] = qs | g | b | 0xff000000u;
-                    });
+                    const uint32_t old = c == 0 ? 0xff000000u : 0u;
+                    auto quant2 = [&](int r, uint32_t& p0, uint32_t& p1) {
+                        const f32x2 s = (f32x2{av[r], av[r + 1]} + f32x2{bias[nt], bias[nt]}) * f32x2{255.0f, 255.0f} + f32x2{0.5f, 0.5f};
+                        const uint32_t q0 = __builtin_amdgcn_cvt_pk_u8_f32(floorf(s.x), (uint32_t)c, old);
+                        const uint32_t q1 = __builtin_amdgcn_cvt_pk_u8_f32(floorf(s.y), (uint32_t)c, old);
+                        p0 = q0 | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q0, 0x101, 0xF, 0xF, true)    // row_shl:1 (G)
+                                | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q0, 0x102, 0xF, 0xF, true);   // row_shl:2 (B)
+                        p1 = q1 | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q1, 0x101, 0xF, 0xF, true)
+                                | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q1, 0x102, 0xF, 0xF, true);
+                    };
+                    if (full_x) {
+                        uint32_t px[16];
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) quant2(r, px[r], px[r + 1]);
+                        if (writer) for_each_acc_row([&](int r, int row) { base[row * FACTOR] = px[r]; });
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) {
+                            uint32_t p0, p1;
+                            quant2(r, p0, p1);
+                            const int row0 = (r & 3) + 8 * (r >> 2);
+                            if (writer && x0 + 4 * h + row0 < a.W) base[row0 * FACTOR] = p0;
+                            if (writer && x0 + 4 * h + row0 + 1 < a.W) base[(row0 + 1) * FACTOR] = p1;
+                        }
+                    }
                 }
             }
         }
@@ -1248,6 +1275,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     }
     const int first = queue_first(blockIdx.x, nbig, nsmall);
     if (first < 0) return;
+    // a launch with a workgroup per tile (small images) has no queue to ask: its tile is the workgroup's only one
+    const bool single = (int)gridDim.x >= nbig + nsmall;
     int n, x0, y0;
     bool small;
     coords(first, n, x0, y0, small);
@@ -1282,7 +1311,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         // tile loop's merge of the two tile bodies -- the compiler then copies them right after the asm statement, i.e. before
         // the data has arrived; it cannot know these asm outputs land later)
         QueueState qs{0u, 0u, 0, 0, -1};
-        queue_pull_async(a, xcd, wave, lane, st, qs);  // the answer is looked at towards the end of half 0
+        if (!single) queue_pull_async(a, xcd, wave, lane, st, qs);  // the answer is looked at towards the end of half 0
         st.have_next = false;  // not known yet: nothing of the next tile is requested before half 1
         LinPrefetch<IMG_U8, TH> linpx;
         auto do_half = [&](auto jc) {
@@ -1293,7 +1322,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             const uint32_t other = lds0 + ((j + 1) & 1) * HB;
             const char* hb = smem + (j & 1) * HB;
             if constexpr (j == 1) {  // the mailbox was published before the barrier that ended half 0
-                const int next = __builtin_amdgcn_readfirstlane(*s_next);
+                const int next = single ? -1 : __builtin_amdgcn_readfirstlane(*s_next);
                 st.have_next = next >= 0;
                 if (st.have_next) coords(next, nn, nx0, ny0, nsmall_tile);
             }
@@ -1307,7 +1336,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
             using GJ = TileGeom<8, KSJ>;
             constexpr int STEPS_J = HalfTile<KSJ>::STEPS * NTN;
-            PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring, wave, lane, j == 0 ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0};
+            PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring, wave, lane, (j == 0 && !single) ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0};
             if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN>(acc, hb, ring, sm, wave, lane);
             else half_steps_h<GJ::TWH, GJ::PLANE, 2, KSJ, T, NTN>(acc, accx, hb, ring, sm, wave, lane);
         };

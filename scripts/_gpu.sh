@@ -1,20 +1,16 @@
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r3e
-ok=1
-for cfg in "SRHIP_TH=4 SRHIP_PIPE=all" "SRHIP_TAIL=1.5"; do
-  for prec in f32 split_f16; do
-    echo "== $cfg $prec"
-    env $cfg SRHIP_TRACE=2 timeout 40 python scripts/run_once.py $prec 1080x1920 2 2>&1 | grep -c "done" || ok=0
-  done
-done
-echo "== 256 th4 pipe"; SRHIP_TH=4 SRHIP_PIPE=all timeout 40 python scripts/run_once.py f32 256x256 3 && echo fine || ok=0
-if [ $ok = 1 ]; then
-timeout 700 python -m pytest tests -m gpu -x -q --deselect tests/test_bench_contract.py > gpurun_out/r3e/pytest.log 2>&1
-echo "pytest rc=$?"
-tail -n 6 gpurun_out/r3e/pytest.log
-timeout 150 python scripts/band_profile.py f32 7 --tails > gpurun_out/r3e/band_f32.jsonl 2> gpurun_out/r3e/band_f32.err
-timeout 100 python scripts/band_profile.py split_f16 7 > gpurun_out/r3e/band_split.jsonl 2> gpurun_out/r3e/band_split.err
-timeout 150 python scripts/shape_times.py f32 20 > gpurun_out/r3e/shapes_f32.jsonl 2> gpurun_out/r3e/shapes_f32.err
-timeout 100 python scripts/shape_times.py split_f16 20 > gpurun_out/r3e/shapes_split.jsonl 2> gpurun_out/r3e/shapes_split.err
-fi
+mkdir -p gpurun_out/r3i
+bash scripts/profile.sh r3_f32 --precision f32 > gpurun_out/r3i/prof_f32.txt 2>&1
+bash scripts/profile.sh r3_split --precision split_f16 > gpurun_out/r3i/prof_split.txt 2>&1
+python scripts/merge_pmc.py gpurun_out/prof_r3_f32/summary.json gpurun_out/prof_r3_split/summary.json > gpurun_out/r3i/merge.txt 2>&1
+cp profiles/pmc_latest.json gpurun_out/r3i/pmc_latest.json
+find gpurun_out/prof_r3_f32 gpurun_out/prof_r3_split -name "*kernel_trace.csv" -size +5M -delete
+find gpurun_out/prof_r3_f32 gpurun_out/prof_r3_split -name "*counter_collection.csv" -size +5M -delete
+timeout 400 python bench.py --steps 20 --warmup 3 > gpurun_out/r3i/bench.json 2> gpurun_out/r3i/bench.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r3i/trace_band8 -o t -- python $GRAFT_REPO_ROOT/scripts/band_profile.py f32 30 --once 8 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+find gpurun_out/r3i/trace_band8 -name "*kernel_trace.csv" -delete
+grep -A12 "kernel-trace --stats" gpurun_out/r3i/prof_f32.txt | head -14
+grep "MFMA busy\|^void\|^conv" gpurun_out/r3i/prof_split.txt | head -30

@@ -16,7 +16,7 @@ for path, precision in ((sys.argv[1], "f32"), (sys.argv[2], "split_f16")):
     d = json.load(open(path))
     for stage in range(5):
         names = [n for n in d if bench.kernel_matches(n, stage, precision)]
-        names.sort(key=lambda n: 0 if "_col_" in n else 1 if "pipe" in n else 2)
+        names.sort(key=lambda n: 0 if "pipe" in n else 1)
         if names:
             merged[names[0]] = d[names[0]]
 json.dump(merged, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
