@@ -2,8 +2,9 @@
 """Lint of the device assembly: a VGPR that an inline-asm VMEM instruction returns into asynchronously (the queue's
 returning atomic, the head snapshot, the final stage's pixel prefetch) must not be READ before an s_waitcnt vmcnt -- the
 compiler does not know those asm outputs land later and is free to copy them at once (it did, when such a register was
-live across the merge of the two tile bodies: round 3, a hang).  Linear scan from each such instruction to the next
-s_waitcnt vmcnt in layout order; flags any instruction that names the register as a source.
+live across the merge of the two tile bodies: round 3, a hang).  Scan from each such instruction to the next s_waitcnt
+vmcnt along the path the wave takes (unconditional branches followed, conditional ones fall through); flags any instruction
+that names the register as a source.
 
     python scripts/check_async_regs.py [file.s]      (without an argument: compiles sr_kernels.hip to assembly, ~90 s)
 Exit status 1 when something is flagged."""
@@ -36,6 +37,11 @@ def main():
                                "--cuda-device-only", os.path.join(ROOT, "rusty_sr_amd", "csrc", "sr_kernels.hip"), "-o", path],
                               stderr=subprocess.DEVNULL)
     lines = open(path).read().split("\n")
+    labels = {}
+    for i, l in enumerate(lines):  # (labels are unique within the file: .LBB<function>_<block>)
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
     bad, checked, inasm, func = 0, 0, False, "?"
     for i, l in enumerate(lines):
         if l.startswith("_Z") and l.rstrip().endswith(("Args:", "Args")) or re.match(r"^_Z\w+:", l):
@@ -49,9 +55,17 @@ def main():
             continue
         checked += 1
         dst = int(m.group(2)[1:])
-        for j in range(i + 1, min(i + 4000, len(lines))):
+        j, steps = i, 0
+        while steps < 4000 and j + 1 < len(lines):
+            j += 1
+            steps += 1
             t = lines[j].split(";")[0].strip()
             if not t or t.endswith(":") or t.startswith("."):
+                continue
+            if t.startswith("s_branch "):  # follow the path the wave takes (conditional branches: the fall-through)
+                tgt = t.split()[1]
+                if tgt in labels:
+                    j = labels[tgt]
                 continue
             if t.startswith("s_waitcnt") and "vmcnt" in t:
                 break
