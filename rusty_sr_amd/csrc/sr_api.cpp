@@ -227,8 +227,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[7][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
-                                              {"chain", "SRHIP_CHAIN"}, {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}};
+    static const char* const kSwitch[6][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
+                                              {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
     {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
@@ -308,10 +308,7 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
             c->off_bias[4] = push(eb);
         }
         mark("weight packing (host)");
-        for (auto& w : c->ws) {
-            HIPCHK(c, hipMalloc((void**)&w.d_queue, kChainQueueInts * sizeof(int)));
-            HIPCHK(c, hipMemset(w.d_queue, 0, kChainQueueInts * sizeof(int)));
-        }
+        for (auto& w : c->ws) HIPCHK(c, hipMalloc((void**)&w.d_queue, 5 * 8 * sizeof(int)));
 
         HIPCHK(c, hipMalloc((void**)&c->d_params, host.size() * sizeof(float)));
         mark("hipMalloc x3");
@@ -337,7 +334,6 @@ void sr_destroy(sr_ctx* c) {
     for (auto& w : c->ws) {
         for (auto& p : w.d_feat) if (p) (void)hipFree(p);
         if (w.d_queue) (void)hipFree(w.d_queue);
-        if (w.d_flags) (void)hipFree(w.d_flags);
     }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->d_params) (void)hipFree(c->d_params);
@@ -377,8 +373,6 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
         c->env_bands = *v ? atoi(v) : 0;
     } else if (!strcmp(key, "geo")) {  // "0": equal bands also where the host pipeline would shrink them geometrically
         c->env_geo = strcmp(v, "0") != 0;
-    } else if (!strcmp(key, "chain")) {  // "0": one launch per stage; "": automatic; N > 0: stages 1-4 in one persistent launch, pieces published every N tiles
-        c->env_chain = *v ? std::min(240, std::max(0, atoi(v))) : -1;
     } else if (!strcmp(key, "tail")) {  // how many 4-row tiles end a launch of 8-row tiles, in units of the resident workgroups ("" : automatic, "0": none)
         c->env_tail = *v ? (float)atof(v) : -1.0f;
     } else if (!strcmp(key, "bw")) {   // tile-order column-block width in tiles; "" / negative: automatic, 0: plain row-major
@@ -568,44 +562,6 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
         l.grid = l.pipe ? std::min(ntiles, resident) : ntiles;
     }
     static const bool trace_stages = [] { const char* e = getenv("SRHIP_TRACE"); return e && atoi(e) >= 2; }();
-    // Stages 1-4 as ONE persistent launch (conv_chain_kernel) when all four run the pipe form at factor 3: no launch boundary,
-    // no fill and drain per stage.  Per-stage profiling (sr_set_profiling) needs the boundaries and keeps them.
-    const bool chain = c->env_chain != 0 && c->factor == 3 && !prof && L[1].pipe && L[2].pipe && L[3].pipe && L[4].pipe;
-    if (chain) {
-        // completion flags: one word per (4-row unit, tile column) of l1, l2, l3
-        const size_t words = (size_t)n * ((size_t)H / 4 + 8) * tiles_x;
-        if (words > ws.flags_cap) {
-            if (ws.d_flags) HIPCHK(c, hipFree(ws.d_flags));
-            ws.d_flags = nullptr; ws.flags_cap = 0;
-            HIPCHK(c, hipMalloc((void**)&ws.d_flags, 3 * words * sizeof(uint32_t)));
-            HIPCHK(c, hipMemsetAsync(ws.d_flags, 0, 3 * words * sizeof(uint32_t), s));
-            ws.flags_cap = words; ws.epoch = 0;
-        }
-        if (++ws.epoch == 0) {  // wrapped: start over from clean flags
-            HIPCHK(c, hipMemsetAsync(ws.d_flags, 0, 3 * ws.flags_cap * sizeof(uint32_t), s));
-            ws.epoch = 1;
-        }
-    }
-    auto stage_args = [&](int st) {
-        const Launch& l = L[st];
-        StageArgs a{};
-        float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
-        a.pitch = ws.pitch; a.img_stride = ws.img_stride;
-        switch (st) {
-            case 1: a.src[0] = f; a.dst = l1; break;
-            case 2: a.src[0] = f; a.src[1] = l1; a.dst = l2; break;
-            case 3: a.src[0] = f; a.src[1] = l1; a.src[2] = l2; a.dst = l3; break;
-            case 4: a.src[0] = l1; a.src[1] = l2; a.src[2] = l3; a.img = d_img; a.out = d_out; break;
-        }
-        a.wpack = P + (c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
-        a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
-        a.H = H; a.W = W; a.img_ch = img_ch;
-        a.y_begin = l.y0; a.y_end = l.y1; a.tiles_x = tiles_x;
-        a.n_img = n; a.queue = ws.d_queue + st * 8;
-        a.grid[0] = make_tile_grid(8, l.y0, l.ty8, tiles_x, n, bw);
-        a.grid[1] = make_tile_grid(4, l.y0 + 8 * l.ty8, l.ty4, tiles_x, n, bw);
-        return a;
-    };
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
         const Launch& l = L[st];
@@ -620,20 +576,25 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
             a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
             a.n_tiles = n * tiles_x * tiles_y;
             a.queue_reset = ws.d_queue;
-            for (int k = 1; k < 5; ++k) a.queue_grid[k] = chain ? 0 : L[k].grid;  // (a chained launch hands out its first tiles too)
+            for (int k = 1; k < 5; ++k) a.queue_grid[k] = L[k].grid;
             HIPCHK(c, sr_launch_conv0(a, l.th, c->precision, std::min(a.n_tiles, 8 * cus), img_u8, s));
-        } else if (chain) {
-            if (st == 1) {
-                ChainArgs ca{};
-                int grid = 0;
-                for (int k = 1; k < 5; ++k) { ca.st[k - 1] = stage_args(k); grid = std::max(grid, L[k].grid); }
-                for (int k = 0; k < 3; ++k) ca.flags[k] = ws.d_flags + k * ws.flags_cap;
-                ca.exited = ws.d_queue + 40; ca.abort = ws.d_queue + 44; ca.epoch = ws.epoch;
-                ca.period = c->env_chain > 0 ? c->env_chain : 32;
-                HIPCHK(c, sr_launch_chain(ca, c->precision, grid, img_u8, out_u8, s));
-            }
         } else {
-            const StageArgs a = stage_args(st);
+            StageArgs a{};
+            float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
+            a.pitch = ws.pitch; a.img_stride = ws.img_stride;
+            switch (st) {
+                case 1: a.src[0] = f; a.dst = l1; break;
+                case 2: a.src[0] = f; a.src[1] = l1; a.dst = l2; break;
+                case 3: a.src[0] = f; a.src[1] = l1; a.src[2] = l2; a.dst = l3; break;
+                case 4: a.src[0] = l1; a.src[1] = l2; a.src[2] = l3; a.img = d_img; a.out = d_out; break;
+            }
+            a.wpack = P + (c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
+            a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
+            a.H = H; a.W = W; a.img_ch = img_ch;
+            a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x;
+            a.n_img = n; a.queue = ws.d_queue + st * 8;
+            a.grid[0] = make_tile_grid(8, y0, l.ty8, tiles_x, n, bw);
+            a.grid[1] = make_tile_grid(4, y0 + 8 * l.ty8, l.ty4, tiles_x, n, bw);
             if (l.pipe) {
                 HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, l.grid, img_u8, out_u8, s));
             } else {
@@ -642,17 +603,9 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
         }
         if (prof) HIPCHK(c, hipEventRecord(c->ev[st + 1], s));
         if (trace_stages) {  // SRHIP_TRACE=2: which launch a hang or a fault belongs to
-            fprintf(stderr, "[srhip] stage %d launched: rows [%d,%d) th8 x%d th4 x%d grid %d %s%s ... ", st, l.y0, l.y1, l.ty8, l.ty4, l.grid, l.pipe ? "pipe" : "first",
-                    chain && st ? (st == 1 ? " (chained: stages 1-4)" : " (in the chain)") : "");
+            fprintf(stderr, "[srhip] stage %d launched: rows [%d,%d) th8 x%d th4 x%d grid %d %s ... ", st, l.y0, l.y1, l.ty8, l.ty4, l.grid, l.pipe ? "pipe" : "first");
             const hipError_t e = hipStreamSynchronize(s);
-            int ab[4] = {0, 0, 0, 0};
-            if (e == hipSuccess && chain && st == 4) {
-                (void)hipMemcpy(ab, ws.d_queue + 44, sizeof(ab), hipMemcpyDeviceToHost);
-                (void)hipMemset(ws.d_queue + 45, 0, 3 * sizeof(int));
-            }
-            fprintf(stderr, "%s%s", e == hipSuccess ? "done" : hipGetErrorString(e), ab[0] ? "  [chain: a dependency wait ran into its bound]" : "");
-            if (chain && st == 4) fprintf(stderr, "  [chain: %d blocking waits, %d polls in them, %d ended by 'stage over']", ab[1], ab[2], ab[3]);
-            fprintf(stderr, "\n");
+            fprintf(stderr, "%s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
         }
     }
     c->last_h = H; c->last_w = W;

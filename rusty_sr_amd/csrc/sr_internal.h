@@ -25,11 +25,7 @@ struct sr_ctx {
         size_t feat_cap_px = 0;       // allocated padded pixels per map
         int geo_n = 0, geo_h = 0, geo_w = 0;  // geometry the borders were last zeroed for
         int pitch = 0; long img_stride = 0;
-        int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels), then the chained launch's
-                                      // exit counters [4] and its abort word (kChainQueueInts in all)
-        uint32_t* d_flags = nullptr;  // chained launch: completion flags of stages 1..3, flags_cap words each
-        size_t flags_cap = 0;
-        uint32_t epoch = 0;           // what a flag of the current call holds (flags start at 0, epochs at 1)
+        int* d_queue = nullptr;       // 5 stages x 8 per-XCD tile-queue heads (persistent kernels)
     } ws[2];
     hipStream_t stream2 = nullptr;    // second compute stream of the host pipeline
     // host-pointer entry points: two in / out slots so that chunk i+1 uploads and chunk i-1
@@ -51,8 +47,6 @@ struct sr_ctx {
     int env_th[5] = {0, 0, 0, 0, 0};  // 0: automatic
     int env_pipe = 1;                 // 0: first form everywhere, 1: pipe form except for small launches, 2: pipe form everywhere
     int env_bw = -1;                  // tile-order column-block width in tiles (-1: automatic)
-    int env_chain = -1;               // 0: one launch per stage always; else stages 1-4 chained in one launch where all run the pipe
-                                      // form, pieces published every env_chain tiles (-1: automatic)
     float env_tail = -1.0f;           // 4-row tiles at the end of a launch, in resident workgroups (< 0: automatic 1.5, 0: none)
     int env_bands = 0;                // host pipeline: forced number of row bands (0: automatic)
     bool env_geo = true;              // host pipeline: geometric band plan where the call is compute-bound

@@ -87,20 +87,6 @@ struct StageArgs {
     int* queue;           // persistent forms: 8 per-XCD tile-queue heads, set by conv0 (Conv0Args::queue_grid)
 };
 
-// Stages 1..4 of one call as ONE persistent launch (conv_chain_kernel, sr_kernels.hip): what the launch boundaries
-// guaranteed is tracked per piece of a stage's output instead.
-struct ChainArgs {
-    StageArgs st[4];       // stages 1..4
-    uint32_t* flags[3];    // completion flags of stages 1..3: [image][unit row][tile column]
-    int* exited;           // [4] workgroups that have left stage 1..4 (reset by conv0 with the queue heads)
-    int* abort;            // set (sticky) when a dependency wait ran into its bound: results are then invalid
-    uint32_t epoch;        // what a flag of THIS call holds
-    int period;            // a workgroup publishes its finished pieces every `period` tiles (and at the end of a stage); <= 240
-};
-
-hipError_t sr_launch_chain(const ChainArgs& c, int prec, int grid, bool img_u8, bool out_u8, hipStream_t s);
-constexpr int kChainQueueInts = 40 + 8;  // 5 x 8 queue heads, then exited[4], abort, spare: what conv0 resets (not abort)
-
 // Feature maps live in HBM with a zero border so tile staging never tests bounds:
 // rows [-kFeatPad, H + kFeatPadBottom), columns [-kFeatPad, pitch - kFeatPad); kernels only
 // ever store inside [0,H) x [0,W), so the border keeps the reference's zero padding.

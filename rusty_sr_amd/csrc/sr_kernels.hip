@@ -238,7 +238,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     // the tile-queue heads of this call's four stage kernels: entry b / 8 of queue b % 8 belongs to workgroup b of that launch
     // without asking (queue_first), so a head starts at the number of such workgroups; visible to the later launches by stream order
     if (blockIdx.x == 0 && tid < 40) a.queue_reset[tid] = (a.queue_grid[tid >> 3] - (tid & 7) + 7) >> 3;
-    if (blockIdx.x == 0 && tid >= 40 && tid < 44) a.queue_reset[tid] = 0;  // the chained launch's per-stage exit counters
     // img_to_data (main.rs:170) is u8 / 255 with a true division; one table entry per byte value replaces
     // ~10 VALU instructions per sample (the f32 MFMA shares the vector ALU)
     __shared__ float s_lut[256];
@@ -1227,71 +1226,8 @@ struct PipeStream {
     }
 };
 
-// ---- stages chained inside one launch -------------------------------------------------------------------------
-// What a launch loses at its boundaries -- the fill of its first tiles, the spread of its workgroups' finishing times, the
-// L2 write-back and the dispatch of the next grid -- is ~12 us + a third of a tile time per stage launch (profiles/
-// r3_band_profile_*, r3_queuefix_*: 139 us per call on a 3840-px-wide image, whatever its height).  conv_chain_kernel runs
-// the four stage bodies back to back in ONE persistent launch: a workgroup that finds stage s's queue dry moves on to
-// stage s+1 at once.  What a launch boundary guaranteed is now tracked per tile:
-//  * flags: one word per (4-row unit, tile column) of a stage's output, holding the call's epoch once that piece is
-//    complete AND visible;
-//  * a workgroup does not publish tile by tile (the release -- buffer_wbl2 sc1 -- costs microseconds): finished pieces wait
-//    in a small LDS list that is published every kChainPeriod tiles, when the workgroup learns that its current tile is its
-//    last one of the stage, and when it leaves the stage;
-//  * a consumer looks at the <= 12 flags around a tile (the rows it gathers: its own +- 1) only while the producer stage
-//    is still draining; once every workgroup has left that stage (a counter) it stops looking.  The look for the NEXT
-//    tile is taken early in the current one; if the answer is "not yet", the next tile's first gather is simply not
-//    prefetched and the workgroup waits (bounded) after its epilogue.
-// Stage s reads stage s-1's output one pixel around its tile, and everything older through it (l2's tiles around T being
-// complete implies l1's and f's around T are: they were complete before l2's were computed), so one set of flags per stage
-// is enough.  No deadlock: stage 1 waits for nothing inside the launch, tiles are only ever pulled by running workgroups
-// (first tiles included, in this mode), and a workgroup waits only for tiles of the stage before its own.
-__device__ __forceinline__ int chain_units(const StageArgs& a) { return 2 * a.grid[0].tiles_y + a.grid[1].tiles_y; }
-
-// Wave 0: are the producer's pieces under the rows [y0 - 1, y0 + th] x columns [x0 - 32, x0 + 63] of consumer tile
-// (n, y0, x0) published?  bit 0: yes; bit 1: the producer stage is over altogether.
-__device__ __forceinline__ int chain_poll(const StageArgs& a, const StageArgs& prev, const uint32_t* flags, const int* prev_exited,
-                                          uint32_t epoch, int n, int y0, int th, int x0, int lane) {
-    const int yb = prev.y_begin, ye = prev.y_end, U = chain_units(prev);
-    const int ylast = min(y0 + th, a.y_end);                 // one past the last row this tile really produces
-    const int ylo = max(y0 - 1, yb), yhi = min(ylast, ye - 1);
-    const int ulo = (ylo - yb) >> 2, uhi = (yhi - yb) >> 2;  // at most four 4-row units
-    const int u = ulo + lane / 3, tx = (x0 >> 5) + lane % 3 - 1;
-    uint32_t v = epoch;
-    if (lane < 12 && u <= uhi && tx >= 0 && tx < a.tiles_x)
-        v = __hip_atomic_load(flags + ((size_t)n * U + u) * a.tiles_x + tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int e = 0;
-    if (lane == 12) e = __hip_atomic_load(prev_exited, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool ready = __builtin_amdgcn_ballot_w64(v != epoch) == 0;
-    const bool over = __builtin_amdgcn_readlane(e, 12) >= (int)gridDim.x;
-    return (ready || over ? 1 : 0) | (over ? 2 : 0);
-}
-
-// Wave 0, after every wave of the workgroup has drained its stores (vmcnt(0)) and passed a barrier: make the listed
-// pieces visible device-wide, then flag them.  Entry: flag index | (two consecutive unit rows ? 1 << 31 : 0).
-__device__ __forceinline__ void chain_publish(uint32_t* flags, const volatile int* list, int n, uint32_t epoch, int tiles_x, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the wait behind buffer_wbl2: MI355X_MICROARCH.md)
-    for (int k = lane; k < n; k += 64) {
-        const uint32_t e = (uint32_t)list[k];
-        uint32_t* f = flags + (e & 0x7fffffffu);
-        __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e >> 31) __hip_atomic_store(f + tiles_x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-constexpr int kChainList = 240;      // capacity of the LDS list of finished, unpublished pieces
-// (ChainArgs::period: how many a workgroup holds back before it publishes anyway -- the first tiles of the next stage need
-// pieces finished long ago, by workgroups that are nowhere near their last tile)
-constexpr int kChainSpin = 1 << 22;  // polls (>= 64 cycles apart) before a wait gives up: seconds
-
-// The body of a pipe-form stage launch.  CHAIN = false: the whole kernel (conv_stage_pipe_kernel).  CHAIN = true: one
-// stage of conv_chain_kernel; `prev` / `wflags` / `prev_exited` describe the stage it reads (wflags == nullptr: none
-// inside this launch), `dflags` where it publishes (nullptr: nobody waits for it).
-template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, int FACTOR, bool CHAIN>
-__device__ __forceinline__ void stage_pipe_body(const StageArgs& a, char* smem, const StageArgs* prev, const uint32_t* wflags,
-                                                uint32_t* dflags, const int* prev_exited, int* my_exited, int* abortp, uint32_t epoch,
-                                                int period) {
+template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, int FACTOR = 3>
+__global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     __builtin_amdgcn_s_setprio(3);
     constexpr int NTN = FINAL ? (FACTOR * FACTOR + 9) / 10 : 1;  // N-tiles of the node (expand at factor 4: 48 channels = 2)
     using H0 = HalfTile<KS0>;
@@ -1299,12 +1235,10 @@ __device__ __forceinline__ void stage_pipe_body(const StageArgs& a, char* smem, 
     constexpr int HB = H0::BYTES;  // KS0 >= 3: the first source has the largest half tile
     constexpr int NH = 2 * NSRC;
     constexpr int NSTEPS = 2 * (H0::STEPS + (NSRC - 1) * H3::STEPS) * NTN;  // weight chunks per tile: one per (step, N-tile)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem + 2 * HB;
-    volatile int* s_next = (volatile int*)(ring + kRingBytes);          // mailbox: the next tile's number
-    volatile int* s_dep = (volatile int*)(ring + kRingBytes + 4);       // mailbox (chain): what wave 0's look at the flags said
+    volatile int* s_next = (volatile int*)(ring + kRingBytes);
     float* s_wlin = (float*)(ring + kRingBytes + 16);  // final stage: the 9 x 128 fixed weights of the bilinear taps, loaded once
-    volatile int* s_list = (volatile int*)(ring + kRingBytes + 16);     // other stages of a chain: finished, not yet published pieces
-    static_assert(!(CHAIN && FINAL && false), "");
     const uint32_t lds0 = lds_addr(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1321,7 +1255,7 @@ __device__ __forceinline__ void stage_pipe_body(const StageArgs& a, char* smem, 
     h0.init(a.pitch, lane);
     if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
 
-    // combined tile id (queue_slot) -> image, tile origin, tile class
+    // combined tile id (queue_resolve) -> image, tile origin, tile class
     auto coords = [&](int t, int& n, int& x0, int& y0, bool& small) {
         int tx, ty;
         small = t >= nbig;
@@ -1335,94 +1269,17 @@ __device__ __forceinline__ void stage_pipe_body(const StageArgs& a, char* smem, 
         x0 = tx * kTW;
     };
 
-    if constexpr (CHAIN) __syncthreads();  // the stage before is through with the LDS in every wave
     if constexpr (FINAL) {  // (read after the tile's steps, many barriers later)
         const float* wlin = a.wpack + (size_t)NSTEPS * kChunkFloats;
         for (int k = tid; k < 9 * NTN * 128; k += 256) s_wlin[k] = wlin[k];
     }
-    int first;
-    if constexpr (CHAIN) {
-        // no workgroup owns a tile it has not asked for: one that is not resident yet (another kernel holds its slot) must
-        // not be waited for by the others
-        if (wave == 0) {
-            int j = 0;
-            if (lane == 0) j = atomicAdd(&a.queue[xcd], 1);
-            int t = queue_slot(xcd, nbig, nsmall, __builtin_amdgcn_readfirstlane(j));
-            for (int k = 1; k < 8 && t < 0; ++k) {
-                const int x = (xcd + k) & 7;
-                int j2 = 0;
-                if (lane == 0) j2 = atomicAdd(&a.queue[x], 1);
-                t = queue_slot(x, nbig, nsmall, __builtin_amdgcn_readfirstlane(j2));
-            }
-            if (lane == 0) *s_next = t;
-        }
-        __syncthreads();
-        first = __builtin_amdgcn_readfirstlane(*s_next);
-    } else {
-        first = queue_first(blockIdx.x, nbig, nsmall);
-        if (first < 0) return;
-    }
+    const int first = queue_first(blockIdx.x, nbig, nsmall);
+    if (first < 0) return;
     // a launch with a workgroup per tile (small images) has no queue to ask: its tile is the workgroup's only one
-    const bool single = !CHAIN && (int)gridDim.x >= nbig + nsmall;
-    bool deps_done = !CHAIN || wflags == nullptr;  // nothing (more) to wait for in the stage this one reads
-    int npend = 0;                                 // pieces in s_list (chain; the same number in every wave)
-
-    // Chain: block until the producer's pieces around tile (n, y0, x0) are published (bounded), then acquire.
-    auto wait_deps = [&](int n, int y0, int th, int x0) {
-        if constexpr (CHAIN) {
-            if (deps_done) return;
-            if (wave == 0) {
-                int r = 0, spins = 0;
-                auto spin_count = [&](int) { return spins; };
-                for (int spin = 0; spin < kChainSpin; ++spin) {
-                    r = chain_poll(a, *prev, wflags, prev_exited, epoch, n, y0, th, x0, lane);
-                    spins = spin;
-                    if (r & 1) break;
-                    if ((spin & 1023) == 1023 && __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                if (!(r & 1) && lane == 0) __hip_atomic_store(abortp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0) {  // statistics (SRHIP_TRACE=2 prints them): blocking waits, polls spent in them, waits ended by "stage over"
-                    __hip_atomic_fetch_add(abortp + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(abortp + 2, spin_count(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (r & 2) __hip_atomic_fetch_add(abortp + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (lane == 0) *s_dep = r;
-            }
-            __syncthreads();
-            if (__builtin_amdgcn_readfirstlane(*s_dep) & 2) deps_done = true;
-        }
-    };
-    // Chain: note tile (n, y0, x0) as finished.
-    auto note_done = [&](int n, int y0, int x0, bool small) {
-        if constexpr (CHAIN) {
-            if (dflags == nullptr) return;
-            if (tid == 0) {
-                const int u = small ? 2 * a.grid[0].tiles_y + ((y0 - a.grid[1].y0) >> 2) : 2 * ((y0 - a.grid[0].y0) >> 3);
-                s_list[npend] = (int)(((uint32_t)((size_t)n * chain_units(a) + u) * (uint32_t)a.tiles_x + (uint32_t)(x0 >> 5)) | (small ? 0u : 0x80000000u));
-            }
-            ++npend;
-        }
-    };
-    // Chain: publish the list.  Every wave calls it at the same point.
-    auto publish = [&]() {
-        if constexpr (CHAIN) {
-            if (dflags == nullptr || npend == 0) return;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's stores of those tiles have left
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (wave == 0) chain_publish(dflags, s_list, npend, epoch, a.tiles_x, lane);
-            npend = 0;
-            // (the list may be written again at once: its next writer, thread 0, is in the wave that has just read it)
-        }
-    };
-
-    if (first >= 0) {
+    const bool single = (int)gridDim.x >= nbig + nsmall;
     int n, x0, y0;
     bool small;
     coords(first, n, x0, y0, small);
-    wait_deps(n, y0, small ? 4 : 8, x0);
     // first tile only: its first half and the first weight chunks are requested here; every later tile finds
     // them already on the way (requested by the last half / the last steps of the tile before)
     h0.template stage<PREC>(lds0, a.src[0], 0, a.img_stride, a.pitch, n, y0, x0, wave);
@@ -1437,7 +1294,6 @@ __device__ __forceinline__ void stage_pipe_body(const StageArgs& a, char* smem, 
 
     int nn = 0, nx0 = 0, ny0 = 0;  // the tile after this one (known from half 1 on)
     bool nsmall_tile = false;
-    bool prefetched = true;        // chain: the next tile's first half is on its way (else: wait_deps + gather after this tile)
 
     // One tile: T tile rows per wave (2: an 8-row tile, 1: a 4-row tile in the first rows of the same buffers).
     auto tile_body = [&](auto tc) {
@@ -1457,7 +1313,6 @@ __device__ __forceinline__ void stage_pipe_body(const StageArgs& a, char* smem, 
         QueueState qs{0u, 0u, 0, 0, -1};
         if (!single) queue_pull_async(a, xcd, wave, lane, st, qs);  // the answer is looked at towards the end of half 0
         st.have_next = false;  // not known yet: nothing of the next tile is requested before half 1
-        prefetched = true;
         LinPrefetch<IMG_U8, TH> linpx;
         auto do_half = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -1470,29 +1325,12 @@ __device__ __forceinline__ void stage_pipe_body(const StageArgs& a, char* smem, 
                 const int next = single ? -1 : __builtin_amdgcn_readfirstlane(*s_next);
                 st.have_next = next >= 0;
                 if (st.have_next) coords(next, nn, nx0, ny0, nsmall_tile);
-                if constexpr (CHAIN) {
-                    // this tile is the workgroup's last one of the stage: everything it finished before goes public now
-                    if (!st.have_next) publish();
-                    // a first look at what the next tile needs (the answer is read at the start of the last half)
-                    if (st.have_next && !deps_done && wave == 0) {
-                        const int r = chain_poll(a, *prev, wflags, prev_exited, epoch, nn, ny0, nsmall_tile ? 4 : 8, nx0, lane);
-                        if (r & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        if (lane == 0) *s_dep = r;
-                    }
-                }
-            }
-            if constexpr (CHAIN && j == NH - 1 && NH > 2) {
-                if (st.have_next && !deps_done) {
-                    const int r = __builtin_amdgcn_readfirstlane(*s_dep);
-                    prefetched = (r & 1) != 0;
-                    if (r & 2) deps_done = true;
-                }
             }
             // half j+1 of this tile, or the next tile's half 0, goes into the buffer half j-1 has just left; a 4-row tile
             // needs only the first NG_SMALL gather groups of it
             HalfRequest rq;
             if constexpr (j + 1 < NH) rq = HalfRequest{T == 2 ? HalfTile<KSN>::G::NG : HalfTile<KSN>::NG_SMALL, other, a.src[(j + 1) >> 1], (j + 1) & 1, n, y0, x0};
-            else rq = HalfRequest{!(st.have_next && prefetched) ? 0 : nsmall_tile ? HalfTile<KSN>::NG_SMALL : HalfTile<KSN>::G::NG, other, a.src[0], 0, nn, ny0, nx0};
+            else rq = HalfRequest{!st.have_next ? 0 : nsmall_tile ? HalfTile<KSN>::NG_SMALL : HalfTile<KSN>::G::NG, other, a.src[0], 0, nn, ny0, nx0};
             if constexpr (FINAL && j == NH - 1) linpx.issue(a, n, y0, x0, tid, st);
             const HalfTile<KSN>* htn;
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
@@ -1525,48 +1363,10 @@ __device__ __forceinline__ void stage_pipe_body(const StageArgs& a, char* smem, 
     while (true) {
         if (small) tile_body(std::integral_constant<int, 1>{});
         else tile_body(std::integral_constant<int, 2>{});
-        note_done(n, y0, x0, small);
         if (!st.have_next || --budget <= 0) break;
-        if constexpr (CHAIN) {
-            if (npend >= period) publish();
-            if (!prefetched) {
-                // the next tile's producers were not through when this tile looked: wait for them now, then fetch its first
-                // half (its first weight chunks are on their way already: the last steps asked for them)
-                wait_deps(nn, ny0, nsmall_tile ? 4 : 8, nx0);
-                h0.template stage<PREC>(lds0, a.src[0], 0, a.img_stride, a.pitch, nn, ny0, nx0, wave);
-                st.issued += NG0;
-                st.tile_seq = st.issued;
-                wait_vm_barrier<0>(0);
-            }
-        }
         n = nn; x0 = nx0; y0 = ny0; small = nsmall_tile;
     }
-    }  // first >= 0
-    if constexpr (CHAIN) {
-        // leaving the stage: the last tile(s) go public, then the stage's counter (what lets the consumers stop looking)
-        publish();
-        if (dflags != nullptr || my_exited != nullptr) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // no DMA of this stage is in flight, no flag store either
-            __builtin_amdgcn_s_barrier();
-            if (tid == 0 && my_exited) __hip_atomic_fetch_add(my_exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     // (nothing is in flight towards LDS here: the last tile requested no successor; s_endpgm waits for the stores)
-}
-
-template <int NSRC, int KS0, bool FINAL, bool IMG_U8, bool OUT_U8, int PREC, int FACTOR = 3>
-__global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    stage_pipe_body<NSRC, KS0, FINAL, IMG_U8, OUT_U8, PREC, FACTOR, false>(a, smem, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0);
-}
-
-template <bool IMG_U8, bool OUT_U8, int PREC>
-__global__ __launch_bounds__(256, 2) void conv_chain_kernel(ChainArgs c) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    stage_pipe_body<1, 5, false, false, false, PREC, 3, true>(c.st[0], smem, nullptr, nullptr, c.flags[0], nullptr, c.exited + 0, c.abort, c.epoch, c.period);
-    stage_pipe_body<2, 5, false, false, false, PREC, 3, true>(c.st[1], smem, &c.st[0], c.flags[0], c.flags[1], c.exited + 0, c.exited + 1, c.abort, c.epoch, c.period);
-    stage_pipe_body<3, 5, false, false, false, PREC, 3, true>(c.st[2], smem, &c.st[1], c.flags[1], c.flags[2], c.exited + 1, c.exited + 2, c.abort, c.epoch, c.period);
-    stage_pipe_body<3, 3, true, IMG_U8, OUT_U8, PREC, 3, true>(c.st[3], smem, &c.st[2], c.flags[2], nullptr, c.exited + 2, nullptr, c.abort, c.epoch, c.period);
 }
 
 // ---------------------------------------------------------------------------
@@ -1766,36 +1566,6 @@ static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a,
     }
     return hipErrorInvalidValue;
 }
-// All four stages in one persistent launch (factor 3; every stage on the pipe form).  LDS: the largest stage's (+ the list of
-// unpublished pieces behind the ring).
-hipError_t sr_launch_chain(const ChainArgs& c, int prec, int grid, bool img_u8, bool out_u8, hipStream_t s) {
-    constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kRingBytes + 16 + kChainList * sizeof(int);
-    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 128 * sizeof(float);
-    constexpr size_t lds = lds5 > lds3 ? lds5 : lds3;
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static std::mutex mu;
-    static std::set<std::pair<const void*, int>> configured;
-    auto launch = [&](auto kern) -> hipError_t {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            const auto key = std::make_pair((const void*)kern, dev);
-            if (!configured.count(key)) {
-                e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-                configured.insert(key);
-            }
-        }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, c);
-        return hipGetLastError();
-    };
-    if (img_u8 != out_u8) return hipErrorInvalidValue;
-    if (prec == 0) return img_u8 ? launch(conv_chain_kernel<true, true, 0>) : launch(conv_chain_kernel<false, false, 0>);
-    return img_u8 ? launch(conv_chain_kernel<true, true, 1>) : launch(conv_chain_kernel<false, false, 1>);
-}
-
 hipError_t sr_launch_stage_pipe(int stage, int factor, const StageArgs& a, int prec, int grid, bool img_u8, bool out_u8, hipStream_t s) {
     return prec == 0 ? launch_stage_pipe_t<0>(stage, factor, a, grid, img_u8, out_u8, s)
                      : launch_stage_pipe_t<1>(stage, factor, a, grid, img_u8, out_u8, s);
