@@ -112,7 +112,9 @@ bool decode_gif(const uint8_t* d, size_t len, Image& out, std::string& err) {
         pos += 9;
         if (fw <= 0 || fh <= 0 || fx + fw > sw || fy + fh > sh) { err = "GIF frame outside the screen"; return false; }
         // a few bytes must not buy a gigabyte: the screen may exceed the first frame, but not by orders of magnitude
-        if ((uint64_t)sw * sh > ((uint64_t)1 << 24) && (uint64_t)sw * sh > (uint64_t)fw * fh * 64) { err = "GIF screen far larger than its frame"; return false; }
+        // (16 M pixels = 64 MB of RGBA are allowed whatever the frame; beyond that the screen may be at most 4x the frame, whose
+        // own pixels the LZW stream has to pay for)
+        if ((uint64_t)sw * sh > ((uint64_t)1 << 24) && (uint64_t)sw * sh > (uint64_t)fw * fh * 4) { err = "GIF screen far larger than its frame"; return false; }
         const uint8_t* ct = gct;
         int ct_n = gct_n;
         if (flags & 0x80) {
@@ -303,8 +305,10 @@ bool decode_tiff(const uint8_t* d, size_t len, Image& out, std::string& err) {
         if (!r.ok(offsets[s], counts[s])) { err = "truncated TIFF"; return false; }
         have += counts[s];
     }
-    // no scheme here expands more than ~1032:1 (deflate); refuse a header the data cannot back BEFORE allocating
-    if ((uint64_t)row_bytes * h / 1100 > have + 16) { err = "TIFF data too short"; return false; }
+    // refuse a header the data cannot back BEFORE allocating; the bound is the codec's best case: LZW reaches ~1360:1 on a
+    // long run in a single strip (a 4000x4000 solid grey LZW TIFF from libtiff is 13 KB), deflate 1032:1, PackBits 64:1
+    const uint64_t max_ratio = compression == 5 ? 1500 : compression == 1 ? 1 : compression == 32773 ? 128 : 1100;
+    if ((uint64_t)row_bytes * h / max_ratio > have + 16) { err = "TIFF data too short"; return false; }
     out.w = (int)w; out.h = (int)h;
     out.rgba.assign((size_t)w * h * 4, 255);
     std::vector<uint8_t> strip;

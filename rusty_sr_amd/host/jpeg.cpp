@@ -156,6 +156,7 @@ bool decode_scan(BitReader& br, Comp* comp, const Scan& sc, bool progressive, in
             const int t = decode_sym(br, dc[c.td]);
             if (t < 0 || t > 15) { err = "corrupt JPEG data"; return false; }
             c.pred += extend(br.bits(t), t);
+            if (c.pred < -32768 || c.pred > 32767) { err = "corrupt JPEG data"; return false; }  // (libjpeg warns and goes on; a running sum of crafted differences would overflow)
             co[0] = (int16_t)c.pred;
             for (int k = 1; k < 64;) {
                 const int rs = decode_sym(br, ac[c.ta]);
@@ -174,6 +175,7 @@ bool decode_scan(BitReader& br, Comp* comp, const Scan& sc, bool progressive, in
                 const int t = decode_sym(br, dc[c.td]);
                 if (t < 0 || t > 15) { err = "corrupt JPEG data"; return false; }
                 c.pred += extend(br.bits(t), t);
+                if (c.pred < -32768 || c.pred > 32767) { err = "corrupt JPEG data"; return false; }
                 co[0] = (int16_t)(c.pred * (1 << sc.Al));
             } else if (br.bit()) {
                 co[0] = (int16_t)(co[0] | (1 << sc.Al));
@@ -320,8 +322,8 @@ bool decode_jpeg_memory(const uint8_t* d, size_t len, Image& out, std::string& e
             H = s[1] << 8 | s[2]; W = s[3] << 8 | s[4]; ncomp = s[5];
             if (W <= 0 || H <= 0 || (ncomp != 1 && ncomp != 3) || n < 6 + (size_t)3 * ncomp) { err = "unsupported JPEG frame"; return false; }
             // an 8x8 block costs at least 2 bits of entropy-coded data per component: a frame header that promises more
-            // pixels than the file could possibly hold is refused before anything of that size is allocated (also caps at 2^28 px)
-            if ((uint64_t)W * (uint64_t)H > ((uint64_t)1 << 28) || (uint64_t)W * (uint64_t)H / 256 > (uint64_t)len + 64) { err = "JPEG dimensions do not fit the file"; return false; }
+            // pixels than the file could possibly hold is refused before anything of that size is allocated (also caps at 2^27 px: ~2.5 GB of decoder buffers at most)
+            if ((uint64_t)W * (uint64_t)H > ((uint64_t)1 << 27) || (uint64_t)W * (uint64_t)H / 256 > (uint64_t)len + 64) { err = "JPEG dimensions do not fit the file"; return false; }
             for (int i = 0; i < ncomp; ++i) { comp[i].id = s[6 + 3 * i]; comp[i].h = s[7 + 3 * i] >> 4; comp[i].v = s[7 + 3 * i] & 15; comp[i].tq = s[8 + 3 * i] & 3;
                 if (comp[i].h < 1 || comp[i].h > 4 || comp[i].v < 1 || comp[i].v > 4) { err = "bad JPEG sampling factors"; return false; } }
             // T.81 A.2.2: with ONE component nothing is interleaved -- one data unit per MCU whatever factors the header declares

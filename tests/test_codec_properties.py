@@ -127,3 +127,15 @@ def test_jpeg_both_ways_within_a_few_levels(codec, tmp_path, img, quality, sub, 
     theirs = np.array(Image.open(q).convert("RGB")).astype(int)
     ours = codec.decode(q)[..., :3].astype(int)
     assert np.abs(theirs - ours).mean() < 1.5
+
+
+def test_highly_compressible_lzw_tiff_is_not_refused(codec, tmp_path):
+    """A long run in ONE strip compresses ~1230:1 under LZW (a 4000x4000 solid grey image is 13 KB from libtiff): the
+    "header the data cannot back" guard of the TIFF reader must use the codec's own best case, not deflate's 1032:1."""
+    from PIL import Image
+    p = tmp_path / "solid.tif"
+    Image.new("L", (4000, 4000), 128).save(p, compression="tiff_lzw", tiffinfo={278: 4000})  # RowsPerStrip = the whole image
+    assert os.path.getsize(p) < 40000
+    rgba = codec.decode(str(p))
+    assert rgba is not None and rgba.shape == (4000, 4000, 4)
+    assert (rgba[..., :3] == 128).all() and (rgba[..., 3] == 255).all()
