@@ -972,13 +972,29 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
 // big tile's pixel p does), so the two tile bodies differ in nothing but T, the rows per wave, and the number of
 // gather groups requested; both sum in the same order as the first form, so all forms stay bit-identical.
 // ---------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void wait_vm_barrier(int pending) {  // s_waitcnt vmcnt(pending) lgkmcnt(0); s_barrier
-    switch (pending) {
+// s_waitcnt vmcnt(pending) [lgkmcnt(0)]; s_barrier.  LGKM = false leaves this wave's LDS reads in flight across the
+// barrier.  That is safe at the end of a step: what the next step's DMAs overwrite -- the ring slot of the chunk consumed
+// one step ago, the half-tile buffer the previous half has left -- was read into registers at least one step earlier, and
+// those reads had to return before the MFMAs that consumed them could issue; the reads still in flight are the NEXT
+// step's operands (another ring slot, the current half's buffer).  It matters in the split-half mode, whose step is only
+// 12 x 32 cycles of matrix work: with lgkmcnt(0) a wave sat out one LDS round trip per step in front of the barrier.
+// (A plain LDS WRITE that another wave reads behind the barrier -- the tile queue's mailbox -- waits for itself.)
+template <bool LGKM>
+__device__ __forceinline__ void wait_vm_barrier(int pending) {
+    if constexpr (LGKM) {
+        switch (pending) {
 #define SR_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); break;
-        SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
+            SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
 #undef SR_CASE
-        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        }
+    } else {
+        switch (pending) {
+#define SR_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+            SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
+#undef SR_CASE
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1064,7 +1080,7 @@ __device__ __forceinline__ void step_advance(StepStream& st, bool tile) {
     // after this step's step_request, q[k] is the request of chunk gs + 1 + k
     int need = st.q[EXTRA];
     if (tile && st.tile_seq > need) need = st.tile_seq;
-    wait_vm_barrier<0>(st.issued - need);
+    wait_vm_barrier<EXTRA == 0>(st.issued - need);  // (EXTRA = 1: the split-half loop, which reads a step ahead)
     st.gs = st.gs + 1 == st.nsteps ? 0 : st.gs + 1;
     st.slot = st.slot == kRingSlots - 1 ? 0 : st.slot + 1;
 }
@@ -1188,6 +1204,7 @@ __device__ __forceinline__ void queue_publish(const StageArgs& a, int xcd, int w
         }
     }
     if (lane == 0) *mailbox = t;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the write is in LDS before this wave reaches the barrier its readers wait behind
 }
 
 // Stream of the pipe form: chunks through the ring with sequence-numbered waits, plus a piece of the next half
@@ -1290,7 +1307,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     StepStream st{0, 0, NSTEPS, false, NG0 + kRingAhead, {0, NG0 + 2, NG0 + 3, NG0 + 4}, NG0};
     static_assert(kRingAhead == 4, "q[] initialiser");
     // half 0 and chunk 0 (split: and 1) are in; the later chunks may still be in flight
-    wait_vm_barrier<0>(st.issued - (NG0 + 1 + (PREC == 1 ? 1 : 0)));
+    wait_vm_barrier<true>(st.issued - (NG0 + 1 + (PREC == 1 ? 1 : 0)));
 
     int nn = 0, nx0 = 0, ny0 = 0;  // the tile after this one (known from half 1 on)
     bool nsmall_tile = false;

@@ -1,8 +1,13 @@
 set -u
 export TMPDIR=/tmp
-for cfg in "SRHIP_CHAIN=4" "SRHIP_CHAIN=240"; do
-echo "== $cfg f32 1080p"
-env $cfg SRHIP_TRACE=2 timeout 60 python scripts/run_once.py f32 1080x1920 2 2>&1 | grep "stage 4" | tail -n 3
-echo "== $cfg split 1080p"
-env $cfg SRHIP_TRACE=2 timeout 60 python scripts/run_once.py split_f16 1080x1920 2 2>&1 | grep "stage 4" | tail -n 3
-done
+mkdir -p gpurun_out/r3k
+timeout 150 python scripts/shape_times.py split_f16 20 > gpurun_out/r3k/shapes_split.jsonl 2> gpurun_out/r3k/shapes_split.err
+python - <<'PY'
+import json
+for l in open("gpurun_out/r3k/shapes_split.jsonl"):
+    d = json.loads(l)
+    if d["th"] == "auto" and d["tail"] == "auto": print("split", d["shape"], d["ms"], d["tflops"], d["stage_ms"])
+PY
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_multi.py -m gpu -x -q --durations=8 > gpurun_out/r3k/pytest.log 2>&1
+echo "pytest rc=$?"
+tail -n 16 gpurun_out/r3k/pytest.log
