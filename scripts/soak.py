@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Soak: random shapes, batches and band halos through the pipe / column kernels against the first-form kernels (an
+"""Soak: random shapes, batches and band halos through the library's own plan AND through the pipe form under random tile
+plans (8-row tiles, 4-row tiles, tails of any length, any tile order) against the first-form kernels (an
 independent code path, bit-identical by construction), interleaved so that every call changes the workspace geometry, the
 host-pointer entry point (chunks and bands on two streams) against the device call, plus
 repeated 1080p calls that must reproduce themselves bit for bit (a missed vmcnt / barrier shows up as a flicker).
@@ -23,8 +24,9 @@ def soak(budget, seed=None):
     stats = {"shapes": 0, "repeats": 0, "bands": 0, "host_calls": 0, "sharded": 0}
     bad = []
     for prec in ("f32", "split_f16"):
-        a, b = r.Engine(params, precision=prec), r.Engine(params, precision=prec)
+        a, b, c = r.Engine(params, precision=prec), r.Engine(params, precision=prec), r.Engine(params, precision=prec)
         b.set_experiment("pipe", "none")
+        c.set_experiment("pipe", "all")  # the persistent pipe form on every launch, with a tile plan drawn per call
         group = [r.Engine(params, precision=prec) for _ in range(5)]   # one image sharded over k contexts (local transport)
         group_k = 0
         big = torch.from_numpy(rng.integers(0, 256, (1, 1080, 1920, 3), dtype=np.uint8)).cuda()
@@ -41,6 +43,10 @@ def soak(budget, seed=None):
             ga, gb = a.upscale_rgba8_dev(px), b.upscale_rgba8_dev(px)
             if not torch.equal(ga, gb):
                 bad.append((prec, "shape", n, h, w))
+            plan = (str(rng.choice(["", "", "4", "8"])), str(rng.choice(["", "0", "0.01", "0.4", "2", "7"])), str(rng.choice(["", "0", "3", "16"])))
+            c.set_experiment("th", plan[0]); c.set_experiment("tail", plan[1]); c.set_experiment("bw", plan[2])
+            if not torch.equal(c.upscale_rgba8_dev(px), gb):
+                bad.append((prec, "pipe form, plan th/tail/bw", plan, n, h, w))
             stats["shapes"] += 1
             if n == 1 and h > 30:  # a band of it with halos must equal the same rows of the whole
                 y0 = int(rng.integers(7, h - 15))
@@ -77,6 +83,7 @@ def soak(budget, seed=None):
                 stats["repeats"] += 1
         a.close()
         b.close()
+        c.close()
         for e in group:
             e.close()
     return stats, bad

@@ -1,7 +1,8 @@
-"""A short soak of the stage kernels (scripts/soak.py): random shapes, batches and bands through the pipe / column form
-against the first form -- two code paths that must agree bit for bit -- with a geometry change on every call, and
-repeated 1080p frames that must reproduce themselves (a missed wait or barrier in the LDS-DMA pipeline flickers).
-A 100 s run of the same loop (9 000 shapes, 4 700 bands, 27 000 repeats, no mismatch) is in profiles/r2_soak.log."""
+"""A short soak of the stage kernels (scripts/soak.py): random shapes, batches and bands through the library's own plan and
+through the pipe form under random tile plans (8-row / 4-row tiles, tails, tile orders) against the first form -- code
+paths that must agree bit for bit -- with a geometry change on every call, and repeated 1080p frames that must reproduce
+themselves (a missed wait or barrier in the LDS-DMA pipeline flickers).  340 s of the same loop on the round-3 kernels
+(14 800 shapes, 7 700 bands, 3 700 host calls, 1 500 sharded calls, 44 000 repeats, no mismatch): profiles/r3_soak.log."""
 import os
 import sys
 
