@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the config_A / config_C / config_D entries")
     args = ap.parse_args()
 
+    # (before the HSA runtime comes up: the host driver only supports dmabuf IPC, RCCL's peer connections need this)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import rusty_sr_amd as r
