@@ -411,7 +411,6 @@ __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__
 // exactly the packed chunk order.
 __device__ __forceinline__ void weight_chunk_async(char* ring_slot, const float* __restrict__ chunk,
                                                    int wave, int lane) {
-    if (wave >= 4) return;  // 8-wave workgroups: waves 4-7 have nothing to move (their vmcnt waits pass at once)
     lds_dma16<0>(uniform_ptr((const char*)chunk + wave * 1024), (uint32_t)(lane * 16),
                  __builtin_amdgcn_readfirstlane(lds_addr(ring_slot) + wave * 1024));
 }
