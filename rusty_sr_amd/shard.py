@@ -108,9 +108,16 @@ def init_band_comm(engine, rank: int, world: int, group=None) -> None:
     draws the 128-byte id (ncclGetUniqueId), torch.distributed only carries those bytes to the other ranks.  After
     this, Engine.upscale_sharded_dev exchanges halos without touching torch.distributed at all -- the same calls a
     Rust / C++ host makes."""
-    uid = [engine.comm_unique_id() if rank == 0 and world > 1 else b""]
+    uid, err = [b""], None
+    if rank == 0 and world > 1:
+        try:
+            uid = [engine.comm_unique_id()]
+        except Exception as ex:  # noqa: BLE001 -- the other ranks are about to wait in the broadcast: tell them instead of leaving them there
+            err = ex
     if world > 1:
         dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not uid[0]:
+            raise err if err is not None else RuntimeError("rank 0 could not draw an RCCL unique id (librccl not loadable there?)")
     engine.comm_init_rank(uid[0], rank, world)
 
 
