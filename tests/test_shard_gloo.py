@@ -146,3 +146,45 @@ def test_config_c_band_geometry_gloo(tmp_path, params):
     got = torch.cat([torch.load(os.path.join(tmp_path, f"out{r}.pt")) for r in range(world)]).numpy()
     want = oracle.forward(params["imagenet"], oracle.img_to_data(synth_u8(3, 1, h, w)))[0]
     np.testing.assert_array_equal(got, want)
+
+
+class _FakeEngine:
+    """Stands in for rusty_sr_amd.Engine in init_band_comm: records the calls, fails where told to."""
+
+    def __init__(self, fail_id):
+        self.fail_id, self.joined = fail_id, None
+
+    def comm_unique_id(self):
+        if self.fail_id:
+            raise OSError("librccl.so.1: cannot open shared object file")
+        return bytes(range(128))
+
+    def comm_init_rank(self, uid, rank, world):
+        self.joined = (uid, rank, world)
+
+
+def _id_worker(rank, world, port, fail_id, tmp):
+    from rusty_sr_amd.shard import init_band_comm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = _FakeEngine(fail_id and rank == 0)
+        try:
+            init_band_comm(eng, rank, world)
+            outcome = "joined" if eng.joined == (bytes(range(128)), rank, world) else f"wrong {eng.joined}"
+        except Exception as ex:  # noqa: BLE001
+            outcome = type(ex).__name__
+        with open(os.path.join(tmp, f"id_{rank}.txt"), "w") as f:
+            f.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_id", [False, True])
+def test_band_comm_id_travels_and_a_failure_on_rank_0_reaches_every_rank(tmp_path, fail_id):
+    """init_band_comm: rank 0 draws the RCCL id, torch.distributed carries it; if rank 0 cannot draw one, every rank
+    raises instead of waiting in the broadcast for ever (the first multi-GPU run must fail fast, not hang)."""
+    world = 3
+    mp.spawn(_id_worker, args=(world, _free_port(), fail_id, str(tmp_path)), nprocs=world, join=True)
+    got = [open(tmp_path / f"id_{r}.txt").read() for r in range(world)]
+    assert got == (["OSError", "RuntimeError", "RuntimeError"] if fail_id else ["joined"] * world), got
