@@ -555,13 +555,13 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
                 l.ty4 = std::max(0, (rows - 8 * l.ty8 + 3) / 4);
             }
         }
-        l.th = l.ty8 > 0 ? 8 : 4;  // the one class of conv0 / the first form
-        if (!l.pipe && l.ty8 > 0) { l.ty8 = (rows + 7) / 8; l.ty4 = 0; }
         if (l.ty8 > 0 && l.ty4 > 0 && (long)n * tiles_x * (l.ty8 + l.ty4) <= resident) {
             // (cannot happen with the rules above -- a tail is only added to launches of >= 2 rounds -- but a launch with a workgroup
             // per tile hands out tiles by workgroup number alone, which is only a bijection for ONE tile class)
             l.ty8 = 0; l.ty4 = (rows + 3) / 4;
         }
+        l.th = l.ty8 > 0 ? 8 : 4;  // the one class of conv0 / the first form
+        if (!l.pipe && l.ty8 > 0) { l.ty8 = (rows + 7) / 8; l.ty4 = 0; }
         const int ntiles = n * tiles_x * (l.ty8 + l.ty4);
         // the pipe form is persistent: one workgroup per resident slot, tiles from the queue; the first form one per tile
         l.grid = l.pipe ? std::min(ntiles, resident) : ntiles;
