@@ -221,7 +221,7 @@ int sr_set_precision(sr_ctx* ctx, int mode);
 /* Experiment switches -- none changes a result bit, they exist for A/B timing and for the tests that prove
  * exactly that.  key "th": tile height, value "" (automatic: 8-row tiles ended by 4-row tiles, or 4-row tiles only for
  * small launches), "4" / "8" (all stages) or five digits (one per stage); "tail": how many 4-row tiles end a launch of
- * 8-row tiles, in units of the resident workgroups ("" automatic = 1.5, "0" none); "pipe": "none" forces the first
+ * 8-row tiles, in units of the resident workgroups ("" automatic: 1 where it pays, "0" none); "pipe": "none" forces the first
  * form of the stage kernels (one tile class per launch), "all" the pipe form also for small launches ("" automatic); "bw": width in tiles of the column blocks the tile queue walks
  * ("" automatic, "0" plain row-major); "bands": the host pipeline cuts one large image into that many equal row bands
  * ("" / "0": its own plan); "geo": "0" keeps equal bands where the plan would shrink them geometrically.

@@ -529,12 +529,15 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
         //    workgroup, no queue (256x256: 0.157 ms against 0.176-0.178 on either tile class of the pipe form);
         //  * split-half mode, small launch: the pipe form all the same (256x256: 0.091 ms against 0.24), 8-row tiles while
         //    they still give every CU one, else 4-row tiles;
-        //  * otherwise the pipe form on 8-row tiles, and in exact f32 the LAST tiles of every XCD's queue are 4-row tiles
-        //    (sr_set_experiment "tail") when the last round of 8-row tiles would be less than 70 % full: a persistent
-        //    launch ends when its slowest workgroup does, and half-size last tiles halve what the partly filled round
-        //    costs (8-way band of 3840x2160, 8.2 rounds: -2.3 %; 4-way, 16.2: -0.9 %; 1080p, 15.8 and 512x512, 2.0: none,
-        //    there they only cost their own 3-4 %).  The split-half mode pays 17 % per 4-row tile (its B operands are
-        //    re-read per tile row) and keeps 8-row tiles.
+        //  * otherwise the pipe form on 8-row tiles, and in exact f32 the LAST tiles of every XCD's queue are 4-row tiles, one per
+        //    resident workgroup (sr_set_experiment "tail"): a persistent launch ends when its slowest workgroup does, and with
+        //    half-size last tiles (and stealing) the workgroups finish closer together -- also when the tile count is an exact
+        //    multiple of the workgroups (1024x768, 6.00 rounds: -4.9 %).  Measured, interleaved A/B (profiles/r3_tail_ab.txt):
+        //    800x600 -4.7 %, 1000x600 -4.2 %, 1280x720 -2.4 %, 1920x1200 -1.4 %, the 8- / 4- / 2-way band of 3840x2160 -2.1 /
+        //    -0.3 / -0.4 %, 2560x1440 -0.4 %, 3840x2160 0; but 512x512 (2.0 rounds) +5...9 % and 640x480 (2.3) +2 %: the 4-row
+        //    tile body is code the launch would otherwise never touch (~30 us of cold instruction fetch per call), so no tail below
+        //    3 rounds, and none above 14 rounds when the last round is more than 70 % full anyway (1920x1080, 15.8: 0).  The
+        //    split-half mode pays 17 % per 4-row tile (its B operands are re-read per tile row) and keeps 8-row tiles.
         //  conv0 and the first form run one class.
         const long tiles8 = (long)n * tiles_x * ((rows + 7) / 8);
         const int forced = c->env_th[st];
@@ -547,7 +550,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
         } else if (!forced && l.pipe && !small_launch) {
             const double rounds = (double)tiles8 / resident;
             float tail = c->env_tail;
-            if (tail < 0.0f) tail = (!split && std::ceil(rounds) - rounds > 0.3) ? 0.75f : 0.0f;
+            if (tail < 0.0f) tail = (!split && rounds >= 3.0 && !(rounds > 14.0 && std::ceil(rounds) - rounds <= 0.3)) ? 1.0f : 0.0f;
             if (tail > 0.0f) {
                 const long per_row = (long)n * tiles_x;
                 const int want = (int)((tail * resident + per_row - 1) / per_row);  // tile rows of small tiles
