@@ -347,7 +347,9 @@ def main():
     class Band:
         """This rank's row band of an image sharded over the ranks, resident in HBM, and its step function."""
 
-        def __init__(self, px_band):
+        def __init__(self, px_band, lib=None):
+            lib = use_lib if lib is None else lib
+            self.lib = lib
             hb, w = px_band.shape[:2]
             self.hb, self.w = hb, w
             src = torch.from_numpy(px_band).to(dev)
@@ -356,7 +358,7 @@ def main():
             self.out = torch.empty((3 * hb, 3 * w, 4 if u8 else 3), dtype=dt_in, device=dev)
             self.top = 7 if rank > 0 else 0
             self.bot = 7 if rank < world - 1 else 0
-            if use_lib or world == 1:
+            if lib or world == 1:
                 self.band = src.contiguous()
                 self.xchg = None
             else:
@@ -381,7 +383,7 @@ def main():
                 self.step()
                 torch.cuda.synchronize()
                 acc.append(eng.last_timing()["stage_ms"])
-                comm.append(eng.last_comm_ms() if use_lib and world > 1 else 0.0)
+                comm.append(eng.last_comm_ms() if self.lib and world > 1 else 0.0)
             eng.set_profiling(False)
             return np.median(np.array(acc), axis=0), float(np.median(comm))
 
@@ -390,6 +392,45 @@ def main():
 
     # ------------------------------------------------------------------ the `value` workload (weak scaling)
     px = synth_u8(2 + rank, H, W)  # seed 2 = SURVEY.md 8(d) config B; other ranks' bands differ
+    exchange_check = None
+    if use_lib:
+        # The library's RCCL exchange is checked LIVE before it is timed: one step through it and one through torch.distributed's
+        # point-to-point calls (the same band, the same kernels, only the halos travel differently) must give the same bytes on every
+        # rank.  If not, every rank measures the torch path and the line says so.  A deadline stands behind the first exchange: ranks
+        # that wait for each other for ever would otherwise cost the whole run its line.
+        limit = float(os.environ.get("SRHIP_BENCH_EXCHANGE_LIMIT_S", "120"))
+
+        def stuck():
+            msg = f"rank {rank}: the first sharded step through libsrhip's RCCL communicator did not return within {limit:.0f} s"
+            print(msg, file=sys.stderr, flush=True)
+            if rank == 0:
+                print(json.dumps({"metric": "output megapixels/sec at 3x upscale", "value": None, "unit": "output MP/s", "n_gpus": world,
+                                  "error": msg + " (SRHIP_EXCHANGE=torch selects torch.distributed's point-to-point calls instead)"}), flush=True)
+            os._exit(3)
+
+        guard = threading.Timer(limit, stuck)
+        guard.daemon = True
+        guard.start()
+        try:
+            via_lib, via_torch = Band(px, lib=True), Band(px, lib=False)
+            via_lib.step()
+            torch.cuda.synchronize()
+            guard.cancel()
+            via_torch.step()
+            torch.cuda.synchronize()
+            same = [None] * world
+            dist.all_gather_object(same, bool(torch.equal(via_lib.out, via_torch.out)))
+            exchange_check = {"identical_to_torch_p2p_on_every_rank": all(same), "per_rank": same}
+            if not all(same):
+                eng.comm_init_rank(b"", 0, 1)
+                use_lib = False
+                exchange = "torch.distributed P2P (BandExchange) [libsrhip's exchange gave different bytes: see exchange_check]"
+            del via_lib, via_torch
+        except Exception as ex:  # noqa: BLE001 -- the check must not cost the run its line
+            exchange_check = {"error": str(ex)[:200]}
+        finally:
+            guard.cancel()
+        torch.cuda.empty_cache()
     main_band = Band(px)
     # set-up, not steps: the first calls allocate the workspace (4 feature maps), zero its borders
     # and bring the clocks up; with N > 1 RCCL's lazy P2P connection set-up also happens here
@@ -453,6 +494,8 @@ def main():
                                 for s in range(5)]
             if world > 1:
                 result["comm_ms"] = round(comm_ms, 4)
+                if exchange_check is not None:
+                    result["exchange_check"] = exchange_check
             io_bytes = H * W * (3 + 36 if u8 else 12 + 108)
             hbm = {"algorithmic_GBps": round(io_bytes / (ms_per_step / 1e3) / 1e9, 2), "peak_GBps": PEAK_HBM_GBPS,
                    "note": "algorithmic = compulsory image I/O only; the path is MFMA-bound (2170 FLOP/B)"}
