@@ -224,8 +224,10 @@ int sr_set_precision(sr_ctx* ctx, int mode);
  * 8-row tiles, in units of the resident workgroups ("" automatic: 1 where it pays, "0" none); "pipe": "none" forces the first
  * form of the stage kernels (one tile class per launch), "all" the pipe form also for small launches ("" automatic); "bw": width in tiles of the column blocks the tile queue walks
  * ("" automatic, "0" plain row-major); "bands": the host pipeline cuts one large image into that many equal row bands
- * ("" / "0": its own plan); "geo": "0" keeps equal bands where the plan would shrink them geometrically.
- * Defaults come from SRHIP_TH / SRHIP_TAIL / SRHIP_PIPE / SRHIP_BW / SRHIP_BANDS / SRHIP_GEO, read once in sr_create.
+ * ("" / "0": its own plan); "rows": the bands' heights themselves, "r0,r1,..." top to bottom, computed in order on one stream, or with a
+ * leading '=' on alternating streams (used when they add up to the rows of the call); "geo": "0" keeps equal bands where the plan would
+ * shrink them geometrically.
+ * Defaults come from SRHIP_TH / SRHIP_TAIL / SRHIP_PIPE / SRHIP_BW / SRHIP_BANDS / SRHIP_ROWS / SRHIP_GEO, read once in sr_create.
  * Unknown key: SR_E_INVALID. */
 int sr_set_experiment(sr_ctx* ctx, const char* key, const char* value);
 

@@ -227,8 +227,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[6][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
-                                              {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}};
+    static const char* const kSwitch[7][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
+                                              {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}, {"rows", "SRHIP_ROWS"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
     {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
@@ -371,6 +371,15 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
         c->env_pipe = !strcmp(v, "none") ? 0 : !strcmp(v, "all") ? 2 : 1;
     } else if (!strcmp(key, "bands")) {  // host pipeline: row bands of one large image ("" / "0": automatic)
         c->env_bands = *v ? atoi(v) : 0;
+    } else if (!strcmp(key, "rows")) {  // host pipeline: the bands' heights themselves, "r0,r1,..." top to bottom (used when they add up to the
+        c->env_rows.clear();            // rows of the call); computed in order on one stream, with a leading '=' on alternating streams
+        c->env_rows_two = *v == '=';
+        if (*v == '=') ++v;
+        while (*v) {
+            c->env_rows.push_back(atoi(v));
+            while (*v && *v != ',') ++v;
+            if (*v) ++v;
+        }
     } else if (!strcmp(key, "geo")) {  // "0": equal bands also where the host pipeline would shrink them geometrically
         c->env_geo = strcmp(v, "0") != 0;
     } else if (!strcmp(key, "tail")) {  // how many 4-row tiles end a launch of 8-row tiles, in units of the resident workgroups ("" : automatic, "0": none)
@@ -681,7 +690,12 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
         const double kern_ns = (c->precision == SR_PRECISION_SPLIT_F16 ? 0.9 : 2.0) * (f == 4 ? 1.2 : 1.0);
         const double d2h_ns = (double)out_px_bytes * f * f / 52.0;
         const double rho = kern_ns / d2h_ns;
-        if (c->env_bands > 0) {  // sr_set_experiment("bands"): that many equal bands
+        int forced_rows = 0;
+        for (int rk : c->env_rows) forced_rows += rk;
+        if (!c->env_rows.empty() && forced_rows == span) {  // sr_set_experiment("rows"): exactly these bands
+            rows = c->env_rows;
+            *in_order = !c->env_rows_two;
+        } else if (c->env_bands > 0) {  // sr_set_experiment("bands"): that many equal bands
             const int nb = std::min(c->env_bands, span / (2 * SR_HALO));
             for (int k = 0; k < nb; ++k) rows.push_back((span * (k + 1)) / nb - (span * k) / nb);
         } else {
@@ -707,6 +721,21 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
                 }
                 rows.push_back(left);
                 *in_order = true;
+            } else if (rho >= 2.0 && c->env_geo && (double)span * w >= 800e3) {
+                // Compute-bound, but too small for three bands in order (720p .. ~2.8 M px): on alternating streams, two equal
+                // bands that keep the chip full, then a tail -- the exposed download is the last band's, so that one is
+                // ~150K px (smaller no longer pays its five launches), from 1.8 M px on with a band of 2.5x that in front of
+                // it under which the second big band's download finishes.  Measured round 3 (scripts/host_plan_sweep.py,
+                // profiles/r3_host_plans.txt), against the equal bands of round 2: 1920x1080 400,400,200,80 = 4.60 against
+                // 4.89 ms; 1600x900 3.36 / 3.54; 1280x720 2.22 / 2.36.  2560x1440 is the geometric plan's either way.
+                const int last = std::max(16, (int)(150e3 / w + 4.0) / 8 * 8);
+                const int mid = (double)span * w >= 1.8e6 ? (5 * last / 2) / 8 * 8 : 0;
+                const int big = (span - last - mid) / 2 / 8 * 8;
+                if (big >= 2 * last) {
+                    rows = {big, span - last - mid - big};
+                    if (mid) rows.push_back(mid);
+                    rows.push_back(last);
+                }
             }
         }
         if (rows.empty()) {

@@ -49,6 +49,8 @@ struct sr_ctx {
     int env_bw = -1;                  // tile-order column-block width in tiles (-1: automatic)
     float env_tail = -1.0f;           // 4-row tiles at the end of a launch, in resident workgroups (< 0: automatic 1.5, 0: none)
     int env_bands = 0;                // host pipeline: forced number of row bands (0: automatic)
+    std::vector<int> env_rows;        // host pipeline: forced band heights (empty: automatic)
+    bool env_rows_two = false;        //   ... computed on alternating streams instead of in order
     bool env_geo = true;              // host pipeline: geometric band plan where the call is compute-bound
     unsigned long long params_hash = 0;  // FNV-1a of the parameter vector: contexts of one sharded call must agree
     // ---- multi-GPU (sr_comm.cpp): one RCCL communicator per context, neighbour halo exchange

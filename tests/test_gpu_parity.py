@@ -242,8 +242,9 @@ def test_full_size_properties_1080p(engines, params, H, W):
 @pytest.mark.parametrize("h,w", [(1080, 1920), (577, 911), (523, 1100), (2000, 270), (1400, 2100)])
 def test_host_pipeline_bands_are_bit_identical(engines, h, w):
     """sr_upscale_* on host pointers splits a large image into row bands (upload / kernels /
-    download overlap; equal bands, or -- f32 arithmetic with u8 output from ~2.9 M px, here 1400x2100 -- three
-    geometrically shrinking ones computed in order); the result must equal the undivided pass bit for bit, f32 and u8,
+    download overlap; equal bands, or -- f32 arithmetic with u8 output -- two equal bands and a short tail on alternating
+    streams (from 0.8 M px, here 1080x1920) or three geometrically shrinking ones computed in order (from ~2.9 M px, here
+    1400x2100)); the result must equal the undivided pass bit for bit, f32 and u8,
     pageable and page-locked (sr_host_alloc) destinations alike."""
     import rusty_sr_amd as r
     from rusty_sr_amd.engine import host_alloc
