@@ -146,6 +146,58 @@ def roofline_of(stage_ms, rows, W, precision):
     return k, ach, peak
 
 
+def read_sclk_mhz(device=0):
+    """Current shader clock of the GPU as the driver reports it (sysfs pp_dpm_sclk: the level marked '*'), or None."""
+    import glob
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    for path in cards[device:device + 1] or cards[:1]:
+        try:
+            for line in open(path):
+                if "*" in line:
+                    return int(line.split(":")[1].strip().split("M")[0].lower().replace("mhz", "").strip())
+        except Exception:
+            pass
+    return None
+
+
+def aux_entries(r, torch, sizes=((1080, 1920),), reps=200, device=0):
+    """The two parameter-free graphs of the reference's upscale() (bilinear_net / downsample_net, network.rs:111-138; sr_aux.hip)
+    on device-resident images: ms per call, GB/s of COMPULSORY I/O (input once + output once), fraction of the HBM roof (8 TB/s
+    nominal; 6.3 TB/s is what MI355X_MICROARCH.md measures for a copy)."""
+    out = []
+    engines = {"bilinear": r.Engine(graph="bilinear", device=device), "downsample": r.Engine(graph="downsample", device=device)}
+    for (H, W) in sizes:
+        px = synth_u8(7, H, W)
+        for graph, eng in engines.items():
+            for io in ("rgba8", "f32"):
+                if io == "rgba8":
+                    x = torch.from_numpy(px).cuda(device)[None]
+                    fn, in_b, out_b = eng.upscale_rgba8_dev, 3, 4
+                else:
+                    x = torch.from_numpy(r.img_to_data(px)).cuda(device)[None]
+                    fn, in_b, out_b = eng.upscale_f32_dev, 12, 12
+                o = fn(x)
+                for _ in range(10):
+                    fn(x, out=o)
+                torch.cuda.synchronize()
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        fn(x, out=o)
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / reps * 1e3)
+                nbytes = H * W * in_b + o.shape[1] * o.shape[2] * out_b
+                gbps = nbytes / (best / 1e3) / 1e9
+                out.append({"graph": graph + "_net", "io": io, "image": [H, W], "ms": round(best, 5), "io_bytes": nbytes,
+                            "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / PEAK_HBM_GBPS, 4),
+                            "frac_of_6.3TBps_copy_roof": round(gbps / 6300.0, 4)})
+                del o, x
+    for e in engines.values():
+        e.close()
+    return out
+
+
 def usable_cpus():
     """CPUs this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU pod usually owns a
     fraction of its host: the round-2 box reports 256 logical CPUs and a quota of 16).  Oversubscribing the quota with 256
@@ -385,6 +437,7 @@ def main():
                 acc.append(eng.last_timing()["stage_ms"])
                 comm.append(eng.last_comm_ms() if self.lib and world > 1 else 0.0)
             eng.set_profiling(False)
+            self.stage_mean = np.mean(np.array(acc), axis=0)   # beside the median: what `roofline.frac` is quoted on
             return np.median(np.array(acc), axis=0), float(np.median(comm))
 
         def rows(self):
@@ -411,22 +464,29 @@ def main():
         guard = threading.Timer(limit, stuck)
         guard.daemon = True
         guard.start()
+        # The deadline stays armed until every rank has reported: a rank that throws before the gather must not leave its peers
+        # waiting in the torch step or in the gather with nothing behind them.  Each rank contributes "identical", "different" or the
+        # exception it met; anything but identical on every rank sends ALL ranks to the torch path together.
         try:
-            via_lib, via_torch = Band(px, lib=True), Band(px, lib=False)
-            via_lib.step()
-            torch.cuda.synchronize()
-            guard.cancel()
-            via_torch.step()
-            torch.cuda.synchronize()
+            try:
+                via_lib, via_torch = Band(px, lib=True), Band(px, lib=False)
+                via_lib.step()
+                torch.cuda.synchronize()
+                via_torch.step()
+                torch.cuda.synchronize()
+                mine = "identical" if torch.equal(via_lib.out, via_torch.out) else "different"
+                del via_lib, via_torch
+            except Exception as ex:  # noqa: BLE001 -- reported through the gather, so that every rank learns of it
+                mine = "error: " + str(ex)[:160]
             same = [None] * world
-            dist.all_gather_object(same, bool(torch.equal(via_lib.out, via_torch.out)))
-            exchange_check = {"identical_to_torch_p2p_on_every_rank": all(same), "per_rank": same}
-            if not all(same):
+            dist.all_gather_object(same, mine)
+            ok = all(v == "identical" for v in same)
+            exchange_check = {"identical_to_torch_p2p_on_every_rank": ok, "per_rank": same}
+            if not ok:
                 eng.comm_init_rank(b"", 0, 1)
                 use_lib = False
-                exchange = "torch.distributed P2P (BandExchange) [libsrhip's exchange gave different bytes: see exchange_check]"
-            del via_lib, via_torch
-        except Exception as ex:  # noqa: BLE001 -- the check must not cost the run its line
+                exchange = "torch.distributed P2P (BandExchange) [libsrhip's exchange failed its live check: see exchange_check]"
+        except Exception as ex:  # noqa: BLE001 -- the gather itself failed: the check must not cost the run its line
             exchange_check = {"error": str(ex)[:200]}
         finally:
             guard.cancel()
@@ -461,11 +521,58 @@ def main():
                                  (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS), 4),
     }
 
+    if world == 1 and not args.no_roofline:
+        # ---- sustained: the same step looped for >= 3 s of wall time, every step bracketed by its own pair of events on the
+        # launch stream (20 steps are 80 ms: too short for the clocks to settle, or for an SMI sampler to see the GPU busy)
+        try:
+            secs = float(os.environ.get("SRHIP_BENCH_SUSTAINED_S", "3.0"))
+            sclk0 = read_sclk_mhz(local)
+            evs, t0 = [], time.perf_counter()
+            sclk_mid = []
+            while time.perf_counter() - t0 < secs:
+                for _ in range(50):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    main_band.step()
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                sclk_mid.append(read_sclk_mhz(local))
+            wall = time.perf_counter() - t0
+            per = np.array([a.elapsed_time(b) for a, b in evs])
+            sclk_mid = [v for v in sclk_mid if v]
+            result["sustained"] = {"ms_per_step": round(wall / len(per) * 1e3, 4), "steps": len(per), "wall_s": round(wall, 3),
+                                   "event_ms_median": round(float(np.median(per)), 4), "event_ms_mean": round(float(per.mean()), 4),
+                                   "event_ms_p95": round(float(np.percentile(per, 95)), 4), "event_ms_min": round(float(per.min()), 4),
+                                   "vs_headline": round(wall / len(per) * 1e3 / ms_per_step, 4),
+                                   "sclk_mhz_before": sclk0, "sclk_mhz_under_load": (int(np.median(sclk_mid)) if sclk_mid else None),
+                                   "sclk_mhz_under_load_min": (min(sclk_mid) if sclk_mid else None),
+                                   "whole_call_frac": round(H * W * FLOP_PER_PX / (wall / len(per)) / 1e12 /
+                                                            (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS), 4),
+                                   "note": "ms_per_step = wall / steps of a back-to-back loop (what `value` measures, but for >= 3 s); event_* = per-step "
+                                           "durations from an event pair around each call on the launch stream; sclk from sysfs pp_dpm_sclk"}
+            del evs
+        except Exception as ex:  # noqa: BLE001
+            result["sustained"] = {"error": str(ex)[:200]}
+        # ---- what the fork inside the device call is worth on this box: the same 20 steps with it off, then on again
+        try:
+            ab = {}
+            for key, val in (("undivided_ms", "0"), ("forked_ms", "1"), ("automatic_ms", "")):
+                eng.set_experiment("fork", val)
+                ab[key] = round(timed(main_band.step, args.steps, args.warmup), 4)
+            eng.set_experiment("fork", "")
+            result["config"]["device_call"] = ("sr_upscale_*_dev: one image as two row bands (+7 halo rows each, bit-identical) forked onto the context's "
+                                               "second stream and joined back by events where the rounds of tiles allow (sr_run_stack_auto); asynchronous on the caller's stream")
+            result["fork_ab"] = dict(ab, note="same step, sr_set_experiment('fork', '0' / '1' / ''): what overlapping the two bands' launch tails is worth here")
+        except Exception as ex:  # noqa: BLE001
+            result["fork_ab"] = {"error": str(ex)[:200]}
+
     stage_ms = None
     if not args.no_roofline:
         # dominant kernel = stage 3 (l3 node: conv3 5x5 + conv6 3x3 + conv8 3x3, K = 1376);
         # per-launch duration from HIP events recorded on the launch stream around each stage.
-        stage_ms, comm_ms = main_band.stage_ms(max(3, min(args.steps, 10)))
+        stage_ms, comm_ms = main_band.stage_ms(max(10, min(2 * args.steps, 40)))
+        stage_mean = main_band.stage_mean
         rows = main_band.rows() if world > 1 else [H] * 5
         k, ach, peak = roofline_of(stage_ms, rows, W, args.precision)
         if rank == 0:
@@ -479,19 +586,27 @@ def main():
                 "bound": "mfma",
                 "kernel": (f"stage {k} (conv_stage_pipe_kernel<{STAGE_SHAPE[k][0]}, {STAGE_SHAPE[k][1]}, ...>)"
                            if k else "conv0_kernel"),
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                # `achieved` / `frac`: algorithmic FLOPs of one launch / the AVERAGE launch duration of this run (the conservative
+                # figure: a few slow launches -- clock dips -- pull the mean up); the median beside it
+                "achieved": round(stage_tflops(k, rows[k], W, stage_mean[k]), 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(stage_tflops(k, rows[k], W, stage_mean[k]) / peak, 4),
+                "frac_at_median": round(ach / peak, 4), "achieved_at_median": round(ach, 2),
                 "traffic": pmc_traffic(k, H, W, args.precision) if world == 1 else None,
-                "avg_launch_ms": round(float(stage_ms[k]), 4),
-                "source": "hip_events (median over launches, on the launch stream, this run)",
+                "avg_launch_ms": round(float(stage_mean[k]), 4), "median_launch_ms": round(float(stage_ms[k]), 4),
+                "launch": "one launch = the whole frame (the per-stage timing pass runs the call undivided; the headline call runs "
+                          "the same kernel as two half-frame launches on two streams where that pays, see config.device_call)",
+                "source": "hip_events on the launch stream, this run: mean and median over %d launches" % max(10, min(2 * args.steps, 40)),
                 "rocprof": ({"median_ms": pe.get("median_us") and round(pe["median_us"] / 1e3, 4),
                              "avg_ms": pe.get("avg_us") and round(pe["avg_us"] / 1e3, 4),
+                             "frac": pe.get("avg_us") and round(stage_tflops(k, H, W, pe["avg_us"] / 1e3) / peak, 4),
                              "frac_at_median": pe.get("median_us") and round(stage_tflops(k, H, W, pe["median_us"] / 1e3) / peak, 4),
                              "mfma_util_pmc": pe.get("mfma_util") and round(pe["mfma_util"], 4),
                              "source": "profiles/pmc_latest.json (rocprofv3 --kernel-trace of this command, committed)"}
                             if pe else None),
                 "note": note}
-            result["stages"] = [{"stage": s, "ms": round(float(stage_ms[s]), 4), "tflops": round(stage_tflops(s, rows[s], W, stage_ms[s]), 2)}
-                                for s in range(5)]
+            result["stages"] = [{"stage": s, "ms": round(float(stage_ms[s]), 4), "mean_ms": round(float(stage_mean[s]), 4),
+                                 "tflops": round(stage_tflops(s, rows[s], W, stage_ms[s]), 2),
+                                 "frac_of_peak": round(stage_tflops(s, rows[s], W, stage_ms[s]) / peak, 4)} for s in range(5)]
             if world > 1:
                 result["comm_ms"] = round(comm_ms, 4)
                 if exchange_check is not None:
@@ -723,6 +838,14 @@ def main():
                                       "roofline_frac": round(ach_a / peak_here, 4), "whole_call_frac": round(65536 * FLOP_PER_PX / (ms_a / 1e3) / 1e12 / peak_here, 4)}
             except Exception as ex:  # noqa: BLE001
                 result["config_A"] = {"error": str(ex)[:300]}
+
+            try:
+                # the two parameter-free graphs (`-p bilinear`, `-d`), HBM-bound elementwise kernels
+                result["aux_graphs"] = {"entries": aux_entries(r, torch, ((H, W), (3 * H, 3 * W)), 100, local),
+                                        "note": "bilinear_net x3 / downsample_net /3 (network.rs:111-138), device-resident; GBps counts compulsory I/O only "
+                                                "(u8: 3 B in + 4 B RGBA out per pixel; f32: 12 + 12); the (3H, 3W) size is what `-d` of an upscaled frame reads"}
+            except Exception as ex:  # noqa: BLE001
+                result["aux_graphs"] = {"error": str(ex)[:300]}
 
             try:
                 # the same 1920x1080 frame as a batch of 4 in ONE call (n = 4): the per-launch costs of the five kernels -- fill,

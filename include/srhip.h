@@ -119,14 +119,6 @@ int sr_upscale_rgba8(sr_ctx* ctx, const uint8_t* in, int in_channels, int n, int
 int sr_reserve_f32(sr_ctx* ctx, int n, int h, int w);
 int sr_reserve_rgba8(sr_ctx* ctx, int in_channels, int n, int h, int w);
 
-/* The two host-pointer entry points above run upload / conv stack / download as a software
- * pipeline on three HIP streams of the context's own (created on first need: a call that is one chunk uses one, the
- * device-pointer entry points none): a batch goes in chunks of whole images, one large sr_net image
- * goes as row bands with SR_HALO halo rows (bit-identical to the undivided pass, see
- * sr_upscale_band_*).  Results do not depend on the setting; 0 = one upload, one pass, one
- * download.  The reference has no counterpart (its tensors never leave host memory,
- * main.rs:168-175); buffers from sr_host_alloc are page-locked, which lets the copies run at
- * PCIe rate and truly overlap -- any host memory is accepted. */
 /* One image across several GPUs from one process: ctxs[k] (sr_net contexts of the same parameters, normally one
  * per device, created with sr_create(.., device k)) produces a contiguous share of the rows, a multiple of 8.
  * The SR_HALO rows a share needs from its neighbours are read from the caller's image itself, so the devices
@@ -146,6 +138,14 @@ int sr_upscale_f32_batch_multi(sr_ctx* const* ctxs, int n_ctx, const float* in, 
 int sr_upscale_rgba8_batch_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* in, int in_channels, int n, int h, int w,
                                  uint8_t* out_rgba);
 
+/* The host-pointer entry points (sr_upscale_f32 / sr_upscale_rgba8 and their _multi forms) run upload / conv stack / download as a software
+ * pipeline on three HIP streams of the context's own (created on first need: a call that is one chunk uses one, the
+ * device-pointer entry points none): a batch goes in chunks of whole images, one large sr_net image
+ * goes as row bands with SR_HALO halo rows (bit-identical to the undivided pass, see
+ * sr_upscale_band_*).  Results do not depend on the setting; 0 = one upload, one pass, one
+ * download.  The reference has no counterpart (its tensors never leave host memory,
+ * main.rs:168-175); buffers from sr_host_alloc are page-locked, which lets the copies run at
+ * PCIe rate and truly overlap -- any host memory is accepted. */
 int sr_set_pipeline(sr_ctx* ctx, int enabled);         /* default: enabled */
 int sr_host_alloc(void** out, size_t bytes);           /* SR_E_NO_DEVICE without a GPU */
 void sr_host_free(void* p);
@@ -154,7 +154,9 @@ void sr_host_free(void* p);
  * memory (HBM); asynchronous on `stream` (opaque hipStream_t; NULL = HIP's
  * default stream, which is also torch's default stream).  The caller orders
  * its own producers / consumers of d_in / d_out on that stream.  These are what bench.py times and what the multi-GPU
- * driver calls after its halo exchange. */
+ * driver calls after its halo exchange.  One image (n = 1) of enough rows may run as TWO row bands, the second on a stream
+ * of the context's own that is forked from `stream` and joined back to it by events (one band's launches drain while the
+ * other's fill; bit-identical): the call is still asynchronous and ordered on `stream` alone. */
 int sr_upscale_f32_dev(sr_ctx* ctx, const float* d_in, int n, int h, int w, float* d_out,
                        void* stream);
 int sr_upscale_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels, int n, int h, int w,
@@ -199,7 +201,9 @@ int sr_comm_init_local(sr_ctx* const* ctxs, int n);
 void sr_comm_destroy(sr_ctx* ctx);                      /* sr_destroy does this too */
 int sr_comm_rank(sr_ctx* ctx, int* rank, int* nranks);  /* 0 of 1 without a communicator */
 int sr_last_comm_error(sr_ctx* ctx);                    /* ncclResult_t of the last failed RCCL call */
-int sr_last_comm_ms(sr_ctx* ctx, double* comm_ms);      /* device time of the last exchange (needs sr_set_profiling) */
+int sr_last_comm_ms(sr_ctx* ctx, double* comm_ms);      /* device time of the last sharded call's halo exchange (an event pair on the band's
+                                                         * stream, recorded on every call; waits for the exchange, not for the kernels).
+                                                         * sr_last_timing after a sharded call: total_ms = this context's whole step */
 int sr_upscale_sharded_f32_dev(sr_ctx* ctx, const float* d_band, int h_band, int w, float* d_out, void* stream);
 int sr_upscale_sharded_rgba8_dev(sr_ctx* ctx, const uint8_t* d_band, int in_channels, int h_band, int w,
                                  uint8_t* d_out_rgba, void* stream);

@@ -1,7 +1,7 @@
 """CPU oracle for the rusty_sr upscale hot path -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
-this package; rusty_sr_amd never does (tests/test_no_oracle_in_product.py
+this package; rusty_sr_amd never does (tests/test_abi.py::test_product_never_touches_the_oracle
 enforces it).  See sr_oracle.c for what is restated and how it is pinned.
 """
 from .oracle import (  # noqa: F401

@@ -1,12 +1,13 @@
 """Build libsrhip.so (HIP kernels + C ABI) in-tree with hipcc for gfx950."""
 import os
+import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrhip.so")
-SOURCES = ["sr_kernels.hip", "sr_api.cpp", "sr_comm.cpp"]
-DEVICE_ASM = os.path.join(HERE, "build", "temps", "sr_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+SOURCES = ["sr_kernels.hip", "sr_aux.hip", "sr_api.cpp", "sr_comm.cpp"]
+DEVICE_ASM = os.path.join(HERE, "build", "sr_kernels.gfx950.s")  # device assembly of the stage kernels, kept for the ISA lint
 HEADERS = ["sr_kernels.h", "sr_internal.h", os.path.join("..", "..", "include", "srhip.h")]
 
 
@@ -35,17 +36,28 @@ def build_lib(force=False, verbose=False):
         if force or _newer(obj, [src] + hdrs):
             tmp = obj + f".{os.getpid()}.tmp"
             cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", tmp]
-            if f.endswith(".hip"):
-                # keep the device assembly of the kernels: scripts/check_async_regs.py lints it (tests/test_abi.py).  The
-                # compiler's temporaries go to build/temps/ (36 MB; listed in .gpurunignore, the GPU box has no use for them)
-                temps = os.path.join(objdir, "temps")
+            temps = None
+            if f == "sr_kernels.hip":
+                # keep the device assembly of the stage kernels: scripts/check_async_regs.py lints it (tests/test_abi.py).  The
+                # compiler's temporaries go to a directory of this process's own (two builds at once -- parallel tests, several
+                # ranks on a fresh checkout -- must not write each other's files); object and assembly are then moved into place
+                temps = os.path.join(objdir, f"temps.{os.getpid()}")
                 os.makedirs(temps, exist_ok=True)
                 tmp = os.path.join(temps, f + ".o")
                 cmd = [hipcc, "-save-temps=obj", *FLAGS, "-x", "hip", "-c", src, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
-            os.replace(tmp, obj)
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, obj)
+                if temps:
+                    # (the temporary's name is the compiler's: <stem>-hip-amdgcn-amd-amdhsa-gfx950.s today; take whichever device .s is there)
+                    asm = [n for n in os.listdir(temps) if n.endswith(".s") and "amdgcn" in n]
+                    if asm:
+                        os.replace(os.path.join(temps, asm[0]), DEVICE_ASM)
+            finally:
+                if temps:
+                    shutil.rmtree(temps, ignore_errors=True)
             relink = True
     if relink or _newer(LIB, objs):
         tmp = LIB + f".{os.getpid()}.tmp"

@@ -227,8 +227,9 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[7][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
-                                              {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}, {"rows", "SRHIP_ROWS"}};
+    static const char* const kSwitch[10][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
+                                               {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}, {"rows", "SRHIP_ROWS"}, {"fork", "SRHIP_FORK"},
+                                               {"forkshare", "SRHIP_FORKSHARE"}, {"forkmin", "SRHIP_FORKMIN"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
     {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
@@ -260,7 +261,11 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
         mark("events");
 
-        if (graph != SR_GRAPH_SR_NET) return SR_OK;  // parameter-free graphs need nothing else
+        if (graph != SR_GRAPH_SR_NET) {  // parameter-free graphs: only the quantiser table of their u8 entry points
+            HIPCHK(c, sr_aux_build_tables(&c->d_qtab));
+            mark("quantiser table");
+            return SR_OK;
+        }
         // ---- pack every parameter once, in the layouts the kernels read
         std::vector<float> host, w;
         auto push = [&](const std::vector<float>& v) {
@@ -337,9 +342,11 @@ void sr_destroy(sr_ctx* c) {
     }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_qtab) (void)hipFree(c->d_qtab);
     for (auto& p : c->d_in) if (p) (void)hipFree(p);
     for (auto& p : c->d_out) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_fork) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->pool) if (e) (void)hipEventDestroy(e);
     if (c->copy_in) { (void)hipStreamSynchronize(c->copy_in); (void)hipStreamDestroy(c->copy_in); }
     if (c->copy_out) { (void)hipStreamSynchronize(c->copy_out); (void)hipStreamDestroy(c->copy_out); }
@@ -384,6 +391,12 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
         c->env_geo = strcmp(v, "0") != 0;
     } else if (!strcmp(key, "tail")) {  // how many 4-row tiles end a launch of 8-row tiles, in units of the resident workgroups ("" : automatic, "0": none)
         c->env_tail = *v ? (float)atof(v) : -1.0f;
+    } else if (!strcmp(key, "fork")) {  // device entry points, one image as two bands on two streams: "" automatic, "0" never, "1" always, N > 1: always, N rows first
+        c->env_fork = *v ? atoi(v) : -1;
+    } else if (!strcmp(key, "forkshare")) {  // ... the first band's share of the rows ("" : 0.5)
+        c->fork_share = *v ? std::min(0.9, std::max(0.1, atof(v))) : 0.5;
+    } else if (!strcmp(key, "forkmin")) {  // ... automatic rule: fork from this many rounds of tiles on
+        c->fork_min_rounds = *v ? atof(v) : 6.0;
     } else if (!strcmp(key, "bw")) {   // tile-order column-block width in tiles; "" / negative: automatic, 0: plain row-major
         c->env_bw = *v ? atoi(v) : -1;
     } else {
@@ -486,47 +499,35 @@ int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes) {
     return SR_OK;
 }
 
-// The whole conv stack on device buffers.  Rows [halo_top, H - halo_bot) of each
-// of the n images are produced; each earlier stage computes just the extra rows
-// the later ones read (f +-5, l1 +-3, l2 +-2, l3 +-1 around the band).
-int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top,
-                 int halo_bot, void* d_out, bool out_u8, hipStream_t s, int slot) {
-    if (!c || !d_img || !d_out || slot < 0 || slot > 1) return SR_E_INVALID;
-    sr_device_guard restore_device;
-    sr_ctx::Workspace& ws = c->ws[slot];
-    if (n <= 0 || H <= 0 || W <= 0) return SR_E_INVALID;
-    if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
-    if (c->graph != SR_GRAPH_SR_NET) {  // bilinear_net / downsample_net: one elementwise kernel
-        if (halo_top || halo_bot) return SR_E_INVALID;
-        if (c->graph == SR_GRAPH_DOWNSAMPLE && (H < 3 || W < 3)) return SR_E_INVALID;
-        if (img_u8 != out_u8) return SR_E_INVALID;
-        HIPCHK(c, hipSetDevice(c->device));
-        AuxArgs a{d_img, d_out, n, H, W, img_ch};
-        HIPCHK(c, sr_launch_aux(c->graph, a, img_u8, out_u8, s));
-        c->last_h = H; c->last_w = W;
-        return SR_OK;
-    }
-    if ((halo_top != 0 && halo_top < SR_HALO) || (halo_bot != 0 && halo_bot < SR_HALO)) return SR_E_HALO;
-    if (halo_top < 0 || halo_bot < 0 || halo_top + halo_bot >= H) return SR_E_INVALID;
-    if ((halo_top || halo_bot) && n != 1) return SR_E_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    // s == nullptr is HIP's legacy default stream (what torch's default stream is);
-    // the context's own non-blocking stream is used only by the host-pointer entry points.
-    const int top = halo_top, bot = H - halo_bot;
+namespace {
+
+// One pass of the conv stack over rows [top, bot) of n images of H x W on one stream with one workspace: planned first
+// (tile classes, grids), then launched stage by stage -- so that two jobs (the two bands of a forked call) can be issued
+// interleaved, stage for stage, each on its own stream.
+struct StackJob {
+    sr_ctx* c = nullptr;
+    sr_ctx::Workspace* ws = nullptr;
+    const void* d_img = nullptr;
+    void* d_out = nullptr;
+    bool img_u8 = false, out_u8 = false;
+    int img_ch = 3, n = 1, H = 0, W = 0, top = 0, bot = 0, tiles_x = 0;
+    hipStream_t s = nullptr;
+    struct Launch { int y0, y1, ty8, ty4, th, grid; bool pipe; } L[5];
+    float* feat[4] = {nullptr, nullptr, nullptr, nullptr};
+    int prepare();
+    int launch(int st) const;
+};
+
+int StackJob::prepare() {
     static const int margin[5] = {5, 3, 2, 1, 0};
-    const int tiles_x = (W + 31) / 32;
-    int rc = ensure_features(c, ws, n, H, W, tiles_x, s);
+    tiles_x = (W + 31) / 32;
+    const int rc = ensure_features(c, *ws, n, H, W, tiles_x, s);
     if (rc != SR_OK) return rc;
     const int cus = c->cus > 0 ? c->cus : 256;
     const int resident = 2 * cus;  // workgroups of a stage kernel that fit the chip at once (2 per CU: 76-78 KB of LDS each)
-    const float* P = c->d_params;
-    const bool prof = c->profiling;
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
-    float* feat[4];
-    for (int k = 0; k < 4; ++k) feat[k] = ws.d_feat[k] + ((size_t)kFeatPad * ws.pitch + kFeatPad) * 32;
-    const int bw = c->env_bw >= 0 ? c->env_bw : kAutoBlockWidth;
+    for (int k = 0; k < 4; ++k) feat[k] = ws->d_feat[k] + ((size_t)kFeatPad * ws->pitch + kFeatPad) * 32;
     // ---- plan every launch first: conv0 (the call's first launch) sets the tile-queue heads of the four stage kernels
-    struct Launch { int y0, y1, ty8, ty4, th, grid; bool pipe; } L[5];
     for (int st = 0; st < 5; ++st) {
         Launch& l = L[st];
         l.y0 = std::max(0, top - margin[st]);
@@ -567,6 +568,11 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
                 l.ty4 = std::max(0, (rows - 8 * l.ty8 + 3) / 4);
             }
         }
+        if (!forced && l.pipe && !small_launch && !split && l.ty4 == 0 && (double)tiles8 / resident >= 3.0 && rows % 8 >= 1 && rows % 8 <= 4) {
+            // the last 1-4 rows as ONE row of 4-row tiles instead of a mostly empty row of 8-row tiles (a band of a forked call, an image
+            // height that is not a multiple of 8): half a tile row of matrix work saved
+            l.ty8 = rows / 8; l.ty4 = 1;
+        }
         if (l.ty8 > 0 && l.ty4 > 0 && (long)n * tiles_x * (l.ty8 + l.ty4) <= resident) {
             // (cannot happen with the rules above -- a tail is only added to launches of >= 2 rounds -- but a launch with a workgroup
             // per tile hands out tiles by workgroup number alone, which is only a bijection for ONE tile class)
@@ -578,50 +584,93 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
         // the pipe form is persistent: one workgroup per resident slot, tiles from the queue; the first form one per tile
         l.grid = l.pipe ? std::min(ntiles, resident) : ntiles;
     }
+    return SR_OK;
+}
+
+int StackJob::launch(int st) const {
+    const int cus = c->cus > 0 ? c->cus : 256;
+    const float* P = c->d_params;
+    const int bw = c->env_bw >= 0 ? c->env_bw : kAutoBlockWidth;
+    const Launch& l = L[st];
+    const int y0 = l.y0, y1 = l.y1;
+    if (st == 0) {
+        const int tiles_y = (y1 - y0 + l.th - 1) / l.th;
+        Conv0Args a{};
+        a.img = d_img; a.wpack = P + c->off_w0; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
+        a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
+        a.pitch = ws->pitch; a.img_stride = ws->img_stride;
+        a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+        a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
+        a.n_tiles = n * tiles_x * tiles_y;
+        a.queue_reset = ws->d_queue;
+        for (int k = 1; k < 5; ++k) a.queue_grid[k] = L[k].grid;
+        // (grid: 8 workgroups per CU walking the tiles with a fixed stride; measured with 8 / 12 / 16 / 32 per CU, one per tile, and
+        // a grid that divides the tile count evenly: conv0's time does not depend on it)
+        HIPCHK(c, sr_launch_conv0(a, l.th, c->precision, std::min(a.n_tiles, 8 * cus), img_u8, s));
+        return SR_OK;
+    }
+    StageArgs a{};
+    float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
+    a.pitch = ws->pitch; a.img_stride = ws->img_stride;
+    switch (st) {
+        case 1: a.src[0] = f; a.dst = l1; break;
+        case 2: a.src[0] = f; a.src[1] = l1; a.dst = l2; break;
+        case 3: a.src[0] = f; a.src[1] = l1; a.src[2] = l2; a.dst = l3; break;
+        case 4: a.src[0] = l1; a.src[1] = l2; a.src[2] = l3; a.img = d_img; a.out = d_out; break;
+    }
+    a.wpack = P + (c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
+    a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
+    a.H = H; a.W = W; a.img_ch = img_ch;
+    a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x;
+    a.n_img = n; a.queue = ws->d_queue + st * 8;
+    a.grid[0] = make_tile_grid(8, y0, l.ty8, tiles_x, n, bw);
+    a.grid[1] = make_tile_grid(4, y0 + 8 * l.ty8, l.ty4, tiles_x, n, bw);
+    if (l.pipe) HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, l.grid, img_u8, out_u8, s));
+    else HIPCHK(c, sr_launch_stage(st, c->factor, a, l.th, c->precision, l.grid, img_u8, out_u8, s));
+    return SR_OK;
+}
+
+}  // namespace
+
+// The whole conv stack on device buffers.  Rows [halo_top, H - halo_bot) of each
+// of the n images are produced; each earlier stage computes just the extra rows
+// the later ones read (f +-5, l1 +-3, l2 +-2, l3 +-1 around the band).
+int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top,
+                 int halo_bot, void* d_out, bool out_u8, hipStream_t s, int slot) {
+    if (!c || !d_img || !d_out || slot < 0 || slot > 1) return SR_E_INVALID;
+    sr_device_guard restore_device;
+    if (n <= 0 || H <= 0 || W <= 0) return SR_E_INVALID;
+    if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    if (c->graph != SR_GRAPH_SR_NET) {  // bilinear_net / downsample_net: one elementwise kernel
+        if (halo_top || halo_bot) return SR_E_INVALID;
+        if (c->graph == SR_GRAPH_DOWNSAMPLE && (H < 3 || W < 3)) return SR_E_INVALID;
+        if (img_u8 != out_u8) return SR_E_INVALID;
+        HIPCHK(c, hipSetDevice(c->device));
+        AuxArgs a{d_img, d_out, n, H, W, img_ch, c->d_qtab};
+        HIPCHK(c, sr_launch_aux(c->graph, a, img_u8, out_u8, s));
+        c->last_h = H; c->last_w = W;
+        return SR_OK;
+    }
+    if ((halo_top != 0 && halo_top < SR_HALO) || (halo_bot != 0 && halo_bot < SR_HALO)) return SR_E_HALO;
+    if (halo_top < 0 || halo_bot < 0 || halo_top + halo_bot >= H) return SR_E_INVALID;
+    if ((halo_top || halo_bot) && n != 1) return SR_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    // s == nullptr is HIP's legacy default stream (what torch's default stream is);
+    // the context's own non-blocking stream is used only by the host-pointer entry points.
+    StackJob job;
+    job.c = c; job.ws = &c->ws[slot]; job.d_img = d_img; job.d_out = d_out; job.img_u8 = img_u8; job.out_u8 = out_u8;
+    job.img_ch = img_ch; job.n = n; job.H = H; job.W = W; job.top = halo_top; job.bot = H - halo_bot; job.s = s;
+    int rc = job.prepare();
+    if (rc != SR_OK) return rc;
+    const bool prof = c->profiling;
     static const bool trace_stages = [] { const char* e = getenv("SRHIP_TRACE"); return e && atoi(e) >= 2; }();
     if (prof) HIPCHK(c, hipEventRecord(c->ev[0], s));
     for (int st = 0; st < 5; ++st) {
-        const Launch& l = L[st];
-        const int y0 = l.y0, y1 = l.y1;
-        if (st == 0) {
-            const int tiles_y = (y1 - y0 + l.th - 1) / l.th;
-            Conv0Args a{};
-            a.img = d_img; a.wpack = P + c->off_w0; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
-            a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
-            a.pitch = ws.pitch; a.img_stride = ws.img_stride;
-            a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
-            a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
-            a.n_tiles = n * tiles_x * tiles_y;
-            a.queue_reset = ws.d_queue;
-            for (int k = 1; k < 5; ++k) a.queue_grid[k] = L[k].grid;
-            // (grid: 8 workgroups per CU walking the tiles with a fixed stride; measured with 8 / 12 / 16 / 32 per CU, one per tile, and
-            // a grid that divides the tile count evenly: conv0's time does not depend on it)
-            HIPCHK(c, sr_launch_conv0(a, l.th, c->precision, std::min(a.n_tiles, 8 * cus), img_u8, s));
-        } else {
-            StageArgs a{};
-            float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
-            a.pitch = ws.pitch; a.img_stride = ws.img_stride;
-            switch (st) {
-                case 1: a.src[0] = f; a.dst = l1; break;
-                case 2: a.src[0] = f; a.src[1] = l1; a.dst = l2; break;
-                case 3: a.src[0] = f; a.src[1] = l1; a.src[2] = l2; a.dst = l3; break;
-                case 4: a.src[0] = l1; a.src[1] = l2; a.src[2] = l3; a.img = d_img; a.out = d_out; break;
-            }
-            a.wpack = P + (c->precision ? c->off_wh[st] : c->off_w[st]); a.bias = P + c->off_bias[st];
-            a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
-            a.H = H; a.W = W; a.img_ch = img_ch;
-            a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x;
-            a.n_img = n; a.queue = ws.d_queue + st * 8;
-            a.grid[0] = make_tile_grid(8, y0, l.ty8, tiles_x, n, bw);
-            a.grid[1] = make_tile_grid(4, y0 + 8 * l.ty8, l.ty4, tiles_x, n, bw);
-            if (l.pipe) {
-                HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, l.grid, img_u8, out_u8, s));
-            } else {
-                HIPCHK(c, sr_launch_stage(st, c->factor, a, l.th, c->precision, l.grid, img_u8, out_u8, s));
-            }
-        }
+        rc = job.launch(st);
+        if (rc != SR_OK) return rc;
         if (prof) HIPCHK(c, hipEventRecord(c->ev[st + 1], s));
         if (trace_stages) {  // SRHIP_TRACE=2: which launch a hang or a fault belongs to
+            const StackJob::Launch& l = job.L[st];
             fprintf(stderr, "[srhip] stage %d launched: rows [%d,%d) th8 x%d th4 x%d grid %d %s ... ", st, l.y0, l.y1, l.ty8, l.ty4, l.grid, l.pipe ? "pipe" : "first");
             const hipError_t e = hipStreamSynchronize(s);
             fprintf(stderr, "%s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
@@ -629,6 +678,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
     }
     c->last_h = H; c->last_w = W;
     if (prof) {
+        c->band_pending = false;
         HIPCHK(c, hipEventSynchronize(c->ev[5]));
         float ms = 0;
         for (int st = 0; st < 5; ++st) {
@@ -638,6 +688,86 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[5]));
         c->total_ms = ms;
     }
+    return SR_OK;
+}
+
+// A lone frame's five launches each end with a drain (the workgroups of a persistent launch finish up to a tile time
+// apart, the chip idles while the last ones work) and begin with a fill (launch boundary, first gathers): ~0.1 ms of a
+// 4.14 ms 1080p call that a batch of four, or a second frame in flight, does not pay (bench.py batch_of_4,
+// two_frames_in_flight).  The device entry points therefore do for a lone image what those do: the rows are cut into TWO
+// bands -- each with the SR_HALO rows of the other it needs, bit-identical to the undivided pass like every band -- and the
+// second band runs on the context's second stream and workspace, forked from the caller's stream by an event and joined
+// back by another, the launches of the two issued alternately.  A stage launch of one band then drains while the other
+// band's launch of that stage fills the freed slots; the call stays asynchronous on the caller's stream.  Costs: 14
+// recomputed rows (0.3 % of the FLOPs at 1080p) and a second set of feature maps.
+int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
+                      void* d_out, bool out_u8, hipStream_t s) {
+    if (!c || !d_img || !d_out) return SR_E_INVALID;
+    const int own = H - halo_top - halo_bot;
+    bool fork = c->graph == SR_GRAPH_SR_NET && n == 1 && !c->profiling && c->env_fork != 0 && W > 0 && own >= 4 * SR_HALO &&
+                halo_top >= 0 && halo_bot >= 0 && (halo_top == 0 || halo_top >= SR_HALO) && (halo_bot == 0 || halo_bot >= SR_HALO);
+    if (fork && c->env_fork < 0) {
+        // automatic: where the launches have enough rounds of tiles for two bands to fill the chip each (measured)
+        const int cus = c->cus > 0 ? c->cus : 256;
+        const double rounds = (double)((W + 31) / 32) * ((own + 7) / 8) / (2.0 * cus);
+        // measured (scripts/fork_ab.py, profiles/r4_fork_ab_*.jsonl): exact f32 720p / 1080p gain, 540x960 (4 rounds) loses 3.5 %, 3840x2160
+        // (63 rounds: the launch boundaries are 0.6 % of the call) and the split-half mode (tiles of 14 us) lose 0.3-2 %
+        fork = c->precision == SR_PRECISION_F32 && rounds >= c->fork_min_rounds && rounds < c->fork_max_rounds;
+    }
+    if (!fork) return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s);
+    sr_device_guard restore_device;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (auto& e : c->ev_fork) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // The first band's own rows: near the requested share, at the cut (within +-8 rows of it) that wastes the least matrix work in
+    // partly filled tile rows.  Stage s of the first band computes rows_a + margin rows from the band's top, of the second band
+    // own - rows_a + margin rows; a remainder of 1-4 rows costs a row of 4-row tiles (0.52 of an 8-row one), 5-7 rows a full one.
+    int rows_a = c->env_fork > 1 ? c->env_fork : (int)(own * c->fork_share);
+    rows_a = std::max(2 * SR_HALO, std::min(rows_a, own - 2 * SR_HALO));
+    if (c->env_fork <= 1) {
+        static const int margin[5] = {5, 3, 2, 1, 0};
+        static const double weight[5] = {0.0, 25600.0, 34816.0, 44032.0, 28800.0};  // issued MACs per pixel of stages 1-4 (conv0: negligible)
+        const bool fours = c->precision == SR_PRECISION_F32;
+        auto tile_rows = [&](int rows) { const int r = rows % 8; return rows / 8 + (r == 0 ? 0.0 : (r <= 4 && fours) ? 0.52 : 1.0); };
+        double best = 1e300;
+        int best_rows = rows_a;
+        for (int cand = rows_a - 8; cand <= rows_a + 8; ++cand) {
+            if (cand < 2 * SR_HALO || own - cand < 2 * SR_HALO) continue;
+            double cost = 0.0;
+            for (int st = 1; st < 5; ++st) {
+                const int ra = cand + margin[st] + std::min(halo_top, margin[st]), rb = own - cand + margin[st] + std::min(halo_bot, margin[st]);
+                cost += weight[st] * (tile_rows(ra) + tile_rows(rb));
+            }
+            cost += 1e-3 * std::abs(cand - rows_a);  // ties: the cut nearest the requested share
+            if (cost < best) { best = cost; best_rows = cand; }
+        }
+        rows_a = best_rows;
+    }
+    const int cut = halo_top + rows_a;  // first row of the second band, in the coordinates of the caller's buffer
+    const size_t in_px = img_u8 ? (size_t)img_ch : 3 * sizeof(float), out_px = out_u8 ? 4 : 3 * sizeof(float);
+    const int f = c->factor;
+    StackJob a, b;
+    a.c = b.c = c; a.img_u8 = b.img_u8 = img_u8; a.out_u8 = b.out_u8 = out_u8; a.img_ch = b.img_ch = img_ch; a.W = b.W = W;
+    a.ws = &c->ws[0]; a.s = s;
+    a.d_img = d_img; a.d_out = d_out; a.H = cut + SR_HALO; a.top = halo_top; a.bot = cut;
+    b.ws = &c->ws[1]; b.s = c->stream2;
+    b.d_img = (const char*)d_img + (size_t)(cut - SR_HALO) * W * in_px;
+    b.d_out = (char*)d_out + (size_t)rows_a * f * W * f * out_px;
+    b.H = H - (cut - SR_HALO); b.top = SR_HALO; b.bot = b.H - halo_bot;
+    HIPCHK(c, hipEventRecord(c->ev_fork[0], s));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork[0], 0));
+    int rc = a.prepare();
+    if (rc == SR_OK) rc = b.prepare();
+    for (int st = 0; st < 5 && rc == SR_OK; ++st) {
+        rc = a.launch(st);
+        if (rc == SR_OK) rc = b.launch(st);
+    }
+    // join also on failure: whatever was queued on the second stream must be ordered before the caller's next work
+    const hipError_t e1 = hipEventRecord(c->ev_fork[1], c->stream2);
+    const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, c->ev_fork[1], 0) : e1;
+    if (rc != SR_OK) return rc;
+    HIPCHK(c, e1); HIPCHK(c, e2);
+    c->last_h = c->last_w = 0;  // each workspace holds one band: sr_read_feature refuses
     return SR_OK;
 }
 
@@ -903,7 +1033,7 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
         HIPCHK(c, hipEventElapsedTime(&ms, ev(0, 2), ev(i, 3))); ker = std::max(ker, (double)ms);
         HIPCHK(c, hipEventElapsedTime(&ms, ev(i, 3), ev(i, 4))); d2h += ms;  // includes waiting for the copy engine
     }
-    c->h2d_ms = h2d; c->total_ms = ker; c->d2h_ms = d2h;
+    c->h2d_ms = h2d; c->total_ms = ker; c->d2h_ms = d2h; c->band_pending = false;
     c->last_chunks = nch;
     if (nch > 1) c->last_h = c->last_w = 0;  // the feature maps hold one chunk only: sr_read_feature refuses
     return SR_OK;
@@ -941,23 +1071,23 @@ int sr_check_context_set(sr_ctx* const* ctxs, int n_ctx) { return check_context_
 extern "C" {
 
 int sr_upscale_f32_dev(sr_ctx* c, const float* d_in, int n, int h, int w, float* d_out, void* stream) {
-    return sr_run_stack(c, d_in, false, 3, n, h, w, 0, 0, d_out, false, (hipStream_t)stream);
+    return sr_run_stack_auto(c, d_in, false, 3, n, h, w, 0, 0, d_out, false, (hipStream_t)stream);
 }
 
 int sr_upscale_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, int n, int h, int w,
                          uint8_t* d_out, void* stream) {
-    return sr_run_stack(c, d_in, true, in_channels, n, h, w, 0, 0, d_out, true, (hipStream_t)stream);
+    return sr_run_stack_auto(c, d_in, true, in_channels, n, h, w, 0, 0, d_out, true, (hipStream_t)stream);
 }
 
 int sr_upscale_band_f32_dev(sr_ctx* c, const float* d_in, int h_ext, int w, int halo_top, int halo_bot,
                             float* d_out, void* stream) {
-    return sr_run_stack(c, d_in, false, 3, 1, h_ext, w, halo_top, halo_bot, d_out, false, (hipStream_t)stream);
+    return sr_run_stack_auto(c, d_in, false, 3, 1, h_ext, w, halo_top, halo_bot, d_out, false, (hipStream_t)stream);
 }
 
 int sr_upscale_band_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, int h_ext, int w,
                               int halo_top, int halo_bot, uint8_t* d_out, void* stream) {
-    return sr_run_stack(c, d_in, true, in_channels, 1, h_ext, w, halo_top, halo_bot, d_out, true,
-                        (hipStream_t)stream);
+    return sr_run_stack_auto(c, d_in, true, in_channels, 1, h_ext, w, halo_top, halo_bot, d_out, true,
+                             (hipStream_t)stream);
 }
 
 int sr_reserve_f32(sr_ctx* c, int n, int h, int w) {
@@ -1062,6 +1192,15 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
 
 int sr_last_timing(sr_ctx* c, double* total_ms, double stage_ms[5], double* h2d_ms, double* d2h_ms) {
     if (!c) return SR_E_INVALID;
+    if (c->band_pending) {  // a sharded call (sr_comm.cpp): its whole step on this context -- band copy, halo exchange, conv stack -- waited for here
+        float ms = 0;
+        HIPCHK(c, hipEventSynchronize(c->ev_band[1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_band[0], c->ev_band[1]));
+        c->total_ms = ms;
+        for (auto& v : c->stage_ms) v = 0;
+        c->h2d_ms = c->d2h_ms = 0;
+        c->band_pending = false;
+    }
     if (total_ms) *total_ms = c->total_ms;
     if (stage_ms) for (int i = 0; i < 5; ++i) stage_ms[i] = c->stage_ms[i];
     if (h2d_ms) *h2d_ms = c->h2d_ms;

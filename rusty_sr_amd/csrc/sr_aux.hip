@@ -1,0 +1,339 @@
+// sr_aux.hip -- the two parameter-free graphs of the reference's upscale(): bilinear_net (network.rs:111-123,
+// `-p bilinear`) and downsample_net (network.rs:125-138, `-d`), for gfx950.
+//
+//   bilinear_net   : out = LinearToSrgb(LinearInterp x3(SrgbToLinear(x)))          36 B (u8 RGBA) or 108 B (f32) out per input px
+//   downsample_net : out = LinearToSrgb(mean 3x3(SrgbToLinear(x)))                 27 / 108 B in per output px
+//
+// Both are HBM-bound by their I/O if the transfer functions cost nothing, so that is what the kernels arrange:
+//  * u8 in : SrgbToLinear of a byte is a 256-entry table (built per workgroup in LDS with the same powf expression the
+//    one-thread-per-pixel kernels of rounds 1-3 evaluated per sample: bit-identical);
+//  * u8 out: data_to_img(LinearToSrgb(l)) is a monotone step function of l with 255 steps.  The steps' positions (the
+//    smallest float l that quantises to k, k = 1..255) are found ONCE per context by bisection over the float bit
+//    patterns with the same powf expression (threshold_kernel), and laid out as a table indexed by the top 16 bits of
+//    l (exponent + 7 mantissa bits: 128 buckets per octave, at most one step per bucket -- the builder checks): a
+//    lookup is one ds_read_b64, one compare and one add instead of a powf, and gives the powf's answer;
+//  * f32 in / out: powf(x, p) = exp2(p * log2(x)) on v_log_f32 / v_exp_f32 (1 ulp each; measured <= 4e-7 absolute
+//    against the oracle's libm, inside the 1e-5 the tests ask of these graphs and far inside north_star's 1e-4);
+//  * every input sample is linearised once per tile (staged, edge-replicated, in LDS as [pixel][4] f32), the
+//    interpolation runs in the reference's operation order ((1-t) a + t b, rows then columns), one workgroup owns an
+//    output tile and a thread stores 16 bytes at a time (4 RGBA pixels / 4 floats) whenever the rows are 16-byte aligned
+//    (W % 4 == 0), dwords otherwise.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "sr_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- the transfer functions, exactly as rounds 1-3 evaluated them (alumina SrgbToLinear / LinearToSrgb: IEC 61966-2-1)
+__device__ __forceinline__ float srgb_to_linear(float s) { return s <= 0.04045f ? s / 12.92f : powf((s + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float linear_to_srgb(float l) { return l <= 0.0031308f ? 12.92f * l : 1.055f * powf(l, 1.0f / 2.4f) - 0.055f; }
+__device__ __forceinline__ uint32_t quant_u8(float v) {  // data_to_img (main.rs:175)
+    return (uint32_t)fminf(fmaxf(floorf(255.0f * v + 0.5f), 0.0f), 255.0f);
+}
+// ... and on the hardware's log2 / exp2 (the f32 entry points: no table can help an arbitrary float)
+__device__ __forceinline__ float fast_pow(float x, float p) { return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)); }
+__device__ __forceinline__ float srgb_to_linear_fast(float s) { return s <= 0.04045f ? s / 12.92f : fast_pow((s + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float linear_to_srgb_fast(float l) { return l <= 0.0031308f ? 12.92f * l : 1.055f * fast_pow(l, 1.0f / 2.4f) - 0.055f; }
+
+// ---- quantiser table: byte = base + (l >= step) for the bucket of l
+constexpr int kQExp0 = 114;                       // biased exponent of 2^-13: below it every l quantises to 0
+constexpr int kQBuckets = (127 - kQExp0) * 128;   // [2^-13, 1) in 128 buckets per octave; entry kQBuckets: l >= 1 -> 255
+struct QEntry { float step; uint32_t base; };
+__device__ __forceinline__ uint32_t quant_lookup(const QEntry* tab, float l) {
+    // (arithmetic shift: zero, everything below 2^-13 and negative values land at or below 0 -> bucket 0, whose base is 0; from 1.0 up
+    // -> the last bucket, 255.  The u8 entry points never produce a NaN here: table values and weights are finite and >= 0.)
+    const int idx = min(max(((int)__float_as_uint(l) >> 16) - (kQExp0 << 7), 0), kQBuckets);
+    const QEntry e = tab[idx];
+    return e.base + (l >= e.step ? 1u : 0u);
+}
+
+// smallest float l in [0, 1] with quant_u8(linear_to_srgb(l)) >= k, for k = 1 .. 255 (thread k - 1): bisection over
+// the bit patterns (non-negative floats order like their bits), then a short downward scan in case the powf is not
+// monotone to the last bit around the step
+__global__ void threshold_kernel(float* steps) {
+    const uint32_t k = threadIdx.x + 1;
+    if (k > 255) return;
+    uint32_t lo = 0, hi = __float_as_uint(1.0f);  // quant(lo) < k <= quant(hi)
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (quant_u8(linear_to_srgb(__uint_as_float(mid))) >= k) hi = mid; else lo = mid;
+    }
+    for (int i = 0; i < 64 && hi > 1; ++i)
+        if (quant_u8(linear_to_srgb(__uint_as_float(hi - 1))) >= k) --hi;
+    steps[k - 1] = __uint_as_float(hi);
+}
+
+constexpr int kBlTW = 64, kBlTH = 16;                      // bilinear: input tile; output tile 192 x 48
+constexpr int kBlTWH = kBlTW + 2, kBlTHH = kBlTH + 2, kBlNPIX = kBlTWH * kBlTHH;
+
+// Output column o of the tile (in units of the interpolated quantity: pixels) -> tile column of its first input and the
+// weight of the second: phase p = o % 3 of input pixel i = o / 3 reads inputs (i-1, i) with t = 2/3 for p = 0, (i, i+1)
+// with t = 0 for p = 1 and t = 1/3 for p = 2 (LinearInterp, network.rs:118: half-pixel centres; the oracle's
+// linterp3_acc).  The tile carries a one-pixel edge-replicated halo, so input i sits at tile column i + 1.
+__device__ __forceinline__ void phase(int o, int& i0, float& t) {
+    const int i = o / 3, p = o - 3 * i;
+    i0 = min(i + (p == 0 ? 0 : 1), kBlTWH - 2);  // (clamped for the padding of a row's last, partial chunk: computed, never stored)
+    t = p == 0 ? 2.0f / 3.0f : (p == 1 ? 0.0f : 1.0f / 3.0f);
+}
+
+// One work item = one 16-byte chunk column (4 RGBA pixels / 4 floats) of the THREE output rows of one input row y: the
+// horizontal interpolation of input rows y-1, y, y+1 is done once and shared by the three output rows (vertical phases
+// t = 2/3 of (y-1, y), 0 of (y, y+1), 1/3 of (y, y+1)), in the expression and order of the one-thread-per-pixel kernel
+// this replaces: ra = (1-tx) v00 + tx v01, rb = ..., out = (1-ty) ra + ty rb.  Consecutive lanes own consecutive chunks
+// of a row, so every store instruction writes one contiguous run.
+template <bool IMG_U8, bool OUT_U8, bool ALIGNED>
+__global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_lin[kBlNPIX * 4];
+    __shared__ float s_lut[IMG_U8 ? 256 : 1];
+    __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQBuckets + 1 : 1];
+    const int tid = threadIdx.x;
+    if constexpr (IMG_U8) s_lut[tid] = srgb_to_linear(__fdiv_rn((float)tid, 255.0f));  // img_to_data (main.rs:170), then SrgbToLinear
+    if constexpr (OUT_U8) {
+        const QEntry* q = (const QEntry*)a.qtab;
+        for (int k = tid; k <= kQBuckets; k += 256) s_q[k] = q[k];
+    }
+    const int tiles_x = (a.W + kBlTW - 1) / kBlTW, tiles_y = (a.H + kBlTH - 1) / kBlTH;
+    const long ntiles = (long)a.n * tiles_x * tiles_y;
+    const int OW = 3 * a.W, OH = 3 * a.H;
+    constexpr int EPP = OUT_U8 ? 1 : 3;               // 4-byte elements per output pixel
+    constexpr int CPR = 3 * kBlTW * EPP / 4;          // chunks per output row of a full tile
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int x0 = tx * kBlTW, y0 = ty * kBlTH;
+        __syncthreads();  // the previous tile's readers are done (and the tables are in place)
+        for (int p = tid; p < kBlNPIX; p += 256) {
+            const int py = p / kBlTWH, px = p - py * kBlTWH;
+            const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
+            const size_t gp = ((size_t)n * a.H + gy) * a.W + gx;
+            f32x4 v;
+            if constexpr (IMG_U8) {
+                const uint8_t* q = (const uint8_t*)a.img + gp * a.img_ch;
+                v = f32x4{s_lut[q[0]], s_lut[q[1]], s_lut[q[2]], 0.f};
+            } else {
+                const float* q = (const float*)a.img + gp * 3;
+                v = f32x4{srgb_to_linear_fast(q[0]), srgb_to_linear_fast(q[1]), srgb_to_linear_fast(q[2]), 0.f};
+            }
+            *(f32x4*)&s_lin[p * 4] = v;
+        }
+        __syncthreads();
+        const int tw = min(kBlTW, a.W - x0), th = min(kBlTH, a.H - y0);  // this tile's own input pixels
+        const int elems = 3 * tw * EPP;                                  // 4-byte elements per output row of this tile
+        for (int q = tid; q < CPR * kBlTH; q += 256) {
+            const int y = q / CPR, cx = q - y * CPR;
+            if (y >= th || 4 * cx >= elems) continue;
+            const float* row = s_lin + (y * kBlTWH) * 4;   // input row y - 1 (tile row y); y and y + 1 follow
+            float h[3][4];                                  // horizontally interpolated: [input row][element of the chunk]
+            if constexpr (OUT_U8) {
+                uint32_t px4[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int xa; float txv;
+                    phase(4 * cx + e, xa, txv);
+                    f32x4 hh[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const f32x4 v0 = *(const f32x4*)(row + (r * kBlTWH + xa) * 4), v1 = *(const f32x4*)(row + (r * kBlTWH + xa) * 4 + 4);
+                        hh[r] = (1.0f - txv) * v0 + txv * v1;
+                    }
+#pragma unroll
+                    for (int py = 0; py < 3; ++py) {
+                        const float tyv = py == 0 ? 2.0f / 3.0f : (py == 1 ? 0.0f : 1.0f / 3.0f);
+                        const f32x4 o = (1.0f - tyv) * hh[py == 0 ? 0 : 1] + tyv * hh[py == 0 ? 1 : 2];
+                        px4[py][e] = 0xff000000u | quant_lookup(s_q, o.x) | (quant_lookup(s_q, o.y) << 8) | (quant_lookup(s_q, o.z) << 16);
+                    }
+                }
+                (void)h;
+#pragma unroll
+                for (int py = 0; py < 3; ++py) {
+                    uint32_t* dst = (uint32_t*)a.out + ((size_t)n * OH + 3 * (y0 + y) + py) * OW + 3 * x0 + 4 * cx;
+                    if (ALIGNED || 4 * cx + 4 <= elems) {
+                        if constexpr (ALIGNED) *(u32x4*)dst = u32x4{px4[py][0], px4[py][1], px4[py][2], px4[py][3]};
+                        else { dst[0] = px4[py][0]; dst[1] = px4[py][1]; dst[2] = px4[py][2]; dst[3] = px4[py][3]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (4 * cx + e < elems) dst[e] = px4[py][e];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fi = 4 * cx + e, ox = fi / 3, c = fi - 3 * ox;   // [x][c] interleaved: 9 floats per input pixel
+                    int xa; float txv;
+                    phase(ox, xa, txv);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) h[r][e] = (1.0f - txv) * row[(r * kBlTWH + xa) * 4 + c] + txv * row[(r * kBlTWH + xa) * 4 + 4 + c];
+                }
+#pragma unroll
+                for (int py = 0; py < 3; ++py) {
+                    const float tyv = py == 0 ? 2.0f / 3.0f : (py == 1 ? 0.0f : 1.0f / 3.0f);
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = linear_to_srgb_fast((1.0f - tyv) * h[py == 0 ? 0 : 1][e] + tyv * h[py == 0 ? 1 : 2][e]);
+                    float* dst = (float*)a.out + (((size_t)n * OH + 3 * (y0 + y) + py) * OW + 3 * x0) * 3 + 4 * cx;
+                    if (ALIGNED || 4 * cx + 4 <= elems) {
+                        if constexpr (ALIGNED) *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
+                        else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (4 * cx + e < elems) dst[e] = o[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// downsample_net: one thread per output pixel; a workgroup owns 64 x 4 output pixels = 192 x 12 input pixels, whose rows
+// are staged raw in LDS by coalesced dword loads (an input row segment starts at any byte: loaded from the 4-byte word
+// that holds its first byte on, the misalignment added back at the read).  No input sample is read twice (the 3x3
+// windows do not overlap), the 9 samples are summed in the reference's order (rows, then columns) and divided by 9.
+constexpr int kDsTW = 64, kDsTH = 4;
+template <bool IMG_U8, bool OUT_U8>
+__global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
+    constexpr int ROW_BYTES = 3 * kDsTW * (IMG_U8 ? 4 : 12) + 16;   // a staged row segment (u8: up to 4 channels), + misalignment slack
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[3 * kDsTH * ROW_BYTES / 4];
+    __shared__ float s_lut[IMG_U8 ? 256 : 1];
+    __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQBuckets + 1 : 1];
+    const int tid = threadIdx.x;
+    if constexpr (IMG_U8) s_lut[tid] = srgb_to_linear(__fdiv_rn((float)tid, 255.0f));
+    if constexpr (OUT_U8) {
+        const QEntry* q = (const QEntry*)a.qtab;
+        for (int k = tid; k <= kQBuckets; k += 256) s_q[k] = q[k];
+    }
+    const int OH = a.H / 3, OW = a.W / 3;  // remainder rows / columns dropped (unpinned, see oracle)
+    const int tiles_x = (OW + kDsTW - 1) / kDsTW, tiles_y = (OH + kDsTH - 1) / kDsTH;
+    const long ntiles = (long)a.n * tiles_x * tiles_y;
+    const size_t px_bytes = IMG_U8 ? (size_t)a.img_ch : 12;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int ox0 = tx * kDsTW, oy0 = ty * kDsTH;
+        const int tw = min(kDsTW, OW - ox0), th = min(kDsTH, OH - oy0);
+        const int seg = 3 * tw * (int)px_bytes;  // bytes of one input row segment
+        __syncthreads();
+        for (int r = 0; r < 3 * th; ++r) {
+            const uintptr_t addr = (uintptr_t)a.img + (((size_t)n * a.H + 3 * oy0 + r) * a.W + 3 * ox0) * px_bytes;
+            const uint32_t* src = (const uint32_t*)(addr & ~(uintptr_t)3);
+            const int words = (int)((addr & 3) + seg + 3) / 4;
+            for (int k = tid; k < words; k += 256) s_raw[r * (ROW_BYTES / 4) + k] = src[k];
+        }
+        __syncthreads();
+        const int lx = tid & (kDsTW - 1), ly = tid / kDsTW;
+        if (lx < tw && ly < th) {
+            float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = 3 * ly + dy;
+                const uintptr_t addr = (uintptr_t)a.img + (((size_t)n * a.H + 3 * oy0 + r) * a.W + 3 * ox0) * px_bytes;
+                const unsigned char* row = (const unsigned char*)(s_raw + r * (ROW_BYTES / 4)) + (addr & 3);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float v;
+                        if constexpr (IMG_U8) v = s_lut[row[(3 * lx + dx) * a.img_ch + c]];
+                        else v = srgb_to_linear_fast(*(const float*)(row + ((3 * lx + dx) * 3 + c) * 4));
+                        acc[c] += v;
+                    }
+            }
+            const size_t op = ((size_t)n * OH + oy0 + ly) * OW + ox0 + lx;
+            if constexpr (OUT_U8) {
+                uint32_t pk = 0xff000000u;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pk |= quant_lookup(s_q, acc[c] / 9.0f) << (8 * c);
+                ((uint32_t*)a.out)[op] = pk;
+            } else {
+                float* d = (float*)a.out + op * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = linear_to_srgb_fast(acc[c] / 9.0f);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// The quantiser table of a context of one of these graphs (sr_create_graph): 255 step positions from the device's own
+// powf, laid out by bucket on the host.  *d_tab: kQBuckets + 1 entries of 8 bytes in device memory (hipFree'd by sr_destroy).
+hipError_t sr_aux_build_tables(void** d_tab) {
+    *d_tab = nullptr;
+    float* d_steps = nullptr;
+    hipError_t e = hipMalloc((void**)&d_steps, 255 * sizeof(float));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(threshold_kernel, dim3(1), dim3(256), 0, nullptr, d_steps);
+    float steps[255];
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(steps, d_steps, sizeof(steps), hipMemcpyDeviceToHost);
+    (void)hipFree(d_steps);
+    if (e != hipSuccess) return e;
+    std::vector<QEntry> tab(kQBuckets + 1);
+    auto bucket_lo = [](int idx) {  // smallest float of bucket idx
+        const uint32_t bits = ((uint32_t)(kQExp0 << 7) + (uint32_t)idx) << 16;
+        float f;
+        memcpy(&f, &bits, 4);
+        return f;
+    };
+    // byte(l) = #{k : steps[k] <= l}.  For a bucket [lo, hi): base = #{steps < lo}; the one step inside it (lo <= step < hi), if any,
+    // is the entry's `step`.  Bucket 0 also serves every l below 2^-13, the last bucket every l from 1.0 up.
+    for (int i = 1; i < 255; ++i)
+        if (!(steps[i] > steps[i - 1])) return hipErrorUnknown;
+    int k = 0;
+    for (int idx = 0; idx <= kQBuckets; ++idx) {
+        const float lo = idx > 0 ? bucket_lo(idx) : -INFINITY, hi = idx < kQBuckets ? bucket_lo(idx + 1) : INFINITY;
+        while (k < 255 && steps[k] < lo) ++k;
+        tab[idx].base = (uint32_t)k;
+        tab[idx].step = INFINITY;
+        if (k < 255 && steps[k] < hi) {
+            tab[idx].step = steps[k];
+            if (k + 1 < 255 && steps[k + 1] < hi) return hipErrorUnknown;  // two steps in one bucket: cannot happen (see the header)
+        }
+    }
+    e = hipMalloc(d_tab, tab.size() * sizeof(QEntry));
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(*d_tab, tab.data(), tab.size() * sizeof(QEntry), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(*d_tab); *d_tab = nullptr; }
+    return e;
+}
+
+hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, hipStream_t s) {
+    if (img_u8 != out_u8) return hipErrorInvalidValue;
+    if (out_u8 && !a.qtab) return hipErrorInvalidValue;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (graph == 1) {
+        const long tiles = (long)a.n * ((a.W + kBlTW - 1) / kBlTW) * ((a.H + kBlTH - 1) / kBlTH);
+        if (tiles == 0) return hipSuccess;
+        // a few workgroups per CU walk the tiles -- the tables are read once per workgroup, not once per tile -- and every workgroup
+        // gets the same number of them (+-1)
+        const long per = (tiles + 6L * cus - 1) / (6L * cus);
+        const int grid = (int)((tiles + per - 1) / per);
+        const bool aligned = a.W % 4 == 0 && ((uintptr_t)a.out & 15) == 0;
+        if (img_u8) {
+            if (aligned) hipLaunchKernelGGL((bilinear_tile_kernel<true, true, true>), dim3(grid), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((bilinear_tile_kernel<true, true, false>), dim3(grid), dim3(256), 0, s, a);
+        } else {
+            if (aligned) hipLaunchKernelGGL((bilinear_tile_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((bilinear_tile_kernel<false, false, false>), dim3(grid), dim3(256), 0, s, a);
+        }
+    } else {
+        const int OH = a.H / 3, OW = a.W / 3;
+        const long tiles = (long)a.n * ((OW + kDsTW - 1) / kDsTW) * ((OH + kDsTH - 1) / kDsTH);
+        if (tiles == 0) return hipSuccess;
+        const long per = (tiles + 8L * cus - 1) / (8L * cus);
+        const int grid = (int)((tiles + per - 1) / per);
+        if (img_u8) hipLaunchKernelGGL((downsample_tile_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((downsample_tile_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}

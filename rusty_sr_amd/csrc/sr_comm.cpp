@@ -135,6 +135,14 @@ int prepare_band(sr_ctx* c, const void* d_band, int h_band, int w, size_t px_byt
     g = band_geom(c, h_band, w, px_bytes);
     const int rc = sr_ensure_buf(c, &c->d_ext, &c->ext_cap, (size_t)g.h_ext * g.row_bytes);
     if (rc != SR_OK) return rc;
+    // Two event pairs time every sharded step on the band's stream, profiling or not (an event record costs the stream nothing):
+    // the whole step of this context and the halo exchange inside it.  They are read -- with a wait for the second event -- only when
+    // the caller asks (sr_last_timing / sr_last_comm_ms), so the call itself stays asynchronous and the bands of a one-process call
+    // are not serialised the way per-stage profiling serialises them.
+    for (auto& e : c->ev_comm) if (!e) HIPCHK(c, hipEventCreate(&e));
+    for (auto& e : c->ev_band) if (!e) HIPCHK(c, hipEventCreate(&e));
+    c->comm_pending = c->band_pending = false;
+    HIPCHK(c, hipEventRecord(c->ev_band[0], s));
     HIPCHK(c, hipMemcpyAsync((char*)c->d_ext + (size_t)g.top * g.row_bytes, d_band, (size_t)h_band * g.row_bytes,
                              hipMemcpyDeviceToDevice, s));
     return SR_OK;
@@ -152,7 +160,7 @@ int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, 
     if (c->comm_nranks > 1) {
         Rccl* R = rccl();
         if (!R) return SR_E_COMM;
-        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[0], s));
+        HIPCHK(c, hipEventRecord(c->ev_comm[0], s));
         NCCLCHK(c, R->GroupStart());
         rc = post_exchange(c, R, d_band, h_band, g, s);
         const ncclResult_t ge = R->GroupEnd();
@@ -161,15 +169,14 @@ int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, 
             abort_comm(c, R);
             return SR_E_COMM;
         }
-        if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_comm[1], s));
+        HIPCHK(c, hipEventRecord(c->ev_comm[1], s));
     }
-    rc = sr_run_stack(c, c->d_ext, u8, img_ch, 1, g.h_ext, w, g.top, g.bot, d_out, u8, s);
-    if (rc == SR_OK && c->profiling && c->comm_nranks > 1) {  // sr_run_stack has synchronised on its last event
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_comm[0], c->ev_comm[1]));
-        c->comm_ms = ms;
-    }
-    return rc;
+    rc = sr_run_stack_auto(c, c->d_ext, u8, img_ch, 1, g.h_ext, w, g.top, g.bot, d_out, u8, s);
+    if (rc != SR_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_band[1], s));
+    c->comm_pending = c->comm_nranks > 1;
+    c->band_pending = !c->profiling;  // (with per-stage profiling on, sr_last_timing reports the conv stack's own events)
+    return SR_OK;
 }
 
 // one process, all ranks: every band of one image, synchronous
@@ -212,44 +219,52 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
             const size_t halo = (size_t)SR_HALO * g[k].row_bytes;
             char* ext = (char*)c->d_ext;
             rc = hip(c, hipSetDevice(c->device));
-            if (rc == SR_OK && c->profiling) rc = hip(c, hipEventRecord(c->ev_comm[0], c->stream));
+            if (rc == SR_OK) rc = hip(c, hipEventRecord(c->ev_comm[0], c->stream));
             if (rc == SR_OK && g[k].top)
                 rc = hip(c, hipMemcpyPeerAsync(ext, c->device, (const char*)d_bands[k - 1] + (size_t)(h_bands[k - 1] - SR_HALO) * g[k].row_bytes,
                                                ctxs[k - 1]->device, halo, c->stream));
             if (rc == SR_OK && g[k].bot)
                 rc = hip(c, hipMemcpyPeerAsync(ext + (size_t)(g[k].top + h_bands[k]) * g[k].row_bytes, c->device, d_bands[k + 1],
                                                ctxs[k + 1]->device, halo, c->stream));
-            if (rc == SR_OK && c->profiling) rc = hip(c, hipEventRecord(c->ev_comm[1], c->stream));
+            if (rc == SR_OK) rc = hip(c, hipEventRecord(c->ev_comm[1], c->stream));
         }
     } else if (rc == SR_OK && n > 1) {
-        ncclResult_t gs = R->GroupStart();
+        for (int k = 0; k < n && rc == SR_OK; ++k) {
+            rc = hip(ctxs[k], hipSetDevice(ctxs[k]->device));
+            if (rc == SR_OK) rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_comm[0], ctxs[k]->stream));
+        }
+        ncclResult_t gs = rc == SR_OK ? R->GroupStart() : ncclSuccess;
         if (gs != ncclSuccess) { ctxs[0]->last_nccl = (int)gs; rc = SR_E_COMM; }
+        const bool grouped = rc == SR_OK;
         for (int k = 0; k < n && rc == SR_OK; ++k) {
             (void)hipSetDevice(ctxs[k]->device);
             rc = post_exchange(ctxs[k], R, d_bands[k], h_bands[k], g[k], ctxs[k]->stream);
         }
-        if (gs == ncclSuccess) {
+        if (grouped) {
             const ncclResult_t ge = R->GroupEnd();
             if (rc == SR_OK && ge != ncclSuccess) { ctxs[0]->last_nccl = (int)ge; rc = SR_E_COMM; }
+        }
+        for (int k = 0; k < n && rc == SR_OK; ++k) {
+            (void)hipSetDevice(ctxs[k]->device);
+            rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_comm[1], ctxs[k]->stream));
         }
         // a failure inside the group may have left some ranks' operations queued without partners: abort every
         // communicator of the set, so that the drain below returns instead of waiting for them for ever
         if (rc != SR_OK)
             for (int k = 0; k < n; ++k) { (void)hipSetDevice(ctxs[k]->device); abort_comm(ctxs[k], R); }
     }
-    for (int k = 0; k < n && rc == SR_OK; ++k)
-        rc = sr_run_stack(ctxs[k], ctxs[k]->d_ext, u8, img_ch, 1, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, ctxs[k]->stream);
+    for (int k = 0; k < n && rc == SR_OK; ++k) {
+        rc = sr_run_stack_auto(ctxs[k], ctxs[k]->d_ext, u8, img_ch, 1, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, ctxs[k]->stream);
+        if (rc == SR_OK) rc = hip(ctxs[k], hipSetDevice(ctxs[k]->device));
+        if (rc == SR_OK) rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_band[1], ctxs[k]->stream));
+        if (rc == SR_OK) { ctxs[k]->comm_pending = n > 1; ctxs[k]->band_pending = !ctxs[k]->profiling; }
+    }
     int first = rc;
     for (int k = 0; k < n; ++k) {  // drain every device, also on failure
         (void)hipSetDevice(ctxs[k]->device);
         const hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
         if (e != hipSuccess && first == SR_OK) { ctxs[k]->last_hip = (int)e; first = SR_E_HIP; }
     }
-    for (int k = 0; k < n && first == SR_OK && local && n > 1; ++k)
-        if (ctxs[k]->profiling) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, ctxs[k]->ev_comm[0], ctxs[k]->ev_comm[1]) == hipSuccess) ctxs[k]->comm_ms = ms;
-        }
     return first;
 }
 
@@ -264,6 +279,8 @@ void sr_comm_release(sr_ctx* c) {
     c->comm_rank = 0; c->comm_nranks = 1; c->comm_local = false; c->comm_broken = false;
     if (c->d_ext) { (void)hipFree(c->d_ext); c->d_ext = nullptr; c->ext_cap = 0; }
     for (auto& e : c->ev_comm) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : c->ev_band) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    c->comm_pending = c->band_pending = false;
 }
 
 extern "C" {
@@ -388,6 +405,13 @@ int sr_last_comm_error(sr_ctx* c) { return c ? c->last_nccl : 0; }
 
 int sr_last_comm_ms(sr_ctx* c, double* comm_ms) {
     if (!c || !comm_ms) return SR_E_INVALID;
+    if (c->comm_pending) {  // waits for the exchange of the last sharded call (not for its kernels)
+        float ms = 0;
+        HIPCHK(c, hipEventSynchronize(c->ev_comm[1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_comm[0], c->ev_comm[1]));
+        c->comm_ms = ms;
+        c->comm_pending = false;
+    }
     *comm_ms = c->comm_ms;
     return SR_OK;
 }

@@ -13,6 +13,7 @@ struct sr_ctx {
     char name[128] = {0};
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
+    void* d_qtab = nullptr;     // bilinear_net / downsample_net: data_to_img(LinearToSrgb(l)) as a step table (sr_aux.hip)
     size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
@@ -47,7 +48,13 @@ struct sr_ctx {
     int env_th[5] = {0, 0, 0, 0, 0};  // 0: automatic
     int env_pipe = 1;                 // 0: first form everywhere, 1: pipe form except for small launches, 2: pipe form everywhere
     int env_bw = -1;                  // tile-order column-block width in tiles (-1: automatic)
-    float env_tail = -1.0f;           // 4-row tiles at the end of a launch, in resident workgroups (< 0: automatic 1.5, 0: none)
+    float env_tail = -1.0f;           // 4-row tiles at the end of a launch, in resident workgroups (< 0: automatic = 1 where the tail rule applies, 0: none)
+    int env_fork = -1;                // device entry points, one image: two row bands on two streams (sr_run_stack_auto); -1 automatic, 0 never,
+                                      // 1 always, > 1: always, with this many rows in the first band
+    double fork_min_rounds = 6.0;     //   automatic: fork from this many rounds of 8-row tiles per resident workgroup on ...
+    double fork_max_rounds = 40.0;    //   ... and below this many
+    double fork_share = 0.5;          //   the first band's share of the rows
+    hipEvent_t ev_fork[2] = {nullptr, nullptr};  // fork (caller's stream -> stream2) and join (stream2 -> caller's stream)
     int env_bands = 0;                // host pipeline: forced number of row bands (0: automatic)
     std::vector<int> env_rows;        // host pipeline: forced band heights (empty: automatic)
     bool env_rows_two = false;        //   ... computed on alternating streams instead of in order
@@ -58,7 +65,9 @@ struct sr_ctx {
     bool comm_local = false;          // sr_comm_init_local: neighbours are contexts of this process, halos go by peer copy
     int comm_rank = 0, comm_nranks = 1;
     void* d_ext = nullptr; size_t ext_cap = 0;  // band + halo rows, the exchange lands here
-    hipEvent_t ev_comm[2] = {nullptr, nullptr};
+    hipEvent_t ev_comm[2] = {nullptr, nullptr};  // around the halo exchange of a sharded call, on the band's stream
+    hipEvent_t ev_band[2] = {nullptr, nullptr};  // around the whole sharded step of this context (band copy, exchange, conv stack)
+    bool comm_pending = false, band_pending = false;  // the events of the last sharded call have not been read yet (sr_last_comm_ms / sr_last_timing)
     double comm_ms = 0;
     int last_nccl = 0;
     bool comm_broken = false;         // an exchange failed half-posted: the communicator was aborted, sharded calls return SR_E_COMM
@@ -89,6 +98,9 @@ struct sr_device_guard {
 // The whole conv stack on device buffers (sr_api.cpp): rows [halo_top, H - halo_bot) of each image are produced.
 int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
                  void* d_out, bool out_u8, hipStream_t s, int slot = 0);
+// ... the same for one image as two row bands forked onto the context's second stream where that pays (the device entry points)
+int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
+                      void* d_out, bool out_u8, hipStream_t s);
 int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes);
 int sr_ensure_streams(sr_ctx* c, bool pipelined);  // the context's own streams are created on first use
 void sr_comm_release(sr_ctx* c);  // sr_comm.cpp: destroy the communicator and its buffers (called by sr_destroy)

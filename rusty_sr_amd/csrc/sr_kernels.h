@@ -107,7 +107,9 @@ struct AuxArgs {          // bilinear_net / downsample_net (parameter-free graph
     const void* img;      // n*H*W*3 f32 or n*H*W*img_ch u8
     void* out;            // bilinear: n*3H*3W*(3 f32 | 4 u8); downsample: n*(H/3)*(W/3)*(3 f32 | 4 u8)
     int n, H, W, img_ch;
+    const void* qtab;     // u8 output: the quantiser table of the context (sr_aux_build_tables), else unused
 };
+hipError_t sr_aux_build_tables(void** d_tab);  // sr_aux.hip: data_to_img(LinearToSrgb(l)) as a step table, built once per context
 hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, hipStream_t s);  // graph: 1 bilinear, 2 downsample
 
 // prec: 0 = exact f32 (v_mfma_f32_32x32x2_f32), 1 = split-half (3 x v_mfma_f32_32x32x16_f16)

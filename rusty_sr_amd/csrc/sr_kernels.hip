@@ -214,6 +214,14 @@ __device__ __forceinline__ void for_each_acc_row(F&& f) {
 
 }  // namespace
 
+// An address the hardware takes from SGPRs (LDS-DMA base, the origin of a tile).  Every caller passes a wave-uniform pointer; this spells it out for the
+// cases where the compiler cannot prove it (folds away where it can).
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
 // ---------------------------------------------------------------------------
 // Stage 0: conv0 5x5 3->32 + bias + BeLU.  The x tile (with halo) sits in LDS as [pixel][3 channels]; along a
 // kernel row the 5 taps x 3 channels are 15 CONSECUTIVE floats from pixel i on, so K is packed per kernel row:
@@ -243,6 +251,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     __shared__ float s_lut[256];
     if constexpr (IMG_U8) s_lut[tid] = __fdiv_rn((float)tid, 255.0f);
     const float bias = a.bias[i], beta = a.beta[i];
+    // Staging plan of a tile, once per workgroup: thread t moves tile pixels t and t + 256; their byte offsets from the tile's
+    // first (halo) pixel do not depend on the tile.  An INTERIOR tile (halo inside the image, last image row excluded: the 4-byte
+    // load of a 3-byte pixel must not run past the buffer) then costs a thread one load at `uniform origin + offset`, two VALU
+    // instructions per sample for the table address and the LDS traffic -- the index arithmetic and the four bounds tests per pixel of
+    // the general path (~40 instructions per pixel, on the vector ALU the f32 MFMA shares) are paid by border tiles only.
+    constexpr int PER = (NPIX + kThreads - 1) / kThreads;
+    const uint32_t px_bytes = IMG_U8 ? (uint32_t)a.img_ch : 12u;
+    uint32_t rel[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int p = min(tid + kThreads * k, NPIX - 1), py = p / TWH, px = p - py * TWH;
+        rel[k] = (uint32_t)(py * a.W + px) * px_bytes;
+    }
   for (int bid = blockIdx.x; bid < a.n_tiles; bid += gridDim.x) {
     const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
     const int ty = tile_div(t, a.div_tx), tx = t - ty * a.tiles_x;
@@ -250,6 +271,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     const size_t img_px0 = (size_t)n * a.H * a.W;
 
     __syncthreads();  // the previous tile's reads of s_x are done
+    const bool interior = y0 >= 2 && y0 - 2 + THH < a.H && x0 >= 2 && x0 - 2 + TWH <= a.W;  // wave-uniform
+    if (interior) {
+        const char* origin = uniform_ptr((const char*)a.img + (img_px0 + (size_t)(y0 - 2) * a.W + (x0 - 2)) * px_bytes);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int p = tid + kThreads * k;
+            if (p < NPIX) {
+                if constexpr (IMG_U8) {
+                    uint32_t v;
+                    __builtin_memcpy(&v, origin + rel[k], 4);  // one (unaligned) dword: R, G, B and a byte of the next pixel / alpha
+                    s_x[p * 3] = s_lut[v & 0xffu]; s_x[p * 3 + 1] = s_lut[(v >> 8) & 0xffu]; s_x[p * 3 + 2] = s_lut[(v >> 16) & 0xffu];
+                } else {
+                    const float* q = (const float*)(origin + rel[k]);
+                    s_x[p * 3] = q[0]; s_x[p * 3 + 1] = q[1]; s_x[p * 3 + 2] = q[2];
+                }
+            }
+        }
+    } else {
     for (int p = tid; p < NPIX; p += kThreads) {
         const int py = p / TWH, px = p - py * TWH;
         const int gy = y0 - 2 + py, gx = x0 - 2 + px;
@@ -266,6 +305,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
             }
         }
         s_x[p * 3] = v.x; s_x[p * 3 + 1] = v.y; s_x[p * 3 + 2] = v.z;
+    }
     }
     __syncthreads();
 
@@ -357,12 +397,14 @@ __device__ __forceinline__ void lds_dma16(const void* base, uint32_t voff, uint3
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
                  :: "s"(lds), "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
-// The DMA base must sit in SGPRs.  Every caller passes a wave-uniform pointer; this spells it out for the
-// cases where the compiler cannot prove it (folds away where it can).
-__device__ __forceinline__ const char* uniform_ptr(const void* p) {
-    const uint64_t v = (uint64_t)(uintptr_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+// The same with `base + byte_off` formed inside the statement, on the scalar ALU (vcc as the address pair).  Given base + constant
+// in C the compiler hoists every step's 64-bit address out of the tile loop as a loop invariant -- 46 pointer pairs for the weight
+// chunks of stage 3 -- and, 102 SGPRs being all there are, spills them into VGPR lanes: two v_readlane per step in the matrix
+// stream, each worth ~10 cycles of f32-MFMA time.  A constant offset is rematerialised instead (one s_mov).
+__device__ __forceinline__ void lds_dma16_at(const void* base, uint32_t byte_off, uint32_t voff, uint32_t lds) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    asm volatile("s_add_u32 vcc_lo, %0, %2\n\ts_addc_u32 vcc_hi, %1, 0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, vcc offset:0"
+                 :: "s"((uint32_t)b), "s"((uint32_t)(b >> 32)), "s"(byte_off), "s"(lds), "v"(voff) : "vcc", "scc", "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
@@ -978,23 +1020,41 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
 // step's operands (another ring slot, the current half's buffer).  It matters in the split-half mode, whose step is only
 // 12 x 32 cycles of matrix work: with lgkmcnt(0) a wave sat out one LDS round trip per step in front of the barrier.
 // (A plain LDS WRITE that another wave reads behind the barrier -- the tile queue's mailbox -- waits for itself.)
+// The immediate of s_waitcnt must be a constant, `pending` is a run-time number (how many of the newest DMAs may stay in flight:
+// StepStream).  A C switch over it compiles to a chain of ~50 scalar instructions and ~10 branches per wait (and, where the
+// compiler does not see that the number is wave-uniform, to a tree of EXEC-masked branches with v_cmp / s_and_saveexec, each EXEC
+// write draining the matrix pipe) -- once per step, i.e. per 12 MFMAs of 32 cycles in the split-half mode.  Here: one indexed
+// jump into a table of sixteen `s_waitcnt vmcnt(k); s_branch end` pairs (8 bytes each), eight scalar instructions and two taken
+// branches whatever the number.  Fewer than `pending` in flight is always safe, so the index is min(pending, 15), and a negative
+// number (never produced) waits for everything.
+#define SR_WAIT_ROW(k, extra) "s_waitcnt vmcnt(" #k ")" extra "\n\ts_branch .Lsrwait%=\n\t"
+#define SR_WAIT_TABLE(extra)                                                                                                \
+    "s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, 15\n\ts_lshl_b32 %0, %0, 3\n\ts_add_u32 %0, %0, 12\n\t"                        \
+    "s_getpc_b64 vcc\n\ts_add_u32 vcc_lo, vcc_lo, %0\n\ts_addc_u32 vcc_hi, vcc_hi, 0\n\ts_setpc_b64 vcc\n\t"                \
+    SR_WAIT_ROW(0, extra) SR_WAIT_ROW(1, extra) SR_WAIT_ROW(2, extra) SR_WAIT_ROW(3, extra) SR_WAIT_ROW(4, extra)              \
+    SR_WAIT_ROW(5, extra) SR_WAIT_ROW(6, extra) SR_WAIT_ROW(7, extra) SR_WAIT_ROW(8, extra) SR_WAIT_ROW(9, extra)              \
+    SR_WAIT_ROW(10, extra) SR_WAIT_ROW(11, extra) SR_WAIT_ROW(12, extra) SR_WAIT_ROW(13, extra) SR_WAIT_ROW(14, extra)         \
+    SR_WAIT_ROW(15, extra) ".Lsrwait%=:"
+template <bool LGKM>
+__device__ __forceinline__ void wait_vm_n(int pending) {  // s_waitcnt vmcnt(min(pending, 15)) [lgkmcnt(0)]
+    if (__builtin_constant_p(pending)) {  // (resolved after inlining and unrolling: many steps know their number at compile time)
+        switch (pending < 0 ? 0 : pending) {
+#define SR_CASE(k) case k: if constexpr (LGKM) asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+            SR_CASE(0) SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
+            SR_CASE(11) SR_CASE(12) SR_CASE(13) SR_CASE(14)
+#undef SR_CASE
+            default: if constexpr (LGKM) asm volatile("s_waitcnt vmcnt(15) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        }
+        return;
+    }
+    const int p = __builtin_amdgcn_readfirstlane(pending);
+    int t;
+    if constexpr (LGKM) asm volatile(SR_WAIT_TABLE(" lgkmcnt(0)") : "=&s"(t) : "s"(p) : "vcc", "scc", "memory");
+    else asm volatile(SR_WAIT_TABLE("") : "=&s"(t) : "s"(p) : "vcc", "scc", "memory");
+}
 template <bool LGKM>
 __device__ __forceinline__ void wait_vm_barrier(int pending) {
-    if constexpr (LGKM) {
-        switch (pending) {
-#define SR_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); break;
-            SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
-#undef SR_CASE
-            default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-        }
-    } else {
-        switch (pending) {
-#define SR_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-            SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
-#undef SR_CASE
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        }
-    }
+    wait_vm_n<LGKM>(pending);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -1031,14 +1091,16 @@ struct HalfTile {
 #pragma unroll
         for (int g = 0; g < G::NG; ++g) lds_dma16<0>(origin, off[g], dst + g * 1024);
     }
-    // one gather instruction of that request: pixel group g (64 tile pixels) of this wave's plane
+    // the same request in pieces: where this wave's channel group of the tile starts in HBM / its plane in LDS (once per half) ...
     template <int PREC>
-    __device__ __forceinline__ void stage_one(int g, uint32_t buf, const float* __restrict__ src, int khalf, long img_stride,
-                                              int pitch, int n, int y0, int x0, int wave) const {
-        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) +
-                                         chunk_of<PREC>(khalf, wave) * 16);
-        lds_dma16<0>(origin, off[g], __builtin_amdgcn_readfirstlane(buf + wave * G::PLANE + g * 1024));
+    static __device__ __forceinline__ const char* origin_of(const float* __restrict__ src, int khalf, long img_stride, int pitch, int n,
+                                                            int y0, int x0, int wave) {
+        return uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) +
+                           chunk_of<PREC>(khalf, wave) * 16);
     }
+    static __device__ __forceinline__ uint32_t plane_of(uint32_t buf, int wave) { return __builtin_amdgcn_readfirstlane(buf + wave * G::PLANE); }
+    // ... and one gather instruction of it: pixel group g (64 tile pixels)
+    __device__ __forceinline__ void stage_one(int g, const char* origin, uint32_t dst) const { lds_dma16<0>(origin, off[g], dst + g * 1024); }
 };
 
 // Bookkeeping of the pipe form's DMA traffic.  Every LDS-DMA instruction a wave issues gets a sequence number;
@@ -1048,7 +1110,7 @@ struct HalfTile {
 // next tile.  Half tiles: requested piecemeal over the first steps of the previous half (a burst of gathers
 // stalls the issuing wave for ~250 cycles per instruction), needed at its end.
 struct StepStream {
-    int gs, slot;        // this step's number within the tile and its ring slot
+    int slot;            // ring slot of the current step's chunk
     int nsteps;          // steps per tile
     bool have_next;      // another tile follows (its chunks are requested by the last steps of this one)
     int issued;          // DMA instructions issued so far by this wave
@@ -1056,8 +1118,10 @@ struct StepStream {
     int tile_seq;        // sequence number of the newest half-tile DMA
 };
 
-__device__ __forceinline__ void step_request(StepStream& st, char* ring, const float* __restrict__ wpack, int wave, int lane) {
-    int req = st.gs + kRingAhead;
+// `gs`: this step's number within the tile -- a constant at every call site once the half's loops are unrolled (PipeStream counts
+// it), so that the chunk's byte offset is an immediate; `wbase`: the weight pack + this wave's quarter of a chunk.
+__device__ __forceinline__ void step_request(StepStream& st, int gs, uint32_t ring_lds, const char* wbase, int lane) {
+    int req = gs + kRingAhead;
     bool go = true;
     if (req >= st.nsteps) {
         go = st.have_next;
@@ -1068,7 +1132,7 @@ __device__ __forceinline__ void step_request(StepStream& st, char* ring, const f
     if (go) {
         int s2 = st.slot + kRingAhead;
         if (s2 >= kRingSlots) s2 -= kRingSlots;
-        weight_chunk_async(ring + s2 * 4096, wpack + (size_t)req * kChunkFloats, wave, lane);
+        lds_dma16_at(wbase, (uint32_t)req * 4096u, (uint32_t)(lane * 16), ring_lds + s2 * 4096);
         ++st.issued;
     }
     st.q[kRingAhead - 1] = st.issued;  // nothing requested: nothing newer to wait for either
@@ -1080,7 +1144,6 @@ __device__ __forceinline__ void step_advance(StepStream& st, bool tile) {
     int need = st.q[EXTRA];
     if (tile && st.tile_seq > need) need = st.tile_seq;
     wait_vm_barrier<EXTRA == 0>(st.issued - need);  // (EXTRA = 1: the split-half loop, which reads a step ahead)
-    st.gs = st.gs + 1 == st.nsteps ? 0 : st.gs + 1;
     st.slot = st.slot == kRingSlots - 1 ? 0 : st.slot + 1;
 }
 
@@ -1088,20 +1151,11 @@ __device__ __forceinline__ void step_advance(StepStream& st, bool tile) {
 // (n, y0, x0) of `src` into `buf`.  ng = 0: nothing (last half of the last tile).
 struct HalfRequest {
     int ng;
-    uint32_t buf;
-    const float* src;
-    int khalf, n, y0, x0;
+    const char* origin;  // this wave's 16-byte channel group of the tile's first (halo) pixel: formed ONCE per half, in SGPRs
+    uint32_t dst;        // this wave's plane of the LDS buffer
 };
 
-__device__ __forceinline__ void wait_vm(int pending) {  // s_waitcnt vmcnt(pending), pending any value (>= 16: waits for all)
-    switch (pending) {
-#define SR_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        SR_CASE(1) SR_CASE(2) SR_CASE(3) SR_CASE(4) SR_CASE(5) SR_CASE(6) SR_CASE(7) SR_CASE(8) SR_CASE(9) SR_CASE(10)
-        SR_CASE(11) SR_CASE(12) SR_CASE(13) SR_CASE(14) SR_CASE(15)
-#undef SR_CASE
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
+__device__ __forceinline__ void wait_vm(int pending) { wait_vm_n<false>(pending); }  // s_waitcnt vmcnt(pending), any pending (> 15: 15)
 
 // Final stage of the pipe form: the input pixels the bilinear taps need (a (TH+2) x (32+2) tile, edge-replicated
 // coordinates: LinearInterp clamps indices) are requested at the start of the tile's LAST half and parked in
@@ -1138,6 +1192,12 @@ struct LinPrefetch {
     // wait for the pixels, convert (img_to_data: u8 / 255, true division) and write the [pixel][4] tile
     __device__ __forceinline__ void store(float* s_x, int tid, const StepStream& st) {
         wait_vm(st.issued - seq);
+        // (the loads above returned into raw[] behind the compiler's back: tie every use to this point, after the wait -- without the
+        // dependence a pure use, the conversion below, may be scheduled above the wait; see also scripts/check_async_regs.py)
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) asm volatile("" : "+v"(raw[k][ch]));
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int p = tid + 256 * k;
@@ -1179,6 +1239,7 @@ __device__ __forceinline__ void queue_pull_async(const StageArgs& a, int xcd, in
 __device__ __forceinline__ void queue_presolve(const StageArgs& a, int xcd, int wave, int lane, StepStream& st, QueueState& qs) {
     if (wave != 0) return;
     wait_vm(st.issued - qs.seq_pull);
+    asm volatile("" : "+v"(qs.pulled));  // the atomic's result: no use of it may move above the wait
     const int idx = __builtin_amdgcn_readfirstlane((int)qs.pulled);
     qs.own = queue_slot(xcd, a.grid[0].ntiles, a.grid[1].ntiles, idx);
     if (qs.own < 0) {
@@ -1194,6 +1255,7 @@ __device__ __forceinline__ void queue_publish(const StageArgs& a, int xcd, int w
     if (t < 0) {
         const int nbig = a.grid[0].ntiles, nsmall = a.grid[1].ntiles;
         wait_vm(st.issued - qs.seq_snap);
+        asm volatile("" : "+v"(qs.heads));
         for (int k = 1; k < 8 && t < 0; ++k) {
             const int x = (xcd + k) & 7;
             if ((int)__builtin_amdgcn_readlane((int)qs.heads, x) >= queue_total(x, nbig, nsmall)) continue;  // heads only grow: nothing there
@@ -1214,7 +1276,9 @@ struct PipeStream {
     const HalfRequest& rq;
     const HalfTile<KSN>& htn;
     const StageArgs& a;
-    char* ring;
+    uint32_t ring_lds;      // LDS address of ring slot 0 + this wave's quarter of a chunk
+    const char* wbase;      // the stage's weight pack + this wave's quarter of a chunk
+    int gs0;                // number of this half's first step within the tile
     int wave, lane;
     volatile int* mailbox;  // non-null (half 0): the next tile's number goes there before the last step's barrier
     int xcd;
@@ -1222,16 +1286,14 @@ struct PipeStream {
     int snap_step;          // half 0: the step at which the queue's answer is looked at
     int step_no;
     __device__ __forceinline__ void begin_step() {
-        step_request(st, ring, a.wpack, wave, lane);
-        if (mailbox) {
-            if (step_no == snap_step) queue_presolve(a, xcd, wave, lane, st, qs);
-            ++step_no;
-        }
+        step_request(st, gs0 + step_no, ring_lds, wbase, lane);
+        if (mailbox && step_no == snap_step) queue_presolve(a, xcd, wave, lane, st, qs);
+        ++step_no;
     }
     // gather instruction number g of the half tile being requested (g compile-time after unrolling)
     __device__ __forceinline__ void piece(int g) {
         if (g < HalfTile<KSN>::G::NG && g < rq.ng) {
-            htn.template stage_one<PREC>(g, rq.buf, rq.src, rq.khalf, a.img_stride, a.pitch, rq.n, rq.y0, rq.x0, wave);
+            htn.stage_one(g, rq.origin, rq.dst);
             st.tile_seq = ++st.issued;
         }
     }
@@ -1262,6 +1324,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     const int i = lane & 31;
     const int nbig = a.grid[0].ntiles, nsmall = a.grid[1].ntiles;
     const int xcd = blockIdx.x & 7;
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(lds_addr(ring) + wave * 1024);
+    const char* wbase = uniform_ptr((const char*)a.wpack + wave * 1024);
     float bias[NTN];
 #pragma unroll
     for (int nt = 0; nt < NTN; ++nt) bias[nt] = a.bias[nt * 32 + i];
@@ -1303,7 +1367,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
     constexpr int NG0 = H0::G::NG;
     // sequence numbers so far: half tile 1..NG0, chunks 0..3 = NG0+1..NG0+4; q[] is shifted before use (step_request)
-    StepStream st{0, 0, NSTEPS, false, NG0 + kRingAhead, {0, NG0 + 2, NG0 + 3, NG0 + 4}, NG0};
+    StepStream st{0, NSTEPS, false, NG0 + kRingAhead, {0, NG0 + 2, NG0 + 3, NG0 + 4}, NG0};
     static_assert(kRingAhead == 4, "q[] initialiser");
     // half 0 and chunk 0 (split: and 1) are in; the later chunks may still be in flight
     wait_vm_barrier<true>(st.issued - (NG0 + 1 + (PREC == 1 ? 1 : 0)));
@@ -1345,14 +1409,21 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             // half j+1 of this tile, or the next tile's half 0, goes into the buffer half j-1 has just left; a 4-row tile
             // needs only the first NG_SMALL gather groups of it
             HalfRequest rq;
-            if constexpr (j + 1 < NH) rq = HalfRequest{T == 2 ? HalfTile<KSN>::G::NG : HalfTile<KSN>::NG_SMALL, other, a.src[(j + 1) >> 1], (j + 1) & 1, n, y0, x0};
-            else rq = HalfRequest{!st.have_next ? 0 : nsmall_tile ? HalfTile<KSN>::NG_SMALL : HalfTile<KSN>::G::NG, other, a.src[0], 0, nn, ny0, nx0};
+            if constexpr (j + 1 < NH)
+                rq = HalfRequest{T == 2 ? HalfTile<KSN>::G::NG : HalfTile<KSN>::NG_SMALL,
+                                 HalfTile<KSN>::template origin_of<PREC>(a.src[(j + 1) >> 1], (j + 1) & 1, a.img_stride, a.pitch, n, y0, x0, wave),
+                                 HalfTile<KSN>::plane_of(other, wave)};
+            else
+                rq = HalfRequest{!st.have_next ? 0 : nsmall_tile ? HalfTile<KSN>::NG_SMALL : HalfTile<KSN>::G::NG,
+                                 HalfTile<KSN>::template origin_of<PREC>(a.src[0], 0, a.img_stride, a.pitch, nn, ny0, nx0, wave),
+                                 HalfTile<KSN>::plane_of(other, wave)};
             if constexpr (FINAL && j == NH - 1) linpx.issue(a, n, y0, x0, tid, st);
             const HalfTile<KSN>* htn;
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
             using GJ = TileGeom<8, KSJ>;
             constexpr int STEPS_J = HalfTile<KSJ>::STEPS * NTN;
-            PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring, wave, lane, (j == 0 && !single) ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0};
+            constexpr int GS0 = (j == 0 ? 0 : j == 1 ? H0::STEPS : 2 * H0::STEPS + (j - 2) * H3::STEPS) * NTN;  // steps of the halves before this one
+            PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring_lds, wbase, GS0, wave, lane, (j == 0 && !single) ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0};
             if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN>(acc, hb, ring, sm, wave, lane);
             else half_steps_h<GJ::TWH, GJ::PLANE, 2, KSJ, T, NTN>(acc, accx, hb, ring, sm, wave, lane);
         };
@@ -1379,92 +1450,20 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     while (true) {
         if (small) tile_body(std::integral_constant<int, 1>{});
         else tile_body(std::integral_constant<int, 2>{});
-        if (!st.have_next || --budget <= 0) break;
+        if (!st.have_next) break;
+        if (--budget <= 0) {
+            // Unreachable while the queue is consistent.  A successor was announced, so its first half tile and weight chunks are on
+            // their way into LDS and a tile has been taken from the queue: leaving quietly would drop that tile.  Let the DMAs land, then
+            // fail the launch loudly (the host sees a HIP error on this stream) rather than return an image with a hole in it.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_trap();
+        }
         n = nn; x0 = nx0; y0 = ny0; small = nsmall_tile;
     }
     // (nothing is in flight towards LDS here: the last tile requested no successor; s_endpgm waits for the stores)
 }
 
-// ---------------------------------------------------------------------------
-// The two parameter-free graphs of the reference: bilinear_net (network.rs:111-123,
-// `-p bilinear`) and downsample_net (network.rs:125-138, `-d`).  Elementwise,
-// HBM-trivial: one thread per output pixel.
-// ---------------------------------------------------------------------------
-namespace {
-__device__ __forceinline__ float srgb_to_linear(float s) {  // alumina SrgbToLinear: IEC 61966-2-1
-    return s <= 0.04045f ? s / 12.92f : powf((s + 0.055f) / 1.055f, 2.4f);
-}
-__device__ __forceinline__ float linear_to_srgb(float l) {  // alumina LinearToSrgb
-    return l <= 0.0031308f ? 12.92f * l : 1.055f * powf(l, 1.0f / 2.4f) - 0.055f;
-}
-__device__ __forceinline__ uint32_t quant_u8(float v) {  // data_to_img (main.rs:175)
-    return (uint32_t)fminf(fmaxf(floorf(255.0f * v + 0.5f), 0.0f), 255.0f);
-}
-}  // namespace
-
-template <bool IMG_U8, bool OUT_U8>
-__global__ __launch_bounds__(256) void bilinear_srgb_kernel(AuxArgs a) {
-    const size_t total = (size_t)a.n * a.H * 3 * a.W * 3;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int OW = a.W * 3, OH = a.H * 3;
-        const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), n = (int)(idx / ((size_t)OW * OH));
-        const int x = ox / 3, px = ox - 3 * x, y = oy / 3, py = oy - 3 * y;
-        // LinearInterp x3 (network.rs:118), same phase weights as the oracle's linterp3_acc
-        const float tx = px == 0 ? 2.0f / 3.0f : (px == 1 ? 0.0f : 1.0f / 3.0f);
-        const float ty = py == 0 ? 2.0f / 3.0f : (py == 1 ? 0.0f : 1.0f / 3.0f);
-        const int xa = min(max(x + (px == 0 ? -1 : 0), 0), a.W - 1), xb = min(max(x + (px == 0 ? 0 : 1), 0), a.W - 1);
-        const int ya = min(max(y + (py == 0 ? -1 : 0), 0), a.H - 1), yb = min(max(y + (py == 0 ? 0 : 1), 0), a.H - 1);
-        const size_t p0 = (size_t)n * a.H * a.W;
-        float o[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v00 = srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)ya * a.W + xa, c));
-            const float v01 = srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)ya * a.W + xb, c));
-            const float v10 = srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)yb * a.W + xa, c));
-            const float v11 = srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)yb * a.W + xb, c));
-            const float ra = (1.0f - tx) * v00 + tx * v01, rb = (1.0f - tx) * v10 + tx * v11;
-            o[c] = linear_to_srgb((1.0f - ty) * ra + ty * rb);
-        }
-        if constexpr (OUT_U8) ((uint32_t*)a.out)[idx] = quant_u8(o[0]) | (quant_u8(o[1]) << 8) | (quant_u8(o[2]) << 16) | 0xff000000u;
-        else { float* d = (float*)a.out + idx * 3; d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; }
-    }
-}
-
-template <bool IMG_U8, bool OUT_U8>
-__global__ __launch_bounds__(256) void downsample_srgb_kernel(AuxArgs a) {
-    const int OH = a.H / 3, OW = a.W / 3;  // remainder rows / columns dropped (unpinned, see oracle)
-    const size_t total = (size_t)a.n * OH * OW;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), n = (int)(idx / ((size_t)OW * OH));
-        const size_t p0 = (size_t)n * a.H * a.W;
-        float o[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float acc = 0.f;
-            for (int dy = 0; dy < 3; ++dy)
-                for (int dx = 0; dx < 3; ++dx)
-                    acc += srgb_to_linear(load_img(a.img, a.img_ch, IMG_U8, p0 + (size_t)(3 * oy + dy) * a.W + 3 * ox + dx, c));
-            o[c] = linear_to_srgb(acc / 9.0f);
-        }
-        if constexpr (OUT_U8) ((uint32_t*)a.out)[idx] = quant_u8(o[0]) | (quant_u8(o[1]) << 8) | (quant_u8(o[2]) << 16) | 0xff000000u;
-        else { float* d = (float*)a.out + idx * 3; d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; }
-    }
-}
-
-hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, hipStream_t s) {
-    const size_t total = graph == 1 ? (size_t)a.n * a.H * 3 * a.W * 3 : (size_t)a.n * (a.H / 3) * (a.W / 3);
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    if (grid == 0) return hipSuccess;
-    if (img_u8 != out_u8) return hipErrorInvalidValue;
-    if (graph == 1) {
-        if (img_u8) hipLaunchKernelGGL((bilinear_srgb_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((bilinear_srgb_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
-    } else {
-        if (img_u8) hipLaunchKernelGGL((downsample_srgb_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((downsample_srgb_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
-    }
-    return hipGetLastError();
-}
+// (the two parameter-free graphs of the reference, bilinear_net and downsample_net, live in sr_aux.hip)
 
 // ---------------------------------------------------------------------------
 // zero border of the feature maps for a new geometry: one workgroup per buffer row (and per map)

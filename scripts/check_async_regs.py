@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Lint of the device assembly: a VGPR that an inline-asm VMEM instruction returns into asynchronously (the queue's
-returning atomic, the head snapshot, the final stage's pixel prefetch) must not be READ before an s_waitcnt vmcnt -- the
-compiler does not know those asm outputs land later and is free to copy them at once (it did, when such a register was
-live across the merge of the two tile bodies: round 3, a hang).  Scan from each such instruction to the next s_waitcnt
-vmcnt along the path the wave takes (unconditional branches followed, conditional ones fall through); flags any instruction
-that names the register as a source.
+returning atomic, the head snapshot, the final stage's pixel prefetch) must not be READ before an s_waitcnt vmcnt that
+COVERS it -- the compiler does not know those asm outputs land later and is free to copy them at once (it did, when such
+a register was live across the merge of the two tile bodies: round 3, a hang).  From each such instruction every path the
+wave can take is walked (both sides of a conditional branch) until a covering wait.  The kernels' OWN waits (inline asm:
+wait_vm / wait_vm_barrier, whose immediate is picked at run time from the sequence numbers StepStream keeps) are trusted;
+a wait the COMPILER inserted, `s_waitcnt vmcnt(N)` outside an asm block, covers the instruction only if at least N VMEM
+instructions were issued after it on that path (memory instructions retire in order, so "at most N outstanding" then
+includes it among the retired ones; with a larger N it does not and the walk goes on).  Any instruction on the way that
+names the register as a source is flagged.
 
     python scripts/check_async_regs.py [file.s]      (without an argument: compiles sr_kernels.hip to assembly, ~90 s)
 Exit status 1 when something is flagged."""
@@ -15,6 +19,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VMEM = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "scratch_load", "scratch_store",
+        "flat_load", "flat_store", "flat_atomic")
 ASYNC = re.compile(r"^\s*(global_atomic_add|global_load_dword|global_load_ubyte)\s+(v\d+),\s*v\[?\d+")
 
 
@@ -42,6 +48,13 @@ def main():
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if m:
             labels[m.group(1)] = i
+    in_asm, flag = [], False
+    for l in lines:
+        if "#ASMSTART" in l:
+            flag = True
+        elif "#ASMEND" in l:
+            flag = False
+        in_asm.append(flag)
     bad, checked, inasm, func = 0, 0, False, "?"
     for i, l in enumerate(lines):
         if l.startswith("_Z") and l.rstrip().endswith(("Args:", "Args")) or re.match(r"^_Z\w+:", l):
@@ -55,33 +68,51 @@ def main():
             continue
         checked += 1
         dst = int(m.group(2)[1:])
-        j, steps = i, 0
-        while steps < 4000 and j + 1 < len(lines):
-            j += 1
-            steps += 1
-            t = lines[j].split(";")[0].strip()
-            if not t or t.endswith(":") or t.startswith("."):
-                continue
-            if t.startswith("s_branch "):  # follow the path the wave takes (conditional branches: the fall-through)
-                tgt = t.split()[1]
-                if tgt in labels:
-                    j = labels[tgt]
-                continue
-            if t.startswith("s_waitcnt") and "vmcnt" in t:
-                break
-            if t.startswith("s_endpgm"):
-                break
-            ops = t.replace(",", " ").split()
-            srcs = set()
-            for tok in ops[2:]:  # ops[1] is the destination of almost every VALU / VMEM-load form
-                srcs |= regs_of(tok)
-            if ops[0].startswith(("global_store", "ds_write", "buffer_store", "global_load_lds", "v_cmp", "v_readlane", "v_readfirstlane")):
-                for tok in ops[1:]:
+        # depth-first over the paths from here; best[j] = fewest VMEM instructions issued since the asm with which line j was reached
+        # (fewer is the harder case for a wait to cover, so a revisit with more is pruned)
+        stack, best, steps, flagged = [(i, 0)], {}, 0, False
+        while stack and not flagged and steps < 200000:
+            j, issued = stack.pop()
+            while j + 1 < len(lines) and steps < 200000:
+                j += 1
+                steps += 1
+                if j in best and best[j] <= issued:
+                    break
+                best[j] = issued
+                t = lines[j].split(";")[0].strip()
+                if not t or t.endswith(":") or t.startswith(".") or t.startswith("#"):
+                    continue
+                ops = t.replace(",", " ").split()
+                if ops[0] == "s_branch":
+                    if ops[1] in labels:
+                        j = labels[ops[1]]
+                        continue
+                    break
+                if ops[0].startswith("s_cbranch") and ops[-1] in labels:
+                    stack.append((labels[ops[-1]], issued))  # ... and the fall-through below
+                    continue
+                if ops[0] in ("s_endpgm", "s_setpc_b64"):
+                    break
+                if ops[0] == "s_waitcnt":
+                    mm = re.search(r"vmcnt\((\d+)\)", t)
+                    if mm and (in_asm[j] or int(mm.group(1)) <= issued):
+                        break  # covered on this path
+                    continue
+                srcs = set()
+                for tok in ops[2:]:  # ops[1] is the destination of almost every VALU / VMEM-load form
                     srcs |= regs_of(tok)
-            if dst in srcs:
-                print(f"{func}: line {j + 1}: `{t}` reads v{dst} before the wait for `{l.strip()}` (line {i + 1})")
-                bad += 1
-                break
+                if ops[0].startswith(("global_store", "ds_write", "buffer_store", "scratch_store", "global_load_lds", "v_cmp", "v_readlane", "v_readfirstlane")):
+                    for tok in ops[1:]:
+                        srcs |= regs_of(tok)
+                if dst in srcs:
+                    print(f"{func}: line {j + 1}: `{t}` reads v{dst} before a wait that covers `{l.strip()}` (line {i + 1})")
+                    bad += 1
+                    flagged = True
+                    break
+                if ops[0].startswith(VMEM):
+                    issued += 1
+                    if ops[0].startswith(("global_load", "buffer_load", "scratch_load", "flat_load")) and "lds" not in ops[0] and dst in regs_of(ops[1]):
+                        break  # the register is given a new value: the old result is dead on this path
     print(f"{checked} asynchronous asm results checked, {bad} read too early")
     return 1 if bad else 0
 

@@ -1,5 +1,5 @@
 /* comm_smoke.c -- one image over every visible GPU from ONE plain-C process: no torch, no Python, no MPI.
- *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/c/comm_smoke.c -Lrusty_sr_amd -lsrhip \
+ *   gcc -std=c99 -D_POSIX_C_SOURCE=199309L -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/c/comm_smoke.c -Lrusty_sr_amd -lsrhip \
  *       -L/opt/rocm/lib -lamdhip64 -o comm_smoke
  *   comm_smoke PARAMS.rsr [max_devices]
  * What it checks (SURVEY.md 8(b) "one RCCL communicator inside the context", 8(e) config C; the call being sharded is
@@ -12,6 +12,10 @@
  *   5. the calling thread's current HIP device is what it was before every call (the library restores it);
  *   6. error paths leave the set usable: duplicate devices refused by sr_comm_init_all, a band thinner than SR_HALO
  *      refused with SR_E_HALO, and after either the sharded call still works.
+ *   7. NUMBERS, whatever lease first sees several devices: config C (3840x2160 over all devices, equal bands) five times per
+ *      transport with per-stage profiling OFF (the bands run concurrently, as in production); per rank the device time of its
+ *      whole step and of its halo exchange, from the two event pairs libsrhip records on the band's stream (sr_last_timing /
+ *      sr_last_comm_ms), and the wall time of the call.
  * With one visible device the multi-device steps cannot run: RCCL admits one rank per device.  The program then runs
  * (4) with two contexts on device 0 (peer copy within one device), prints "skipped: 1 device" for (3) and exits 0. */
 #include <hip/hip_runtime_api.h>
@@ -19,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "srhip.h"
 
@@ -74,6 +79,56 @@ static int sharded_equals(sr_ctx** ctxs, const int* dev, int n, const uint8_t* p
     if (!rc) printf("  %s over %d contexts: bit-identical (bands", what, n);
     if (!rc) { for (k = 0; k < n; ++k) printf(" %d", h_band[k]); printf(")\n"); }
     return rc;
+}
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+}
+
+static int cmp_double(const void* a, const void* b) { const double x = *(const double*)a, y = *(const double*)b; return x < y ? -1 : x > y; }
+
+/* config C on the devices of ctxs: 3840x2160 in n equal bands, timed; prints one line per rank (medians of 5 calls) */
+static int timed_config_c(sr_ctx** ctxs, const int* dev, int n, const char* what) {
+    enum { HC = 2160, WC = 3840, REPS = 5 };
+    int h_band[MAXDEV], k, rep;
+    const uint8_t* d_in[MAXDEV];
+    uint8_t* d_out[MAXDEV];
+    double band[MAXDEV][REPS], xchg[MAXDEV][REPS], wall[REPS];
+    const int home = current_device();
+    for (k = 0; k < n; ++k) h_band[k] = HC * (k + 1) / n - HC * k / n;
+    for (k = 0; k < n; ++k) {
+        void *pi = NULL, *po = NULL;
+        HIP(hipSetDevice(dev[k]));
+        HIP(hipMalloc(&pi, (size_t)h_band[k] * WC * 3));
+        HIP(hipMalloc(&po, (size_t)9 * h_band[k] * WC * 4));
+        HIP(hipMemset(pi, 0x5a, (size_t)h_band[k] * WC * 3));
+        d_in[k] = (const uint8_t*)pi; d_out[k] = (uint8_t*)po;
+    }
+    HIP(hipSetDevice(home));
+    for (rep = -2; rep < REPS; ++rep) {  /* two warm-up calls: workspaces, clocks, RCCL's lazy connections */
+        const double t0 = now_ms();
+        CHECK(sr_upscale_sharded_rgba8_all(ctxs, n, d_in, 3, h_band, WC, d_out));
+        if (rep < 0) continue;
+        wall[rep] = now_ms() - t0;
+        for (k = 0; k < n; ++k) {
+            double tot = 0, cm = 0;
+            CHECK(sr_last_timing(ctxs[k], &tot, NULL, NULL, NULL));
+            CHECK(sr_last_comm_ms(ctxs[k], &cm));
+            band[k][rep] = tot; xchg[k][rep] = cm;
+        }
+    }
+    qsort(wall, REPS, sizeof(double), cmp_double);
+    printf("  config C, %dx%d over %d contexts, %s: wall %.3f ms per call (median of %d) = %.0f output MP/s\n", WC, HC, n, what, wall[REPS / 2], REPS,
+           9.0 * HC * WC / 1e6 / (wall[REPS / 2] / 1e3));
+    for (k = 0; k < n; ++k) {
+        qsort(band[k], REPS, sizeof(double), cmp_double);
+        qsort(xchg[k], REPS, sizeof(double), cmp_double);
+        printf("    rank %d (device %d, %d rows): step %.3f ms, of which halo exchange %.3f ms\n", k, dev[k], h_band[k], band[k][REPS / 2], xchg[k][REPS / 2]);
+    }
+    for (k = 0; k < n; ++k) { (void)hipFree((void*)d_in[k]); (void)hipFree(d_out[k]); }
+    return 0;
 }
 
 int main(int argc, char** argv) {
@@ -147,6 +202,9 @@ int main(int argc, char** argv) {
         if (sharded_equals(ctxs, dev, ndev, px, want, "peer copy (sr_comm_init_local)")) return 1;
         CHECK(sr_comm_init_all(ctxs, ndev));                              /* and back: a set may change transport */
         if (sharded_equals(ctxs, dev, ndev, px, want, "RCCL again")) return 1;
+        if (timed_config_c(ctxs, dev, ndev, "RCCL")) return 1;
+        CHECK(sr_comm_init_local(ctxs, ndev));
+        if (timed_config_c(ctxs, dev, ndev, "peer copy")) return 1;
     } else {
         printf("  RCCL over several devices: skipped: 1 device\n");
         sr_ctx* two[2];
@@ -155,6 +213,7 @@ int main(int argc, char** argv) {
         CHECK(sr_create(&two[1], params, n, SR_FACTOR, 0));
         CHECK(sr_comm_init_local(two, 2));
         if (sharded_equals(two, dev0, 2, px, want, "peer copy, two contexts of device 0")) return 1;
+        if (timed_config_c(two, dev0, 2, "peer copy, both contexts on device 0 (a rehearsal, not a measurement of two GPUs)")) return 1;
         sr_destroy(two[1]);
         CHECK(sr_comm_init_rank(ctxs[0], NULL, 0, 0, 1));
     }

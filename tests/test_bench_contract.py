@@ -33,6 +33,15 @@ def test_bench_single_gpu_contract():
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["source"].startswith("hip_events")
+    # `frac` is quoted on the AVERAGE launch duration (the conservative figure), the median stands beside it
+    assert 0 < rf["frac_at_median"] <= 1 and rf["avg_launch_ms"] > 0 and rf["median_launch_ms"] > 0
+    assert abs(rf["frac_at_median"] * rf["median_launch_ms"] - rf["frac"] * rf["avg_launch_ms"]) < 1e-3 * rf["frac"] * rf["avg_launch_ms"] + 1e-4
+    su = d["sustained"]  # the headline step looped for seconds, not for 3 steps
+    assert "error" not in su and su["wall_s"] >= 2.5 and su["steps"] > 100 and su["ms_per_step"] > 0 and su["event_ms_p95"] >= su["event_ms_median"]
+    assert "error" not in d["fork_ab"] and d["fork_ab"]["undivided_ms"] > 0 and d["fork_ab"]["forked_ms"] > 0
+    aux = d["aux_graphs"]["entries"]  # the two parameter-free graphs, u8 and f32, at the frame size and at 3x it
+    assert {(e["graph"], e["io"]) for e in aux} == {(g, io) for g in ("bilinear_net", "downsample_net") for io in ("rgba8", "f32")}
+    assert all(e["ms"] > 0 and 0 < e["frac_of_8TBps"] < 1 for e in aux)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["leg"] in cb["legs"] and cb["value"] == max(cb["legs"][k]["value"] for k in ("c_oracle", "torch_cpu") if "value" in cb["legs"][k])

@@ -12,7 +12,7 @@ from conftest import ROOT
 
 def _build(tmp_path):
     exe = tmp_path / "comm_smoke"
-    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+    cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=199309L", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "tests", "c", "comm_smoke.c"), "-L", os.path.join(ROOT, "rusty_sr_amd"), "-lsrhip", "-L", "/opt/rocm/lib",
            "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "rusty_sr_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
     subprocess.check_call(cmd)
@@ -35,3 +35,4 @@ def test_comm_smoke_runs(tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.rstrip().endswith("comm_smoke ok")
     assert "bit-identical" in res.stdout
+    assert "config C, 3840x2160 over" in res.stdout and "halo exchange" in res.stdout  # the per-rank numbers a multi-GPU lease should yield

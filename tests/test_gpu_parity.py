@@ -544,3 +544,37 @@ def test_other_factors_against_the_restatement(factor, precision):
 def test_factor3_general_path_is_the_pinned_path(params):
     x = oracle.img_to_data(synth_u8(5, 1, 21, 34))
     np.testing.assert_array_equal(oracle.forward_factor(params["anime"], x, 3), oracle.forward(params["anime"], x))
+
+
+def test_forked_device_call_is_bit_identical(engines):
+    """sr_upscale_*_dev / sr_upscale_band_*_dev may run one image as TWO row bands on two streams (sr_run_stack_auto: the drain of
+    one band's launch under the fill of the other's): whatever the cut, the bytes must be those of the undivided pass -- u8 and
+    f32, whole images and bands with halos, heights that leave every remainder of 8 rows, forced cuts and the automatic one --
+    and the call must stay ordered on the caller's stream (the result is read on that stream without a device-wide sync)."""
+    import torch
+    eng = engines["imagenet"]
+    rng = np.random.default_rng(77)
+    side = torch.cuda.Stream()
+    try:
+        for (h, w, top, bot) in ((64, 96, 0, 0), (131, 257, 0, 0), (300, 515, 0, 0), (83, 640, 7, 0), (90, 333, 7, 7), (77, 1024, 0, 7), (1080, 1920, 0, 0)):
+            px = torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).cuda()
+            x = px.to(torch.float32) / 255.0
+            band = top or bot
+            def run8(stream=None):
+                return eng.upscale_band_rgba8_dev(px, top, bot, stream=stream) if band else eng.upscale_rgba8_dev(px[None], stream=stream)[0]
+            def run32(stream=None):
+                return eng.upscale_band_f32_dev(x, top, bot, stream=stream) if band else eng.upscale_f32_dev(x[None], stream=stream)[0]
+            eng.set_experiment("fork", "0")
+            want8, want32 = run8(), run32()
+            torch.cuda.synchronize()
+            own = h - top - bot
+            cuts = ["1"] + [str(c) for c in (14, 16, 21, own // 2 + 3, own - 14) if 14 <= c <= own - 14]
+            for cut in cuts:
+                eng.set_experiment("fork", cut)
+                with torch.cuda.stream(side):
+                    got8 = run8(side)
+                    got32 = run32(side)
+                    same8, same32 = torch.equal(got8, want8), torch.equal(got32, want32)  # on the caller's stream: ordered behind the join
+                assert same8 and same32, (h, w, top, bot, cut)
+    finally:
+        eng.set_experiment("fork", "")
