@@ -147,17 +147,19 @@ def roofline_of(stage_ms, rows, W, precision):
 
 
 def read_sclk_mhz(device=0):
-    """Current shader clock of the GPU as the driver reports it (sysfs pp_dpm_sclk: the level marked '*'), or None."""
+    """Current shader clock as the driver reports it (sysfs pp_dpm_sclk: the level marked '*'), or None.  A GPU pod sees the sysfs
+    nodes of every card of its host but owns one; the others sleep (level 'S', ~95 MHz), so the busiest card's clock is reported."""
     import glob
-    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-    for path in cards[device:device + 1] or cards[:1]:
+    best = None
+    for path in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
         try:
             for line in open(path):
                 if "*" in line:
-                    return int(line.split(":")[1].strip().split("M")[0].lower().replace("mhz", "").strip())
+                    mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+                    best = mhz if best is None else max(best, mhz)
         except Exception:
             pass
-    return None
+    return best
 
 
 def aux_entries(r, torch, sizes=((1080, 1920),), reps=200, device=0):

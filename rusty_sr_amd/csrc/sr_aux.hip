@@ -5,8 +5,8 @@
 //   downsample_net : out = LinearToSrgb(mean 3x3(SrgbToLinear(x)))                 27 / 108 B in per output px
 //
 // Both are HBM-bound by their I/O if the transfer functions cost nothing, so that is what the kernels arrange:
-//  * u8 in : SrgbToLinear of a byte is a 256-entry table (built per workgroup in LDS with the same powf expression the
-//    one-thread-per-pixel kernels of rounds 1-3 evaluated per sample: bit-identical);
+//  * u8 in : SrgbToLinear of a byte is a 256-entry table (built once per context with the same powf expression the
+//    one-thread-per-pixel kernels of rounds 1-3 evaluated per sample: bit-identical; copied into LDS per workgroup);
 //  * u8 out: data_to_img(LinearToSrgb(l)) is a monotone step function of l with 255 steps.  The steps' positions (the
 //    smallest float l that quantises to k, k = 1..255) are found ONCE per context by bisection over the float bit
 //    patterns with the same powf expression (threshold_kernel), and laid out as a table indexed by the top 16 bits of
@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -31,6 +32,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -48,11 +50,13 @@ __device__ __forceinline__ float linear_to_srgb_fast(float l) { return l <= 0.00
 // ---- quantiser table: byte = base + (l >= step) for the bucket of l
 constexpr int kQExp0 = 114;                       // biased exponent of 2^-13: below it every l quantises to 0
 constexpr int kQBuckets = (127 - kQExp0) * 128;   // [2^-13, 1) in 128 buckets per octave; entry kQBuckets: l >= 1 -> 255
+constexpr int kQEntries = kQBuckets + 8;          // ... and seven more of the same: the index has no upper clamp (see quant_lookup)
 struct QEntry { float step; uint32_t base; };
 __device__ __forceinline__ uint32_t quant_lookup(const QEntry* tab, float l) {
-    // (arithmetic shift: zero, everything below 2^-13 and negative values land at or below 0 -> bucket 0, whose base is 0; from 1.0 up
-    // -> the last bucket, 255.  The u8 entry points never produce a NaN here: table values and weights are finite and >= 0.)
-    const int idx = min(max(((int)__float_as_uint(l) >> 16) - (kQExp0 << 7), 0), kQBuckets);
+    // (arithmetic shift: zero, everything below 2^-13 and negative values land at or below 0 -> bucket 0, whose base is 0.  No upper
+    // clamp: the u8 entry points interpolate table values in [0, 1] with weights that sum to 1 +- an ulp, so l < 1 + 2^-7 and the
+    // index stays within the seven spare entries behind bucket "1.0 and up"; one VALU instruction less on each of 36 lookups per item.)
+    const int idx = max(((int)__float_as_uint(l) >> 16) - (kQExp0 << 7), 0);
     const QEntry e = tab[idx];
     return e.base + (l >= e.step ? 1u : 0u);
 }
@@ -72,6 +76,9 @@ __global__ void threshold_kernel(float* steps) {
         if (quant_u8(linear_to_srgb(__uint_as_float(hi - 1))) >= k) --hi;
     steps[k - 1] = __uint_as_float(hi);
 }
+
+// img_to_data (main.rs:170: byte / 255, a true division) then SrgbToLinear, for every byte value: 256 floats behind the step table
+__global__ void lut_kernel(float* lut) { lut[threadIdx.x] = srgb_to_linear(__fdiv_rn((float)threadIdx.x, 255.0f)); }
 
 constexpr int kBlTW = 64, kBlTH = 16;                      // bilinear: input tile; output tile 192 x 48
 constexpr int kBlTWH = kBlTW + 2, kBlTHH = kBlTH + 2, kBlNPIX = kBlTWH * kBlTHH;
@@ -95,37 +102,59 @@ template <bool IMG_U8, bool OUT_U8, bool ALIGNED>
 __global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
     __shared__ __attribute__((aligned(16))) float s_lin[kBlNPIX * 4];
     __shared__ float s_lut[IMG_U8 ? 256 : 1];
-    __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQBuckets + 1 : 1];
+    __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQEntries : 1];
     const int tid = threadIdx.x;
-    if constexpr (IMG_U8) s_lut[tid] = srgb_to_linear(__fdiv_rn((float)tid, 255.0f));  // img_to_data (main.rs:170), then SrgbToLinear
+    if constexpr (IMG_U8) s_lut[tid] = ((const float*)((const QEntry*)a.qtab + kQEntries))[tid];  // SrgbToLinear(byte / 255): lut_kernel
     if constexpr (OUT_U8) {
         const QEntry* q = (const QEntry*)a.qtab;
-        for (int k = tid; k <= kQBuckets; k += 256) s_q[k] = q[k];
+        for (int k = tid; k < kQEntries; k += 256) s_q[k] = q[k];
     }
     const int tiles_x = (a.W + kBlTW - 1) / kBlTW, tiles_y = (a.H + kBlTH - 1) / kBlTH;
     const long ntiles = (long)a.n * tiles_x * tiles_y;
     const int OW = 3 * a.W, OH = 3 * a.H;
     constexpr int EPP = OUT_U8 ? 1 : 3;               // 4-byte elements per output pixel
     constexpr int CPR = 3 * kBlTW * EPP / 4;          // chunks per output row of a full tile
+    // The input pixels of a tile travel global -> registers -> (table) -> LDS.  The loads of the NEXT tile are issued before this tile's
+    // arithmetic and land under it: every workgroup of the launch starts at the same moment, so without this all of them sit out the
+    // same load latency together, twice per tile pair.
+    constexpr int PER = (kBlNPIX + 255) / 256;
+    uint32_t raw[PER][3];
+    auto fetch = [&](long tile) {
+        const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int x0 = tx * kBlTW, y0 = ty * kBlTH;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int p = min(tid + 256 * k, kBlNPIX - 1), py = p / kBlTWH, px = p - py * kBlTWH;
+            const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
+            const size_t gp = ((size_t)n * a.H + gy) * a.W + gx;
+            if constexpr (IMG_U8) {
+                const uint8_t* q = (const uint8_t*)a.img + gp * a.img_ch;
+                raw[k][0] = q[0]; raw[k][1] = q[1]; raw[k][2] = q[2];
+            } else {
+                const uint32_t* q = (const uint32_t*)a.img + gp * 3;
+                raw[k][0] = q[0]; raw[k][1] = q[1]; raw[k][2] = q[2];
+            }
+        }
+    };
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
         const int x0 = tx * kBlTW, y0 = ty * kBlTH;
         __syncthreads();  // the previous tile's readers are done (and the tables are in place)
-        for (int p = tid; p < kBlNPIX; p += 256) {
-            const int py = p / kBlTWH, px = p - py * kBlTWH;
-            const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
-            const size_t gp = ((size_t)n * a.H + gy) * a.W + gx;
-            f32x4 v;
-            if constexpr (IMG_U8) {
-                const uint8_t* q = (const uint8_t*)a.img + gp * a.img_ch;
-                v = f32x4{s_lut[q[0]], s_lut[q[1]], s_lut[q[2]], 0.f};
-            } else {
-                const float* q = (const float*)a.img + gp * 3;
-                v = f32x4{srgb_to_linear_fast(q[0]), srgb_to_linear_fast(q[1]), srgb_to_linear_fast(q[2]), 0.f};
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int p = tid + 256 * k;
+            if (p < kBlNPIX) {
+                f32x4 v;
+                if constexpr (IMG_U8) v = f32x4{s_lut[raw[k][0]], s_lut[raw[k][1]], s_lut[raw[k][2]], 0.f};
+                else v = f32x4{srgb_to_linear_fast(__uint_as_float(raw[k][0])), srgb_to_linear_fast(__uint_as_float(raw[k][1])),
+                               srgb_to_linear_fast(__uint_as_float(raw[k][2])), 0.f};
+                *(f32x4*)&s_lin[p * 4] = v;
             }
-            *(f32x4*)&s_lin[p * 4] = v;
         }
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         __syncthreads();
         const int tw = min(kBlTW, a.W - x0), th = min(kBlTH, a.H - y0);  // this tile's own input pixels
         const int elems = 3 * tw * EPP;                                  // 4-byte elements per output row of this tile
@@ -140,17 +169,25 @@ __global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     int xa; float txv;
                     phase(4 * cx + e, xa, txv);
-                    f32x4 hh[3];
+                    // (R, G) as a packed pair, B alone: the fourth lane of the staged pixel is padding
+                    f32x2 hxy[3]; float hz[3];
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         const f32x4 v0 = *(const f32x4*)(row + (r * kBlTWH + xa) * 4), v1 = *(const f32x4*)(row + (r * kBlTWH + xa) * 4 + 4);
-                        hh[r] = (1.0f - txv) * v0 + txv * v1;
+                        hxy[r] = (1.0f - txv) * f32x2{v0.x, v0.y} + txv * f32x2{v1.x, v1.y};
+                        hz[r] = (1.0f - txv) * v0.z + txv * v1.z;
                     }
 #pragma unroll
                     for (int py = 0; py < 3; ++py) {
-                        const float tyv = py == 0 ? 2.0f / 3.0f : (py == 1 ? 0.0f : 1.0f / 3.0f);
-                        const f32x4 o = (1.0f - tyv) * hh[py == 0 ? 0 : 1] + tyv * hh[py == 0 ? 1 : 2];
-                        px4[py][e] = 0xff000000u | quant_lookup(s_q, o.x) | (quant_lookup(s_q, o.y) << 8) | (quant_lookup(s_q, o.z) << 16);
+                        f32x2 oxy; float oz;
+                        if (py == 1) {  // t = 0: (1 - 0) a + 0 b = a exactly (every value here is finite and >= 0)
+                            oxy = hxy[1]; oz = hz[1];
+                        } else {
+                            const float tyv = py == 0 ? 2.0f / 3.0f : 1.0f / 3.0f;
+                            oxy = (1.0f - tyv) * hxy[py == 0 ? 0 : 1] + tyv * hxy[py == 0 ? 1 : 2];
+                            oz = (1.0f - tyv) * hz[py == 0 ? 0 : 1] + tyv * hz[py == 0 ? 1 : 2];
+                        }
+                        px4[py][e] = 0xff000000u | quant_lookup(s_q, oxy.x) | (quant_lookup(s_q, oxy.y) << 8) | (quant_lookup(s_q, oz) << 16);
                     }
                 }
                 (void)h;
@@ -204,12 +241,12 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
     constexpr int ROW_BYTES = 3 * kDsTW * (IMG_U8 ? 4 : 12) + 16;   // a staged row segment (u8: up to 4 channels), + misalignment slack
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[3 * kDsTH * ROW_BYTES / 4];
     __shared__ float s_lut[IMG_U8 ? 256 : 1];
-    __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQBuckets + 1 : 1];
+    __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQEntries : 1];
     const int tid = threadIdx.x;
-    if constexpr (IMG_U8) s_lut[tid] = srgb_to_linear(__fdiv_rn((float)tid, 255.0f));
+    if constexpr (IMG_U8) s_lut[tid] = ((const float*)((const QEntry*)a.qtab + kQEntries))[tid];
     if constexpr (OUT_U8) {
         const QEntry* q = (const QEntry*)a.qtab;
-        for (int k = tid; k <= kQBuckets; k += 256) s_q[k] = q[k];
+        for (int k = tid; k < kQEntries; k += 256) s_q[k] = q[k];
     }
     const int OH = a.H / 3, OW = a.W / 3;  // remainder rows / columns dropped (unpinned, see oracle)
     const int tiles_x = (OW + kDsTW - 1) / kDsTW, tiles_y = (OH + kDsTH - 1) / kDsTH;
@@ -265,7 +302,8 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
 }  // namespace
 
 // The quantiser table of a context of one of these graphs (sr_create_graph): 255 step positions from the device's own
-// powf, laid out by bucket on the host.  *d_tab: kQBuckets + 1 entries of 8 bytes in device memory (hipFree'd by sr_destroy).
+// powf, laid out by bucket on the host.  *d_tab: kQEntries entries of 8 bytes, then the 256 floats of the input table
+// (lut_kernel), in device memory (hipFree'd by sr_destroy).
 hipError_t sr_aux_build_tables(void** d_tab) {
     *d_tab = nullptr;
     float* d_steps = nullptr;
@@ -277,7 +315,7 @@ hipError_t sr_aux_build_tables(void** d_tab) {
     if (e == hipSuccess) e = hipMemcpy(steps, d_steps, sizeof(steps), hipMemcpyDeviceToHost);
     (void)hipFree(d_steps);
     if (e != hipSuccess) return e;
-    std::vector<QEntry> tab(kQBuckets + 1);
+    std::vector<QEntry> tab(kQEntries);
     auto bucket_lo = [](int idx) {  // smallest float of bucket idx
         const uint32_t bits = ((uint32_t)(kQExp0 << 7) + (uint32_t)idx) << 16;
         float f;
@@ -289,8 +327,8 @@ hipError_t sr_aux_build_tables(void** d_tab) {
     for (int i = 1; i < 255; ++i)
         if (!(steps[i] > steps[i - 1])) return hipErrorUnknown;
     int k = 0;
-    for (int idx = 0; idx <= kQBuckets; ++idx) {
-        const float lo = idx > 0 ? bucket_lo(idx) : -INFINITY, hi = idx < kQBuckets ? bucket_lo(idx + 1) : INFINITY;
+    for (int idx = 0; idx < kQEntries; ++idx) {
+        const float lo = idx > 0 ? bucket_lo(std::min(idx, kQBuckets)) : -INFINITY, hi = idx < kQBuckets ? bucket_lo(idx + 1) : INFINITY;
         while (k < 255 && steps[k] < lo) ++k;
         tab[idx].base = (uint32_t)k;
         tab[idx].step = INFINITY;
@@ -299,9 +337,14 @@ hipError_t sr_aux_build_tables(void** d_tab) {
             if (k + 1 < 255 && steps[k + 1] < hi) return hipErrorUnknown;  // two steps in one bucket: cannot happen (see the header)
         }
     }
-    e = hipMalloc(d_tab, tab.size() * sizeof(QEntry));
+    e = hipMalloc(d_tab, tab.size() * sizeof(QEntry) + 256 * sizeof(float));
     if (e != hipSuccess) return e;
     e = hipMemcpy(*d_tab, tab.data(), tab.size() * sizeof(QEntry), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(lut_kernel, dim3(1), dim3(256), 0, nullptr, (float*)((QEntry*)*d_tab + tab.size()));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
     if (e != hipSuccess) { (void)hipFree(*d_tab); *d_tab = nullptr; }
     return e;
 }

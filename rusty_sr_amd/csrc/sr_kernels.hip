@@ -251,19 +251,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     __shared__ float s_lut[256];
     if constexpr (IMG_U8) s_lut[tid] = __fdiv_rn((float)tid, 255.0f);
     const float bias = a.bias[i], beta = a.beta[i];
-    // Staging plan of a tile, once per workgroup: thread t moves tile pixels t and t + 256; their byte offsets from the tile's
-    // first (halo) pixel do not depend on the tile.  An INTERIOR tile (halo inside the image, last image row excluded: the 4-byte
-    // load of a 3-byte pixel must not run past the buffer) then costs a thread one load at `uniform origin + offset`, two VALU
-    // instructions per sample for the table address and the LDS traffic -- the index arithmetic and the four bounds tests per pixel of
-    // the general path (~40 instructions per pixel, on the vector ALU the f32 MFMA shares) are paid by border tiles only.
-    constexpr int PER = (NPIX + kThreads - 1) / kThreads;
-    const uint32_t px_bytes = IMG_U8 ? (uint32_t)a.img_ch : 12u;
-    uint32_t rel[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int p = min(tid + kThreads * k, NPIX - 1), py = p / TWH, px = p - py * TWH;
-        rel[k] = (uint32_t)(py * a.W + px) * px_bytes;
-    }
   for (int bid = blockIdx.x; bid < a.n_tiles; bid += gridDim.x) {
     const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
     const int ty = tile_div(t, a.div_tx), tx = t - ty * a.tiles_x;
@@ -271,24 +258,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     const size_t img_px0 = (size_t)n * a.H * a.W;
 
     __syncthreads();  // the previous tile's reads of s_x are done
-    const bool interior = y0 >= 2 && y0 - 2 + THH < a.H && x0 >= 2 && x0 - 2 + TWH <= a.W;  // wave-uniform
-    if (interior) {
-        const char* origin = uniform_ptr((const char*)a.img + (img_px0 + (size_t)(y0 - 2) * a.W + (x0 - 2)) * px_bytes);
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int p = tid + kThreads * k;
-            if (p < NPIX) {
-                if constexpr (IMG_U8) {
-                    uint32_t v;
-                    __builtin_memcpy(&v, origin + rel[k], 4);  // one (unaligned) dword: R, G, B and a byte of the next pixel / alpha
-                    s_x[p * 3] = s_lut[v & 0xffu]; s_x[p * 3 + 1] = s_lut[(v >> 8) & 0xffu]; s_x[p * 3 + 2] = s_lut[(v >> 16) & 0xffu];
-                } else {
-                    const float* q = (const float*)(origin + rel[k]);
-                    s_x[p * 3] = q[0]; s_x[p * 3 + 1] = q[1]; s_x[p * 3 + 2] = q[2];
-                }
-            }
-        }
-    } else {
+    // (Round 4 tried a cheaper path for interior tiles -- per-thread byte offsets computed once per workgroup, one unaligned dword
+    // load per pixel, no bounds tests: 0.114 ms against 0.108 for this loop, and 0.127 with byte loads: profiles/r4_ab_variants_f32.txt.
+    // conv0's time is not in its staging arithmetic.)
     for (int p = tid; p < NPIX; p += kThreads) {
         const int py = p / TWH, px = p - py * TWH;
         const int gy = y0 - 2 + py, gx = x0 - 2 + px;
@@ -305,7 +277,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
             }
         }
         s_x[p * 3] = v.x; s_x[p * 3 + 1] = v.y; s_x[p * 3 + 2] = v.z;
-    }
     }
     __syncthreads();
 
@@ -577,8 +548,10 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
     // The split loop walks the taps COLUMN by column (tap t = kernel column t / KS, kernel row t % KS): row m of
     // tap (ky, kx) is tile row ky + m of column kx, so vertically adjacent taps share tile rows.  A row that the
     // current or the previous step already holds is copied between registers instead of read again: 12 LDS reads
-    // per 5-tap column and half instead of 20.  This mode is bound by LDS operand traffic (one ds_read_b128 per
-    // lane per 32-cycle MFMA saturates the LDS at full MFMA rate), VALU copies are free here.
+    // per 5-tap column and half instead of 20 (VALU copies cost the f16 matrix pipe nothing).  Round 4 measured what the reads
+    // themselves cost: with EVERY operand read of the loop removed the 1080p frame is 3.7 % faster, without the A reads 1.2 %
+    // (profiles/r4_split_operand_reads_removed.txt); the LDS array is 25 % busy and conflict-free (profiles/r4_pmc_split_binders.json).
+    // Operand traffic is not what holds this mode at mfma_util 0.66.
     auto row_id = [](int p, int ts, int m) {  // which (column, tile row) operand slot (ts, m) of step p holds; < 0: none
         const int t = 2 * p + ts;
         return t < NT ? (t / KS) * 16 + (t % KS) + m : -1;

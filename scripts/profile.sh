@@ -6,6 +6,10 @@
 # Raw output -> gpurun_out/prof_<tag>/, summaries -> gpurun_out/prof_<tag>/summary_*.csv
 set -u
 export TMPDIR=/tmp
+# The device call may run one frame as two half-frame launches per stage (sr_run_stack_auto); rocprofv3 --stats aggregates by
+# kernel NAME, so the profiled runs keep every launch a whole frame (what bench.py's `roofline` block is quoted on), and the
+# sustained loop short.
+export SRHIP_FORK=0 SRHIP_BENCH_SUSTAINED_S=0.3
 TAG=${1:-r1}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
