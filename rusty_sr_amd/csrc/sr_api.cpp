@@ -710,9 +710,11 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
         // automatic: where the launches have enough rounds of tiles for two bands to fill the chip each (measured)
         const int cus = c->cus > 0 ? c->cus : 256;
         const double rounds = (double)((W + 31) / 32) * ((own + 7) / 8) / (2.0 * cus);
-        // measured (scripts/fork_ab.py, profiles/r4_fork_ab_*.jsonl): exact f32 720p / 1080p gain, 540x960 (4 rounds) loses 3.5 %, 3840x2160
-        // (63 rounds: the launch boundaries are 0.6 % of the call) and the split-half mode (tiles of 14 us) lose 0.3-2 %
-        fork = c->precision == SR_PRECISION_F32 && rounds >= c->fork_min_rounds && rounds < c->fork_max_rounds;
+        // measured (scripts/fork_ab.py, profiles/r4_fork_ab_*.jsonl): exact f32 1280x720 (7 rounds) -0.5 %, 1920x1080 (16) -0.1 ... -1 %;
+        // 960x540 (4 rounds) +3.5 %, 2560x1440 (28) +0.2 %, 3840x2160 (63: the launch boundaries are 0.6 % of the call) +0.3 %, the
+        // split-half mode (tiles of 14 us) +0.3 ... +2 %
+        // (a 276-row band of a 3840-wide image has 8 rounds too, but its 14 recomputed rows are 5 % of it: +1 %)
+        fork = c->precision == SR_PRECISION_F32 && rounds >= c->fork_min_rounds && rounds < c->fork_max_rounds && own >= 640;
     }
     if (!fork) return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s);
     sr_device_guard restore_device;

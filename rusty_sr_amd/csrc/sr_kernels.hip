@@ -41,6 +41,7 @@
 //  * bias + BeLU (or bias + depth-to-space [+ u8 RGBA quantisation]) are fused
 //    into the epilogue: no elementwise kernel exists.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <mutex>
@@ -1163,7 +1164,8 @@ struct LinPrefetch {
         seq = st.issued;
     }
     // wait for the pixels, convert (img_to_data: u8 / 255, true division) and write the [pixel][4] tile
-    __device__ __forceinline__ void store(float* s_x, int tid, const StepStream& st) {
+    // (u8: through the table of byte / 255 -- the division itself is ~10 vector-ALU instructions per sample, in the matrix stream)
+    __device__ __forceinline__ void store(float* s_x, const float* s_lut, int tid, const StepStream& st) {
         wait_vm(st.issued - seq);
         // (the loads above returned into raw[] behind the compiler's back: tie every use to this point, after the wait -- without the
         // dependence a pure use, the conversion below, may be scheduled above the wait; see also scripts/check_async_regs.py)
@@ -1177,7 +1179,7 @@ struct LinPrefetch {
             if (p < NPIX) {
                 f32x4 v;
                 if constexpr (IMG_U8) {
-                    v.x = __fdiv_rn((float)raw[k][0], 255.0f); v.y = __fdiv_rn((float)raw[k][1], 255.0f); v.z = __fdiv_rn((float)raw[k][2], 255.0f);
+                    v.x = s_lut[raw[k][0]]; v.y = s_lut[raw[k][1]]; v.z = s_lut[raw[k][2]];
                 } else {
                     v.x = __uint_as_float(raw[k][0]); v.y = __uint_as_float(raw[k][1]); v.z = __uint_as_float(raw[k][2]);
                 }
@@ -1290,6 +1292,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     char* ring = smem + 2 * HB;
     volatile int* s_next = (volatile int*)(ring + kRingBytes);
     float* s_wlin = (float*)(ring + kRingBytes + 16);  // final stage: the 9 x 128 fixed weights of the bilinear taps, loaded once
+    float* s_lut = s_wlin + 9 * 2 * 128;               // final stage, u8 input: byte / 255 (img_to_data, a true division) for every byte value
     const uint32_t lds0 = lds_addr(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1308,23 +1311,32 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     h0.init(a.pitch, lane);
     if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
 
-    // combined tile id (queue_resolve) -> image, tile origin, tile class
+    // combined tile id (queue_resolve) -> image, tile origin, tile class.  The 16 dwords of the tile class's TileGrid (its divisors)
+    // are needed once per tile; held in SGPRs across the tile they are spilled to VGPR lanes (102 SGPRs are all there are) and come
+    // back as ~60 v_readlane per tile -- vector-ALU instructions in the matrix stream.  They are therefore re-read from the kernel
+    // argument segment with one scalar load (the pointer is laundered through an empty asm so that the compiler cannot merge the
+    // load with an earlier one and keep the values live again).
+    typedef const uint32_t __attribute__((address_space(4)))* KernWords;
+    static_assert(sizeof(TileGrid) == 64 && offsetof(StageArgs, grid) % 4 == 0, "TileGrid is read as 16 dwords");
     auto coords = [&](int t, int& n, int& x0, int& y0, bool& small) {
+        KernWords kw = (KernWords)__builtin_amdgcn_kernarg_segment_ptr();  // StageArgs is the kernel's only explicit argument: offset 0
+        asm volatile("" : "+s"(kw));
         int tx, ty;
         small = t >= nbig;
-        if (small) {
-            tile_coords(a.grid[1], a.tiles_x, t - nbig, n, tx, ty);
-            y0 = a.grid[1].y0 + ty * 4;
-        } else {
-            tile_coords(a.grid[0], a.tiles_x, t, n, tx, ty);
-            y0 = a.grid[0].y0 + ty * 8;
-        }
+        uint32_t words[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) words[k] = kw[offsetof(StageArgs, grid) / 4 + (small ? 16 : 0) + k];
+        TileGrid g;
+        __builtin_memcpy(&g, words, sizeof(g));
+        tile_coords(g, a.tiles_x, small ? t - nbig : t, n, tx, ty);
+        y0 = g.y0 + ty * (small ? 4 : 8);
         x0 = tx * kTW;
     };
 
     if constexpr (FINAL) {  // (read after the tile's steps, many barriers later)
         const float* wlin = a.wpack + (size_t)NSTEPS * kChunkFloats;
         for (int k = tid; k < 9 * NTN * 128; k += 256) s_wlin[k] = wlin[k];
+        if constexpr (IMG_U8) s_lut[tid] = __fdiv_rn((float)tid, 255.0f);
     }
     const int first = queue_first(blockIdx.x, nbig, nsmall);
     if (first < 0) return;
@@ -1407,7 +1419,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         if constexpr (FINAL) {
             // bilinear residual: the image tile goes into the buffer the last half has just left (buffer 1)
             float* s_x = (float*)(smem + HB);
-            linpx.store(s_x, tid, st);
+            linpx.store(s_x, s_lut, tid, st);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1536,7 +1548,8 @@ static hipError_t launch_stage_t(int stage, int factor, const StageArgs& a, int 
 template <int PREC>
 static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s) {
     constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kRingBytes + 16;
-    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 2 * 128 * sizeof(float);  // + bilinear weights (<= 2 N-tiles)
+    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 2 * 128 * sizeof(float) + 256 * sizeof(float);  // + bilinear weights (<= 2 N-tiles), byte / 255 table
+    static_assert(lds3 <= 80 * 1024, "two workgroups per CU");
     switch (stage) {
         case 1: return launch_with_lds(conv_stage_pipe_kernel<1, 5, false, false, false, PREC>, a, grid, lds5, s);
         case 2: return launch_with_lds(conv_stage_pipe_kernel<2, 5, false, false, false, PREC>, a, grid, lds5, s);

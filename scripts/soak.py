@@ -26,6 +26,7 @@ def soak(budget, seed=None):
     for prec in ("f32", "split_f16"):
         a, b, c = r.Engine(params, precision=prec), r.Engine(params, precision=prec), r.Engine(params, precision=prec)
         b.set_experiment("pipe", "none")
+        b.set_experiment("fork", "0")    # ... undivided: the reference every other path is compared with
         c.set_experiment("pipe", "all")  # the persistent pipe form on every launch, with a tile plan drawn per call
         group = [r.Engine(params, precision=prec) for _ in range(5)]   # one image sharded over k contexts (local transport)
         group_k = 0
@@ -43,10 +44,11 @@ def soak(budget, seed=None):
             ga, gb = a.upscale_rgba8_dev(px), b.upscale_rgba8_dev(px)
             if not torch.equal(ga, gb):
                 bad.append((prec, "shape", n, h, w))
-            plan = (str(rng.choice(["", "", "4", "8"])), str(rng.choice(["", "0", "0.01", "0.4", "2", "7"])), str(rng.choice(["", "0", "3", "16"])))
-            c.set_experiment("th", plan[0]); c.set_experiment("tail", plan[1]); c.set_experiment("bw", plan[2])
+            plan = (str(rng.choice(["", "", "4", "8"])), str(rng.choice(["", "0", "0.01", "0.4", "2", "7"])), str(rng.choice(["", "0", "3", "16"])),
+                    str(rng.choice(["", "0", "1", "1", "17", "40"])))  # ... and the device call undivided / as two bands on two streams, at any cut
+            c.set_experiment("th", plan[0]); c.set_experiment("tail", plan[1]); c.set_experiment("bw", plan[2]); c.set_experiment("fork", plan[3])
             if not torch.equal(c.upscale_rgba8_dev(px), gb):
-                bad.append((prec, "pipe form, plan th/tail/bw", plan, n, h, w))
+                bad.append((prec, "pipe form, plan th/tail/bw/fork", plan, n, h, w))
             stats["shapes"] += 1
             if n == 1 and h > 30:  # a band of it with halos must equal the same rows of the whole
                 y0 = int(rng.integers(7, h - 15))
