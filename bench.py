@@ -529,21 +529,24 @@ def main():
         try:
             secs = float(os.environ.get("SRHIP_BENCH_SUSTAINED_S", "3.0"))
             sclk0 = read_sclk_mhz(local)
-            evs, t0 = [], time.perf_counter()
+            evs, t_start, wall = [], time.perf_counter(), 0.0
             sclk_mid = []
-            while time.perf_counter() - t0 < secs:
-                for _ in range(50):
+            while time.perf_counter() - t_start < secs:
+                # bursts of 100 steps, each burst fenced and timed on its own: reading the clock between bursts (a few file reads, ~1 ms)
+                # is not part of any burst's wall time
+                t0 = time.perf_counter()
+                for _ in range(100):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     main_band.step()
                     e1.record()
                     evs.append((e0, e1))
                 torch.cuda.synchronize()
+                wall += time.perf_counter() - t0
                 sclk_mid.append(read_sclk_mhz(local))
-            wall = time.perf_counter() - t0
             per = np.array([a.elapsed_time(b) for a, b in evs])
             sclk_mid = [v for v in sclk_mid if v]
-            result["sustained"] = {"ms_per_step": round(wall / len(per) * 1e3, 4), "steps": len(per), "wall_s": round(wall, 3),
+            result["sustained"] = {"ms_per_step": round(wall / len(per) * 1e3, 4), "steps": len(per), "wall_s": round(time.perf_counter() - t_start, 3), "busy_wall_s": round(wall, 3),
                                    "event_ms_median": round(float(np.median(per)), 4), "event_ms_mean": round(float(per.mean()), 4),
                                    "event_ms_p95": round(float(np.percentile(per, 95)), 4), "event_ms_min": round(float(per.min()), 4),
                                    "vs_headline": round(wall / len(per) * 1e3 / ms_per_step, 4),
@@ -551,13 +554,17 @@ def main():
                                    "sclk_mhz_under_load_min": (min(sclk_mid) if sclk_mid else None),
                                    "whole_call_frac": round(H * W * FLOP_PER_PX / (wall / len(per)) / 1e12 /
                                                             (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS), 4),
-                                   "note": "ms_per_step = wall / steps of a back-to-back loop (what `value` measures, but for >= 3 s); event_* = per-step "
-                                           "durations from an event pair around each call on the launch stream; sclk from sysfs pp_dpm_sclk"}
+                                   "note": "ms_per_step = wall / steps over fenced bursts of 100 back-to-back steps (what `value` measures, for >= 3 s instead of 80 ms); "
+                                           "event_* = per-step durations from an event pair around each call on the launch stream; sclk from sysfs "
+                                           "pp_dpm_sclk, read between bursts"}
             del evs
         except Exception as ex:  # noqa: BLE001
             result["sustained"] = {"error": str(ex)[:200]}
         # ---- what the fork inside the device call is worth on this box: the same 20 steps with it off, then on again
+        # (not when the caller pins the mode with SRHIP_FORK, as scripts/profile.sh does to keep every profiled launch a whole frame)
         try:
+            if "SRHIP_FORK" in os.environ:
+                raise RuntimeError("skipped: SRHIP_FORK is set")
             ab = {}
             for key, val in (("undivided_ms", "0"), ("forked_ms", "1"), ("automatic_ms", "")):
                 eng.set_experiment("fork", val)
