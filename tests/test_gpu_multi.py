@@ -247,9 +247,18 @@ def test_sharded_image_through_the_library_on_one_device(params, n, prec):
             r.upscale_sharded_all(engs, [torch.from_numpy(px[:6]).cuda()] + bands[1:])
         with pytest.raises(r.SrError):   # a lone rank of a local communicator cannot see its neighbours
             engs[0].upscale_sharded_dev(bands[0])
+        # every sharded call is timed by two event pairs on the band's stream, profiling or not: the context's whole step
+        # (sr_last_timing total_ms, no per-stage times) and the halo exchange inside it (sr_last_comm_ms)
+        r.upscale_sharded_all(engs, bands)
+        for e in engs:
+            t, c = e.last_timing(), e.last_comm_ms()
+            assert t["total_ms"] > 0 and sum(t["stage_ms"]) == 0 and 0 < c < t["total_ms"]
         engs[0].set_profiling(True)
         r.upscale_sharded_all(engs, bands)
-        assert engs[0].last_comm_ms() > 0
+        assert engs[0].last_comm_ms() > 0 and sum(engs[0].last_timing()["stage_ms"]) > 0  # ... with it on, the conv stack's own per-stage events
+        engs[0].set_profiling(False)
+        engs[0].upscale_rgba8(px)  # an ordinary call afterwards reports its own timing again
+        assert engs[0].last_timing()["h2d_ms"] > 0
     finally:
         for e in engs:
             e.close()
