@@ -839,10 +839,13 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
                         const f32x2 s = (f32x2{av[r], av[r + 1]} + f32x2{bias[nt], bias[nt]}) * f32x2{255.0f, 255.0f} + f32x2{0.5f, 0.5f};
                         const uint32_t q0 = __builtin_amdgcn_cvt_pk_u8_f32(floorf(s.x), (uint32_t)c, old);
                         const uint32_t q1 = __builtin_amdgcn_cvt_pk_u8_f32(floorf(s.y), (uint32_t)c, old);
-                        p0 = q0 | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q0, 0x101, 0xF, 0xF, true)    // row_shl:1 (G)
-                                | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q0, 0x102, 0xF, 0xF, true);   // row_shl:2 (B)
-                        p1 = q1 | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q1, 0x101, 0xF, 0xF, true)
-                                | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q1, 0x102, 0xF, 0xF, true);
+                        // (two 2-input ORs, kept apart by an empty asm: each then folds its DPP move into a v_or_b32_dpp -- two instructions
+                        // per value; written as one expression the compiler forms a v_or3_b32, which cannot carry DPP: two moves + the OR)
+                        p0 = q0 | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q0, 0x101, 0xF, 0xF, true);    // row_shl:1 (G)
+                        p1 = q1 | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q1, 0x101, 0xF, 0xF, true);
+                        asm volatile("" : "+v"(p0), "+v"(p1));
+                        p0 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q0, 0x102, 0xF, 0xF, true);        // row_shl:2 (B)
+                        p1 |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q1, 0x102, 0xF, 0xF, true);
                     };
                     if (full_x) {
                         uint32_t px[16];
