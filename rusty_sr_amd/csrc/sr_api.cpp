@@ -691,20 +691,20 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
     return SR_OK;
 }
 
-// A lone frame's five launches each end with a drain (the workgroups of a persistent launch finish up to a tile time
-// apart, the chip idles while the last ones work) and begin with a fill (launch boundary, first gathers): ~0.1 ms of a
-// 4.14 ms 1080p call that a batch of four, or a second frame in flight, does not pay (bench.py batch_of_4,
-// two_frames_in_flight).  The device entry points therefore do for a lone image what those do: the rows are cut into TWO
-// bands -- each with the SR_HALO rows of the other it needs, bit-identical to the undivided pass like every band -- and the
-// second band runs on the context's second stream and workspace, forked from the caller's stream by an event and joined
-// back by another, the launches of the two issued alternately.  A stage launch of one band then drains while the other
-// band's launch of that stage fills the freed slots; the call stays asynchronous on the caller's stream.  Costs: 14
-// recomputed rows (0.3 % of the FLOPs at 1080p) and a second set of feature maps.
+// One image as TWO row bands on two streams.  Each band carries the SR_HALO rows of the other it needs and is
+// bit-identical to the undivided pass like every band; the second runs on the context's own second stream and workspace, forked
+// from the caller's stream by an event and joined back by another, the launches of the two issued alternately -- the call stays
+// asynchronous and ordered on the caller's stream.  What it buys, measured: the dispatcher runs the two bands' stage launches side
+// by side (a workgroup of either per CU), so their ramps -- every workgroup's first gather from a cold L2, the partly filled last
+// round of tiles -- overlap the other band's matrix work; against that stand ten launches instead of five, 14 recomputed rows
+// and ~17 us of join / fork between consecutive calls.  Net -0.5 ... -1.4 % for exact-f32 frames of 6-17 rounds of tiles, a loss
+// elsewhere: hence the rule below.  Costs a second set of feature maps.
 int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
                       void* d_out, bool out_u8, hipStream_t s) {
     if (!c || !d_img || !d_out) return SR_E_INVALID;
     const int own = H - halo_top - halo_bot;
     bool fork = c->graph == SR_GRAPH_SR_NET && n == 1 && !c->profiling && c->env_fork != 0 && W > 0 && own >= 4 * SR_HALO &&
+                (!img_u8 || img_ch == 3 || img_ch == 4) &&   // (anything sr_run_stack would refuse is left for it to refuse)
                 halo_top >= 0 && halo_bot >= 0 && (halo_top == 0 || halo_top >= SR_HALO) && (halo_bot == 0 || halo_bot >= SR_HALO);
     if (fork && c->env_fork < 0) {
         // automatic: where the launches have enough rounds of tiles for two bands to fill the chip each (measured)
