@@ -553,7 +553,12 @@ int StackJob::prepare() {
         const int forced = c->env_th[st];
         const bool small_launch = tiles8 < 2L * resident;
         const bool split = c->precision == SR_PRECISION_SPLIT_F16;
-        l.pipe = st > 0 && c->env_pipe != 0 && (c->env_pipe == 2 || !small_launch || split);
+        // (round 4: with the scalar overheads of the pipe form gone it also wins where every workgroup has exactly ONE 4-row tile and the
+        // node has several sources -- their tiles arrive under the previous source's taps instead of between them: 256x256 stages 2 / 3
+        // 40.5 / 49.0 -> 39.1 / 47.2 us; with more than one round of small tiles the first form still leads, 384x384 0.356 against 0.382 ms:
+        // profiles/r4_ab_small_pipe.txt)
+        const bool one_small_round = small_launch && (long)n * tiles_x * ((rows + 3) / 4) <= resident;
+        l.pipe = st > 0 && c->env_pipe != 0 && (c->env_pipe == 2 || !small_launch || split || (st >= 2 && one_small_round));
         l.ty8 = (rows + 7) / 8; l.ty4 = 0;
         if (forced == 4 || (!forced && small_launch && (!split || tiles8 < cus))) {
             l.ty8 = 0; l.ty4 = (rows + 3) / 4;
