@@ -120,11 +120,11 @@ def pmc_traffic(stage, H, W, precision="f32"):
 
 
 def n1_reference(ms_c, world, precision, io):
-    """config_C at N > 1: speed-up over the committed one-GPU time of the same 3840x2160 image (profiles/r3_bench.json, else
-    the round-2 record) -- measured on another box of the same kind, so good to the box-to-box spread (~1.5 %)."""
+    """config_C at N > 1: speed-up over the committed one-GPU time of the same 3840x2160 image (profiles/r4_bench.json, else
+    an earlier round's record) -- measured on another box of the same kind, so good to the box-to-box spread (~1.5 %)."""
     if world == 1:
         return {}
-    for name in ("r3_bench.json", "r2_bench.json"):
+    for name in ("r4_bench.json", "r3_bench.json", "r2_bench.json"):
         d = _profile_json(name)
         ref = d and d.get("config_C", {})
         same = d and d.get("config", {}).get("precision") == precision and d.get("config", {}).get("io") == io
