@@ -233,3 +233,42 @@ def test_encoder_round_trip_under_sanitizers(harness, tmp_path):
     for w, h in ((1, 1), (37, 21), (513, 300), (4096, 33), (1600, 1300)):
         r = subprocess.run([harness, "--roundtrip", str(w), str(h), str(tmp_path / "rt.png")], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and r.stdout.startswith("ok "), (w, h, r.stdout, r.stderr[-2000:])
+
+
+def test_size_limits_sit_where_the_readme_says(harness, tmp_path):
+    """The decoders' refusals are deliberate bounds (README.md, "Limits of the CLI's decoders"), not accidents: files just inside them decode,
+    files just outside are refused with a clean error.  GIF: a logical screen above 16 Mi pixels only if it is at most 4x its first frame;
+    JPEG: a frame that claims more pixels than its bytes could possibly hold (and anything above 2^27 pixels) before any buffer of that
+    size exists."""
+    from PIL import Image
+    gif_hdr = lambda sw, sh: b"GIF89a" + struct.pack("<HH", sw, sh) + b"\x80\x00\x00" + bytes(6)
+
+    def gif_frame(w, h):  # one frame of colour 0: LZW with 2-bit codes, a clear code then runs of the growing dictionary
+        b = io.BytesIO()
+        Image.new("P", (w, h), 0).save(b, "GIF")
+        data = b.getvalue()
+        return data[data.index(b"\x2c"):]  # from the image descriptor on (Pillow writes no local colour table for mode P + global palette)
+
+    small = gif_frame(8, 8)
+    cases = {
+        "screen_16Mi_small_frame.gif": (gif_hdr(4096, 4096) + small, "ok 4096x4096"),          # exactly 16 Mi pixels: allowed whatever the frame
+        "screen_over_small_frame.gif": (gif_hdr(4100, 4100) + small, "error: "),                 # above it with an 8x8 frame: refused
+    }
+    big = Image.new("P", (2100, 2100), 0)
+    b = io.BytesIO(); big.save(b, "GIF")
+    data = b.getvalue()
+    cases["screen_over_quarter_frame.gif"] = (gif_hdr(4100, 4100) + data[data.index(b"\x2c"):], "ok 4100x4100")   # 16.8 M <= 4 x 4.41 M: allowed
+    # JPEG: an 8x8 file re-labelled as 8192 x 8192 (64 Mi pixels from 600 bytes: refused), and a genuine, flat 4096 x 4096 one (16 Mi pixels: decodes)
+    b = io.BytesIO(); Image.new("RGB", (8, 8), (10, 200, 90)).save(b, "JPEG", quality=50)
+    j = bytearray(b.getvalue())
+    k = j.index(b"\xff\xc0")
+    j[k + 5:k + 9] = struct.pack(">HH", 8192, 8192)
+    cases["claims_64Mi_from_600_bytes.jpg"] = (bytes(j), "error: ")
+    b = io.BytesIO(); Image.new("RGB", (4096, 4096), (10, 200, 90)).save(b, "JPEG", quality=50)
+    cases["flat_16Mi.jpg"] = (b.getvalue(), "ok 4096x4096")
+    paths = []
+    for name, (data, _) in cases.items():
+        p = tmp_path / name; p.write_bytes(data); paths.append(p)
+    lines = dict(zip(cases, _run(harness, paths, timeout=600)))
+    for name, (_, want) in cases.items():
+        assert lines[name].startswith(want), (name, lines[name])
