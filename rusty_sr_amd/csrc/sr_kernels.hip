@@ -261,7 +261,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     __syncthreads();  // the previous tile's reads of s_x are done
     // (Round 4 tried a cheaper path for interior tiles -- per-thread byte offsets computed once per workgroup, one unaligned dword
     // load per pixel, no bounds tests: 0.114 ms against 0.108 for this loop, and 0.127 with byte loads: profiles/r4_ab_variants_f32.txt.
-    // conv0's time is not in its staging arithmetic.)
+    // A second attempt kept the kernel at its 64 VGPRs = 8 waves per SIMD (the first had silently dropped to 7: 66-68 VGPRs) with the
+    // offsets parked in LDS: 0.1070 against 0.1073 ms (profiles/r4_ab_conv0_second_attempt.txt).  conv0's time is not in its staging
+    // arithmetic.)
     for (int p = tid; p < NPIX; p += kThreads) {
         const int py = p / TWH, px = p - py * TWH;
         const int gy = y0 - 2 + py, gx = x0 - 2 + px;
