@@ -511,6 +511,7 @@ struct StackJob {
     void* d_out = nullptr;
     bool img_u8 = false, out_u8 = false;
     int img_ch = 3, n = 1, H = 0, W = 0, top = 0, bot = 0, tiles_x = 0;
+    bool forked = false;  // one of the two bands of sr_run_stack_auto: no 4-row tail (see prepare)
     hipStream_t s = nullptr;
     struct Launch { int y0, y1, ty8, ty4, th, grid; bool pipe; } L[5];
     float* feat[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -546,7 +547,7 @@ int StackJob::prepare() {
         //    800x600 -4.7 %, 1000x600 -4.2 %, 1280x720 -2.4 %, 1920x1200 -1.4 %, the 8- / 4- / 2-way band of 3840x2160 -2.1 /
         //    -0.3 / -0.4 %, 2560x1440 -0.4 %, 3840x2160 0; but 512x512 (2.0 rounds) +5...9 % and 640x480 (2.3) +2 %: the 4-row
         //    tile body is code the launch would otherwise never touch (~30 us of cold instruction fetch per call), so no tail below
-        //    3 rounds, and none above 14 rounds when the last round is more than 70 % full anyway (1920x1080, 15.8: 0).  The
+        //    3 rounds (round 3 also excluded launches above 14 rounds with a last round more than 70 % full -- 1920x1080, 15.8: 0 then; see below).  The
         //    split-half mode pays 17 % per 4-row tile (its B operands are re-read per tile row) and keeps 8-row tiles.
         //  conv0 and the first form run one class.
         const long tiles8 = (long)n * tiles_x * ((rows + 7) / 8);
@@ -565,7 +566,11 @@ int StackJob::prepare() {
         } else if (!forced && l.pipe && !small_launch) {
             const double rounds = (double)tiles8 / resident;
             float tail = c->env_tail;
-            if (tail < 0.0f) tail = (!split && rounds >= 3.0 && !(rounds > 14.0 && std::ceil(rounds) - rounds <= 0.3)) ? 1.0f : 0.0f;
+            // (round 4, after the matrix stream lost its scalar overheads and 4-row tiles became relatively cheaper -- interleaved A/B,
+            // profiles/r4_fork_tail.jsonl: the tail now also pays where round 3 excluded it, above 14 rounds with a nearly full last round
+            // (1920x1080 undivided: 4.066 -> 4.052 ms); but NOT in the two bands of a forked call, whose launches run side by side and
+            // end staggered anyway: 1920x1080 4.048 -> 4.018, 1600x900 2.853 -> 2.825, 1280x720 1.841 -> 1.834 ms without it)
+            if (tail < 0.0f) tail = (!split && rounds >= 3.0 && !forked) ? 1.0f : 0.0f;
             if (tail > 0.0f) {
                 const long per_row = (long)n * tiles_x;
                 const int want = (int)((tail * resident + per_row - 1) / per_row);  // tile rows of small tiles
@@ -754,6 +759,7 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
     const size_t in_px = img_u8 ? (size_t)img_ch : 3 * sizeof(float), out_px = out_u8 ? 4 : 3 * sizeof(float);
     const int f = c->factor;
     StackJob a, b;
+    a.forked = b.forked = true;
     a.c = b.c = c; a.img_u8 = b.img_u8 = img_u8; a.out_u8 = b.out_u8 = out_u8; a.img_ch = b.img_ch = img_ch; a.W = b.W = W;
     a.ws = &c->ws[0]; a.s = s;
     a.d_img = d_img; a.d_out = d_out; a.H = cut + SR_HALO; a.top = halo_top; a.bot = cut;

@@ -2,7 +2,7 @@
 """A/B of the forked device call (sr_run_stack_auto: one image as two row bands on two streams) against the undivided
 call, in ONE process, interleaved rounds, bit-for-bit check of every variant.
     python scripts/fork_ab.py [--prec f32] [--sizes 1080x1920,2160x3840] [--variants 0,1,1:0.45,1:0.55] [--rounds 5] [--steps 20]
-A variant is the value of sr_set_experiment("fork") with an optional ":share" (forkshare).  One JSON line per (size, variant)."""
+A variant is the value of sr_set_experiment("fork") with an optional ":share" (forkshare) and ":tail" (4-row tail tiles: "0" none, "1" ...).  One JSON line per (size, variant)."""
 import argparse
 import json
 import os
@@ -41,10 +41,11 @@ for size in a.sizes.split(","):
     variants = a.variants.split(",")
     outs, times = {}, {v: [] for v in variants}
 
-    def select(v):
-        fork, _, share = v.partition(":")
+    def select(v):  # "fork[:share[:tail]]"
+        fork, share, tail = (v.split(":") + ["", ""])[:3]
         eng.set_experiment("fork", fork)
         eng.set_experiment("forkshare", share)
+        eng.set_experiment("tail", tail)
 
     for v in variants:
         select(v)
@@ -73,3 +74,4 @@ for size in a.sizes.split(","):
     torch.cuda.empty_cache()
 eng.set_experiment("fork", "")
 eng.set_experiment("forkshare", "")
+eng.set_experiment("tail", "")
