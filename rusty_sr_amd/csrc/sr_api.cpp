@@ -396,7 +396,7 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
     } else if (!strcmp(key, "forkshare")) {  // ... the first band's share of the rows ("" : 0.5)
         c->fork_share = *v ? std::min(0.9, std::max(0.1, atof(v))) : 0.5;
     } else if (!strcmp(key, "forkmin")) {  // ... automatic rule: fork from this many rounds of tiles on
-        c->fork_min_rounds = *v ? atof(v) : 6.0;
+        c->fork_min_rounds = *v ? atof(v) : 3.5;
     } else if (!strcmp(key, "bw")) {   // tile-order column-block width in tiles; "" / negative: automatic, 0: plain row-major
         c->env_bw = *v ? atoi(v) : -1;
     } else {
@@ -720,11 +720,11 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
         // automatic: where the launches have enough rounds of tiles for two bands to fill the chip each (measured)
         const int cus = c->cus > 0 ? c->cus : 256;
         const double rounds = (double)((W + 31) / 32) * ((own + 7) / 8) / (2.0 * cus);
-        // measured (scripts/fork_ab.py, profiles/r4_fork_ab_*.jsonl): exact f32 1280x720 (7 rounds) -0.5 %, 1920x1080 (16) -0.1 ... -1 %;
-        // 960x540 (4 rounds) +3.5 %, 2560x1440 (28) +0.2 %, 3840x2160 (63: the launch boundaries are 0.6 % of the call) +0.3 %, the
-        // split-half mode (tiles of 14 us) +0.3 ... +2 %
-        // (a 276-row band of a 3840-wide image has 8 rounds too, but its 14 recomputed rows are 5 % of it: +1 %)
-        fork = c->precision == SR_PRECISION_F32 && rounds >= c->fork_min_rounds && rounds < c->fork_max_rounds && own >= 640;
+        // measured, interleaved in one process (scripts/fork_ab.py).  With the bands' launches free of 4-row tails (StackJob::prepare) the fork
+        // wins wherever a band still has a few rounds of tiles, exact f32 (profiles/r4_fork_ab_f32_final_rule.jsonl): 800x600 (3.7 rounds)
+        // -3.8 %, 1280x720 -1.6 %, 1920x1080 -0.8 %, 1920x1200 -0.9 %, 2560x1440 -0.4 %, 3840x2160 -0.1 %, a 276-row band of a 3840-wide
+        // image -0.4 %; 960x540 (4.0 rounds) ties.  The split-half mode (tiles of 14 us) loses 0.6-2.4 % (r4_fork_ab_split.jsonl).
+        fork = c->precision == SR_PRECISION_F32 && rounds >= c->fork_min_rounds && rounds < c->fork_max_rounds;
     }
     if (!fork) return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s);
     sr_device_guard restore_device;

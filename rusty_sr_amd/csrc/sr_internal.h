@@ -51,8 +51,8 @@ struct sr_ctx {
     float env_tail = -1.0f;           // 4-row tiles at the end of a launch, in resident workgroups (< 0: automatic = 1 where the tail rule applies, 0: none)
     int env_fork = -1;                // device entry points, one image: two row bands on two streams (sr_run_stack_auto); -1 automatic, 0 never,
                                       // 1 always, > 1: always, with this many rows in the first band
-    double fork_min_rounds = 6.0;     //   automatic: fork from this many rounds of 8-row tiles per resident workgroup on ...
-    double fork_max_rounds = 17.0;    //   ... and below this many (and from 640 rows on)
+    double fork_min_rounds = 3.5;     //   automatic: fork from this many rounds of 8-row tiles per resident workgroup on ...
+    double fork_max_rounds = 1e9;     //   ... and below this many (no upper bound by default)
     double fork_share = 0.5;          //   the first band's share of the rows
     hipEvent_t ev_fork[2] = {nullptr, nullptr};  // fork (caller's stream -> stream2) and join (stream2 -> caller's stream)
     int env_bands = 0;                // host pipeline: forced number of row bands (0: automatic)
