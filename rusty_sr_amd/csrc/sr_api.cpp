@@ -707,8 +707,9 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
 // asynchronous and ordered on the caller's stream.  What it buys, measured: the dispatcher runs the two bands' stage launches side
 // by side (a workgroup of either per CU), so their ramps -- every workgroup's first gather from a cold L2, the partly filled last
 // round of tiles -- overlap the other band's matrix work; against that stand ten launches instead of five, 14 recomputed rows
-// and ~17 us of join / fork between consecutive calls.  Net -0.5 ... -1.4 % for exact-f32 frames of 6-17 rounds of tiles, a loss
-// elsewhere: hence the rule below.  Costs a second set of feature maps.
+// and ~17 us of join / fork between consecutive calls.  Net, with the bands' launches free of 4-row tails: -0.8 ... -3.8 % for
+// exact-f32 images from 3.5 rounds of tiles on, -0.1 % at 3840x2160; a loss in the split-half mode: hence the rule below.  Costs a
+// second set of feature maps (each band's are half the size).
 int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
                       void* d_out, bool out_u8, hipStream_t s) {
     if (!c || !d_img || !d_out) return SR_E_INVALID;
