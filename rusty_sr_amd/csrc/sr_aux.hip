@@ -64,7 +64,9 @@ __device__ __forceinline__ uint32_t quant_lookup(const QEntry* tab, float l) {
 // (Round 4 also tried the opposite balance -- estimate 255 LinearToSrgb(l) + 0.5 with v_log_f32 / v_exp_f32 and ask the table only
 // within 1e-3 of an integer, bit-identical by construction: 43 us against 32 us for the table alone, for one, two or three of a
 // pixel's channels alike (profiles/r4_aux_quantiser_estimate_first.txt).  The look-ups' bank conflicts cost less than 14 more vector
-// instructions per sample.)
+// instructions per sample.  Likewise the table as two dword arrays (64 consecutive buckets over 64 banks instead of 32 over the 32
+// bank pairs of 8-byte entries): 39 us, profiles/r4_aux_quantiser_split_table.txt -- two LDS instructions per look-up cost more than
+// the conflicts they avoid.)
 
 // smallest float l in [0, 1] with quant_u8(linear_to_srgb(l)) >= k, for k = 1 .. 255 (thread k - 1): bisection over
 // the bit patterns (non-negative floats order like their bits), then a short downward scan in case the powf is not
