@@ -238,15 +238,17 @@ __global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
     }
 }
 
-// downsample_net: one thread per output pixel; a workgroup owns 64 x 4 output pixels = 192 x 12 input pixels, whose rows
+// downsample_net: a thread per output pixel (two for u8: tiles of 64 x 8); a workgroup owns 64 x 4 output pixels = 192 x 12 input pixels (f32), whose rows
 // are staged raw in LDS by coalesced dword loads (an input row segment starts at any byte: loaded from the 4-byte word
 // that holds its first byte on, the misalignment added back at the read).  No input sample is read twice (the 3x3
 // windows do not overlap), the 9 samples are summed in the reference's order (rows, then columns) and divided by 9.
-constexpr int kDsTW = 64, kDsTH = 4;
+constexpr int kDsTW = 64;
+constexpr int ds_tile_rows(bool) { return 4; }  // output rows per tile (8 for u8 was tried: -3 % at 5760x3240, +8 % at 1920x1080)
 template <bool IMG_U8, bool OUT_U8>
 __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
+    constexpr int kDsTH = ds_tile_rows(IMG_U8);
     constexpr int ROW_BYTES = 3 * kDsTW * (IMG_U8 ? 4 : 12) + 16;   // a staged row segment (u8: up to 4 channels), + misalignment slack
-    __shared__ __attribute__((aligned(16))) uint32_t s_raw[3 * kDsTH * ROW_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[3 * kDsTH * (ROW_BYTES / 4)];
     __shared__ float s_lut[IMG_U8 ? 256 : 1];
     __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQEntries : 1];
     const int tid = threadIdx.x;
@@ -259,6 +261,30 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
     const int tiles_x = (OW + kDsTW - 1) / kDsTW, tiles_y = (OH + kDsTH - 1) / kDsTH;
     const long ntiles = (long)a.n * tiles_x * tiles_y;
     const size_t px_bytes = IMG_U8 ? (size_t)a.img_ch : 12;
+    // The raw row segments of a tile travel global -> registers -> LDS; those of the NEXT tile are requested before this tile's
+    // arithmetic and land under it (every workgroup of the launch starts at the same moment: without this they all sit out the same
+    // load latency together, once per tile).  Thread t carries words t, t + 256, ... of each of the tile's (up to) 12 rows.
+    constexpr int ROW_WORDS = ROW_BYTES / 4, LOADS = (ROW_WORDS + 255) / 256;
+    uint32_t raw[3 * kDsTH][LOADS];
+    auto fetch = [&](long tile) {
+        const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
+        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+        const int ox0 = tx * kDsTW, oy0 = ty * kDsTH;
+        const int tw = min(kDsTW, OW - ox0), th = min(kDsTH, OH - oy0);
+        const int seg = 3 * tw * (int)px_bytes;
+#pragma unroll
+        for (int r = 0; r < 3 * kDsTH; ++r) {
+            if (r < 3 * th) {  // wave-uniform
+                const uintptr_t addr = (uintptr_t)a.img + (((size_t)n * a.H + 3 * oy0 + r) * a.W + 3 * ox0) * px_bytes;
+                const uint32_t* src = (const uint32_t*)(addr & ~(uintptr_t)3);
+                const int words = (int)((addr & 3) + seg + 3) / 4;
+#pragma unroll
+                for (int i = 0; i < LOADS; ++i)
+                    if (tid + 256 * i < words) raw[r][i] = src[tid + 256 * i];
+            }
+        }
+    };
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
@@ -266,14 +292,21 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
         const int tw = min(kDsTW, OW - ox0), th = min(kDsTH, OH - oy0);
         const int seg = 3 * tw * (int)px_bytes;  // bytes of one input row segment
         __syncthreads();
-        for (int r = 0; r < 3 * th; ++r) {
-            const uintptr_t addr = (uintptr_t)a.img + (((size_t)n * a.H + 3 * oy0 + r) * a.W + 3 * ox0) * px_bytes;
-            const uint32_t* src = (const uint32_t*)(addr & ~(uintptr_t)3);
-            const int words = (int)((addr & 3) + seg + 3) / 4;
-            for (int k = tid; k < words; k += 256) s_raw[r * (ROW_BYTES / 4) + k] = src[k];
+#pragma unroll
+        for (int r = 0; r < 3 * kDsTH; ++r) {
+            if (r < 3 * th) {
+                const uintptr_t addr = (uintptr_t)a.img + (((size_t)n * a.H + 3 * oy0 + r) * a.W + 3 * ox0) * px_bytes;
+                const int words = (int)((addr & 3) + seg + 3) / 4;
+#pragma unroll
+                for (int i = 0; i < LOADS; ++i)
+                    if (tid + 256 * i < words) s_raw[r * ROW_WORDS + tid + 256 * i] = raw[r][i];
+            }
         }
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         __syncthreads();
-        const int lx = tid & (kDsTW - 1), ly = tid / kDsTW;
+        const int lx = tid & (kDsTW - 1);
+#pragma unroll
+        for (int ly = tid / kDsTW; ly < kDsTH; ly += 256 / kDsTW)
         if (lx < tw && ly < th) {
             float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -378,9 +411,10 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
         }
     } else {
         const int OH = a.H / 3, OW = a.W / 3;
-        const long tiles = (long)a.n * ((OW + kDsTW - 1) / kDsTW) * ((OH + kDsTH - 1) / kDsTH);
+        const int th = ds_tile_rows(img_u8);
+        const long tiles = (long)a.n * ((OW + kDsTW - 1) / kDsTW) * ((OH + th - 1) / th);
         if (tiles == 0) return hipSuccess;
-        const long per = (tiles + 8L * cus - 1) / (8L * cus);
+        const long per = (tiles + 8L * cus - 1) / (8L * cus);  // (8 workgroups per CU: 3 / 4 / 6 measured 10-60 % slower at 5760x3240)
         const int grid = (int)((tiles + per - 1) / per);
         if (img_u8) hipLaunchKernelGGL((downsample_tile_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((downsample_tile_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
