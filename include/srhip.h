@@ -222,18 +222,8 @@ int sr_upscale_sharded_rgba8_all(sr_ctx* const* ctxs, int n, const uint8_t* cons
 enum sr_precision { SR_PRECISION_F32 = 0, SR_PRECISION_SPLIT_F16 = 1 };
 int sr_set_precision(sr_ctx* ctx, int mode);
 
-/* Experiment switches -- none changes a result bit, they exist for A/B timing and for the tests that prove
- * exactly that.  key "th": tile height, value "" (automatic: 8-row tiles ended by 4-row tiles, or 4-row tiles only for
- * small launches), "4" / "8" (all stages) or five digits (one per stage); "tail": how many 4-row tiles end a launch of
- * 8-row tiles, in units of the resident workgroups ("" automatic: 1 where it pays, "0" none); "pipe": "none" forces the first
- * form of the stage kernels (one tile class per launch), "all" the pipe form also for small launches ("" automatic); "bw": width in tiles of the column blocks the tile queue walks
- * ("" automatic, "0" plain row-major); "bands": the host pipeline cuts one large image into that many equal row bands
- * ("" / "0": its own plan); "rows": the bands' heights themselves, "r0,r1,..." top to bottom, computed in order on one stream, or with a
- * leading '=' on alternating streams (used when they add up to the rows of the call); "geo": "0" keeps equal bands where the plan would
- * shrink them geometrically.
- * Defaults come from SRHIP_TH / SRHIP_TAIL / SRHIP_PIPE / SRHIP_BW / SRHIP_BANDS / SRHIP_ROWS / SRHIP_GEO, read once in sr_create.
- * Unknown key: SR_E_INVALID. */
-int sr_set_experiment(sr_ctx* ctx, const char* key, const char* value);
+/* (A/B tuning switches that change no result bit, and their environment defaults, are NOT part of this interface:
+ * include/srhip_experimental.h.) */
 
 /* Test hook: copy the post-activation feature maps of the most recent call
  * (image 0) to host: which = 0..3 -> f, l1, l2, l3 (h*w*32 f32 each).  The

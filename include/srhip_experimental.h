@@ -1,0 +1,34 @@
+/*
+ * srhip_experimental.h -- tuning switches of libsrhip.so that are NOT part of the drop-in C ABI (include/srhip.h).
+ *
+ * Nothing here has a counterpart in the reference (millardjn/rusty_sr has no tuning surface: src/main.rs:33-127 is its
+ * whole CLI) and nothing here changes a result bit.  The switches exist for interleaved A/B timing (scripts/ab_libs.py,
+ * scripts/fork_ab.py, scripts/band_profile.py) and for the tests that prove bit-identity across kernel forms and tile
+ * plans (tests/test_gpu_parity.py).  Keys, values and defaults may change between builds; a host that binds
+ * include/srhip.h alone (rust_host/src/srhip.rs, the C++ CLI) never needs this file.
+ */
+#ifndef SRHIP_EXPERIMENTAL_H
+#define SRHIP_EXPERIMENTAL_H
+
+#include "srhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sr_set_experiment(ctx, key, value).  key "th": tile height, value "" (automatic: 8-row tiles ended by 4-row tiles, or 4-row tiles only for
+ * small launches), "4" / "8" (all stages) or five digits (one per stage); "tail": how many 4-row tiles end a launch of
+ * 8-row tiles, in units of the resident workgroups ("" automatic: 1 where it pays, "0" none); "pipe": "none" forces the first
+ * form of the stage kernels (one tile class per launch), "all" the pipe form also for small launches ("" automatic); "bw": width in tiles of the column blocks the tile queue walks
+ * ("" automatic, "0" plain row-major); "bands": the host pipeline cuts one large image into that many equal row bands
+ * ("" / "0": its own plan); "rows": the bands' heights themselves, "r0,r1,..." top to bottom, computed in order on one stream, or with a
+ * leading '=' on alternating streams (used when they add up to the rows of the call); "geo": "0" keeps equal bands where the plan would
+ * shrink them geometrically.
+ * Defaults come from SRHIP_TH / SRHIP_TAIL / SRHIP_PIPE / SRHIP_BW / SRHIP_BANDS / SRHIP_ROWS / SRHIP_GEO, read once in sr_create.
+ * Unknown key: SR_E_INVALID. */
+int sr_set_experiment(sr_ctx* ctx, const char* key, const char* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRHIP_EXPERIMENTAL_H */

@@ -72,7 +72,6 @@ extern "C" {
                                       w: c_int, d_outs: *const *mut f32) -> c_int;
     pub fn sr_upscale_sharded_rgba8_all(ctxs: *const *mut SrCtx, n: c_int, d_bands: *const *const u8, in_channels: c_int,
                                         h_bands: *const c_int, w: c_int, d_outs: *const *mut u8) -> c_int;
-    pub fn sr_set_experiment(ctx: *mut SrCtx, key: *const c_char, value: *const c_char) -> c_int;
     pub fn sr_set_pipeline(ctx: *mut SrCtx, enabled: c_int) -> c_int;
     pub fn sr_host_alloc(out: *mut *mut c_void, bytes: usize) -> c_int;  // page-locked host memory
     pub fn sr_host_free(p: *mut c_void);

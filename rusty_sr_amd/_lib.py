@@ -54,7 +54,6 @@ SYMBOLS = {
     "sr_upscale_sharded_rgba8_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sr_upscale_sharded_f32_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_i), _i, C.POINTER(_vp)]),
     "sr_upscale_sharded_rgba8_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), _i, C.POINTER(_i), _i, C.POINTER(_vp)]),
-    "sr_set_experiment": (_i, [_vp, C.c_char_p, C.c_char_p]),
     "sr_set_pipeline": (_i, [_vp, _i]),
     "sr_host_alloc": (_i, [C.POINTER(_vp), _sz]),
     "sr_host_free": (None, [_vp]),
@@ -63,6 +62,11 @@ SYMBOLS = {
     "sr_device_info": (_i, [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_i)]),
     "sr_last_hip_error": (_i, [_vp]),
     "sr_strerror": (C.c_char_p, [_i]),
+}
+
+# include/srhip_experimental.h: A/B tuning switches (no result bit depends on them), outside the drop-in ABI
+EXPERIMENTAL = {
+    "sr_set_experiment": (_i, [_vp, C.c_char_p, C.c_char_p]),
 }
 
 _lib = None
@@ -92,7 +96,7 @@ def lib():
         except ImportError:
             pass
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(EXPERIMENTAL.items()):
             f = getattr(L, name)  # AttributeError if the ABI is incomplete
             f.restype, f.argtypes = res, args
         _lib = L

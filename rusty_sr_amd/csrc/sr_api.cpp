@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/srhip.h"
+#include "../../include/srhip_experimental.h"
 #include "sr_kernels.h"
 #include "sr_internal.h"
 

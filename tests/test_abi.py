@@ -11,20 +11,36 @@ import oracle
 from conftest import ROOT, gpu_available
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "srhip.h")).read()
+def _header_functions(header="srhip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(sr_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
+    """Every function any header under include/ declares is exported; the drop-in header (srhip.h) and the tuning header
+    (srhip_experimental.h) are bound by separate tables, so that a switch cannot drift into the stable ABI unnoticed."""
     from rusty_sr_amd import _lib
     L = _lib.lib()
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["srhip.h", "srhip_experimental.h"]
     declared = _header_functions()
     assert len(declared) >= 16
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/srhip.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "python binding table out of sync with the header"
+    experimental = _header_functions("srhip_experimental.h")
+    assert experimental == sorted(_lib.EXPERIMENTAL) == ["sr_set_experiment"]
+    for name in experimental:
+        assert hasattr(L, name), f"{name} declared in include/srhip_experimental.h but not exported"
+    assert not set(experimental) & set(declared)
+
+
+def test_drop_in_header_has_no_tuning_surface():
+    """include/srhip.h is what a reference maintainer binds: no experiment switch, no SRHIP_* environment knob."""
+    src = open(os.path.join(ROOT, "include", "srhip.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    assert "sr_set_experiment" not in code and "SRHIP_" not in code
+    assert "SRHIP_" not in src.replace("SRHIP_H", "")
 
 
 def test_header_constants_match_binding():
@@ -135,8 +151,8 @@ def test_header_is_plain_c(tmp_path):
     """include/srhip.h must bind from C (and therefore from Rust bindgen / cgo / ctypes):
     compile a C99 translation unit that takes the address of every declared function."""
     import subprocess
-    names = _header_functions()
-    src = "#include \"srhip.h\"\ntypedef void (*fn)(void);\nfn table[] = {" + ", ".join(f"(fn){n}" for n in names) + "};\nint main(void) { return sizeof(table) ? 0 : 1; }\n"
+    names = _header_functions() + _header_functions("srhip_experimental.h")
+    src = "#include \"srhip.h\"\n#include \"srhip_experimental.h\"\ntypedef void (*fn)(void);\nfn table[] = {" + ", ".join(f"(fn){n}" for n in names) + "};\nint main(void) { return sizeof(table) ? 0 : 1; }\n"
     c = tmp_path / "abi.c"
     c.write_text(src)
     lib_dir = os.path.join(ROOT, "rusty_sr_amd")
