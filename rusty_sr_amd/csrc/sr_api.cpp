@@ -363,6 +363,12 @@ int sr_num_params(int graph) { return graph == SR_GRAPH_SR_NET ? SR_NUM_PARAMS :
 
 int sr_set_precision(sr_ctx* c, int mode) {
     if (!c || (mode != SR_PRECISION_F32 && mode != SR_PRECISION_SPLIT_F16)) return SR_E_INVALID;
+    if (mode != c->precision) {
+        // the two modes lay their feature maps out differently (sr_kernels.h sr_split_maps_planar): what was interior for one is border
+        // for the other, so the workspaces' borders are cleared again before the next pass (ensure_features)
+        for (auto& w : c->ws) w.geo_n = 0;
+        c->last_h = c->last_w = 0;
+    }
     c->precision = mode;
     return SR_OK;
 }
@@ -471,6 +477,7 @@ int ensure_features(sr_ctx* c, sr_ctx::Workspace& w, int n, int H, int W, int ti
         ClearArgs ca{};
         for (int k = 0; k < 4; ++k) ca.map[k] = w.d_feat[k];
         ca.n = n; ca.H = H; ca.W = W; ca.pitch = pitch; ca.img_stride = img_stride; ca.total_px = (long)npx;
+        ca.planar = c->precision == SR_PRECISION_SPLIT_F16 && sr_split_maps_planar();
         HIPCHK(c, sr_launch_clear_borders(ca, s));
         w.geo_n = n; w.geo_h = H; w.geo_w = W;
     }
@@ -528,7 +535,9 @@ int StackJob::prepare() {
     const int cus = c->cus > 0 ? c->cus : 256;
     const int resident = 2 * cus;  // workgroups of a stage kernel that fit the chip at once (2 per CU: 76-78 KB of LDS each)
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
-    for (int k = 0; k < 4; ++k) feat[k] = ws->d_feat[k] + ((size_t)kFeatPad * ws->pitch + kFeatPad) * 32;
+    // (row-planar maps of the split-half mode: pixel (0,0) of channel group 0 -- kFeatPad rows down, kFeatPad 16-byte cells in)
+    const bool planar = c->precision == SR_PRECISION_SPLIT_F16 && sr_split_maps_planar();
+    for (int k = 0; k < 4; ++k) feat[k] = ws->d_feat[k] + (planar ? (size_t)kFeatPad * ws->pitch * 32 + kFeatPad * 4 : ((size_t)kFeatPad * ws->pitch + kFeatPad) * 32);
     // ---- plan every launch first: conv0 (the call's first launch) sets the tile-queue heads of the four stage kernels
     for (int st = 0; st < 5; ++st) {
         Launch& l = L[st];
@@ -1192,8 +1201,22 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
     sr_device_guard restore_device;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
-    const float* src = c->ws[0].d_feat[which] + ((size_t)kFeatPad * c->ws[0].pitch + kFeatPad) * 32;
-    HIPCHK(c, hipMemcpy2D(out_host, (size_t)c->last_w * 128, src, (size_t)c->ws[0].pitch * 128, (size_t)c->last_w * 128,
+    const size_t pitch = (size_t)c->ws[0].pitch;
+    if (c->precision == SR_PRECISION_SPLIT_F16 && sr_split_maps_planar()) {
+        // row-planar map: row y = 8 runs of `pitch` 16-byte groups (4 x 8 hi halves, then their lo halves); whole padded rows come over
+        std::vector<_Float16> rows((size_t)c->last_h * pitch * 64);
+        HIPCHK(c, hipMemcpy(rows.data(), c->ws[0].d_feat[which] + (size_t)kFeatPad * pitch * 32, rows.size() * sizeof(_Float16), hipMemcpyDeviceToHost));
+        for (int y = 0; y < c->last_h; ++y)
+            for (int x = 0; x < c->last_w; ++x)
+                for (int k = 0; k < 32; ++k) {
+                    const _Float16* row = rows.data() + (size_t)y * pitch * 64;
+                    const size_t cell = ((size_t)(k >> 3) * pitch + kFeatPad + x) * 8 + (k & 7);
+                    out_host[((size_t)y * c->last_w + x) * 32 + k] = (float)row[cell] + (float)row[cell + 4 * pitch * 8] * (1.0f / 2048.0f);
+                }
+        return SR_OK;
+    }
+    const float* src = c->ws[0].d_feat[which] + ((size_t)kFeatPad * pitch + kFeatPad) * 32;
+    HIPCHK(c, hipMemcpy2D(out_host, (size_t)c->last_w * 128, src, pitch * 128, (size_t)c->last_w * 128,
                           c->last_h, hipMemcpyDeviceToHost));
     if (c->precision == SR_PRECISION_SPLIT_F16) {  // pixel = 32 hi halves + 32 lo halves -> 32 f32, in place
         for (size_t p = 0; p < (size_t)c->last_h * c->last_w; ++p) {

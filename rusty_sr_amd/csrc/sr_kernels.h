@@ -98,10 +98,14 @@ constexpr int kFeatPadBottom = 12;   // last tile row may start at H-1: + 8 rows
 struct ClearArgs {
     float* map[4];
     int n, H, W, pitch;
+    int planar;       // the maps are row-planar (split-half mode, see sr_split_maps_planar)
     long img_stride;  // pixels
     long total_px;    // n * img_stride + the rows above image 0 + slack
 };
 hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s);
+// Layout of the split-half mode's maps: true = row-planar, [y][16-byte channel group c][x] (pixel (0,0) of group c sits
+// (kFeatPad * pitch) * 128 + c * pitch * 16 + kFeatPad * 16 bytes into the map); false = pixel-major like the exact-f32 maps.
+bool sr_split_maps_planar();
 
 struct AuxArgs {          // bilinear_net / downsample_net (parameter-free graphs)
     const void* img;      // n*H*W*3 f32 or n*H*W*img_ch u8

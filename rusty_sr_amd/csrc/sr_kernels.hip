@@ -61,6 +61,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// Feature maps in HBM.  Exact-f32 maps are PIXEL-MAJOR: [y][x][128 B].  Split-half maps are ROW-PLANAR: [y][c][x][16 B], c = the eight
+// 16-byte channel groups of a pixel (4 groups of 8 hi halves, then their 4 lo groups), one row of one group = pitch x 16 B contiguous.
+// A tile gather (one LDS-DMA instruction = one channel group of 64 consecutive tile pixels) then reads two or three contiguous
+// runs of up to 576 B -- ~11 cache lines, every byte used -- instead of 64 lines of which it uses 16 B each and which the other
+// three waves' and the other half's instructions fetch again.  The split-half mode is bound by the BOARD'S POWER, not by issue slots
+// (scripts/experiments/ubench_split_floor.hip, profiles/r5_ubench_split_floor.txt: the same step loop sustains 1 170 TFLOP/s with
+// line-per-lane gathers and 1 269 with contiguous ones at the same 1 370 W), so what the memory system moves per MFMA is what counts.
+// The exact-f32 mode runs at the full clock and keeps the layout whose stores are whole 128-B lines.  Measured, interleaved A/B at 1080p
+// (profiles/r5_ab_planar.txt): 1.683 -> 1.625 ms per frame (stages 2 / 3 / 4: -4 / -4.6 / -6 %; the producers' stores, now 32-byte
+// runs per channel group, cost nothing measurable -- a pixel permutation that made them 64-byte runs again changed nothing and was removed).
+#ifndef SR_SPLIT_PLANAR
+#define SR_SPLIT_PLANAR 1
+#endif
+template <int PREC>
+constexpr bool kPlanar = PREC == 1 && SR_SPLIT_PLANAR != 0;
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -174,13 +190,17 @@ __device__ __forceinline__ void split_half2(f32x2 v, uint32_t& hi2, uint32_t& lo
 // v_perm_b32 each), so every store is a full dword and 16 even (odd) lanes write
 // one contiguous 64-byte half line.  `base` already points at this lane's pixel
 // (x0 + 4h + (j&1)) and channel pair; `limit` = image columns left of it.
-template <bool MASKED>
+// PLANAR (row-planar map, see kPlanar): `base` points at this lane's pixel in the row of its hi channel group, dword (j % 8) / 2 of
+// the 16-byte group; consecutive pixels are 16 bytes apart and the lo group's row lies `lo_off` = 4 x pitch x 16 bytes further on.
+template <bool MASKED, bool PLANAR>
 __device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16& accm, const f32x16& accx,
-                                                        float bias, float beta, bool odd, int limit) {
+                                                        float bias, float beta, bool odd, int limit, long lo_off) {
     // v_perm_b32(src0 = partner, src1 = mine): bytes 0-3 = mine, 4-7 = partner
     const uint32_t sel = odd ? 0x03020706u   // (partner.hi16, mine.hi16)  = channels (j-1, j) of pixel row+1
                              : 0x05040100u;  // (mine.lo16, partner.lo16)  = channels (j, j+1) of pixel row
     const f32x2 bb = {bias, bias}, ks = {1.0f / kLoScale, 1.0f / kLoScale};
+    constexpr int PX = PLANAR ? 16 : 128;
+    char* base_lo = base + (PLANAR ? lo_off : 64);
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         const f32x2 v = belu2(f32x2{accm[r], accm[r + 1]} + f32x2{accx[r], accx[r + 1]} * ks + bb, beta);
@@ -190,18 +210,28 @@ __device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16
         const uint32_t oh = __builtin_amdgcn_perm(ph, mh, sel), ol = __builtin_amdgcn_perm(pl, ml, sel);
         const int row = (r & 3) + 8 * (r >> 2);
         if (!MASKED || row < limit) {
-            *(uint32_t*)(base + row * 128) = oh;
-            *(uint32_t*)(base + row * 128 + 64) = ol;
+            *(uint32_t*)(base + row * PX) = oh;
+            *(uint32_t*)(base_lo + row * PX) = ol;
         }
     }
 }
-__device__ __forceinline__ void store_belu_tile_split(char* base, const f32x16& accm, const f32x16& accx,
-                                                      float bias, float beta, bool odd) {
-    store_belu_tile_split_t<false>(base, accm, accx, bias, beta, odd, 0);
+// Where lane i (channel pair (i & ~1, i | 1)) of pixel-row group h writes: the address of pixel x = x0 + 4 h + (i & 1) of map row y.
+template <int PREC>
+__device__ __forceinline__ char* split_store_base(float* dst, size_t n, long img_stride, long y, int pitch, int x, int i) {
+    if constexpr (kPlanar<PREC>)
+        return (char*)(dst + (n * img_stride + y * pitch) * 32) + ((size_t)(i >> 3) * pitch + x) * 16 + ((i & 7) >> 1) * 4;
+    else
+        return (char*)(dst + (n * img_stride + y * pitch + x) * 32) + (i & ~1) * 2;
 }
+template <int PREC>
+__device__ __forceinline__ void store_belu_tile_split(char* base, const f32x16& accm, const f32x16& accx,
+                                                      float bias, float beta, bool odd, int pitch) {
+    store_belu_tile_split_t<false, kPlanar<PREC>>(base, accm, accx, bias, beta, odd, 0, (long)pitch * 64);
+}
+template <int PREC>
 __device__ __forceinline__ void store_belu_tile_split_masked(char* base, const f32x16& accm, const f32x16& accx,
-                                                             float bias, float beta, bool odd, int limit) {
-    store_belu_tile_split_t<true>(base, accm, accx, bias, beta, odd, limit);
+                                                             float bias, float beta, bool odd, int limit, int pitch) {
+    store_belu_tile_split_t<true, kPlanar<PREC>>(base, accm, accx, bias, beta, odd, limit, (long)pitch * 64);
 }
 
 // Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`
@@ -326,11 +356,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
             f32x16 zero, am = acc[m];
 #pragma unroll
             for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-            char* base = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h + (i & 1)) * 32) + (i & ~1) * 2;
+            char* base = split_store_base<PREC>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
             if (full_x) {
-                store_belu_tile_split(base, am, zero, bias, beta, i & 1);
+                store_belu_tile_split<PREC>(base, am, zero, bias, beta, i & 1, a.pitch);
             } else {
-                store_belu_tile_split_masked(base, am, zero, bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)));
+                store_belu_tile_split_masked<PREC>(base, am, zero, bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch);
             }
         }
     }
@@ -394,30 +424,37 @@ struct TileOffsets {
     using G = TileGeom<TH, KS>;
     static constexpr int N = (G::NG + NW - 1) / NW;
     uint32_t v[N];
+    template <int PREC>
     __device__ __forceinline__ void init(int pitch, int wave, int lane) {
 #pragma unroll
         for (int gi = 0; gi < N; ++gi) {
             const int P = min((wave + NW * gi) * 64 + lane, G::NPIX - 1);
             const int prow = P / G::TWH, pcol = P - prow * G::TWH;
-            v[gi] = (uint32_t)(prow * pitch + pcol) * 128u;
+            v[gi] = kPlanar<PREC> ? (uint32_t)(prow * pitch) * 128u + (uint32_t)pcol * 16u : (uint32_t)(prow * pitch + pcol) * 128u;
         }
     }
 };
 
-template <int TH, int KS, int NW = 4>
+template <int TH, int KS, int PREC, int NW = 4>
 __device__ __forceinline__ void stage_tile(char* tile, const float* __restrict__ src, const TileOffsets<TH, KS, NW>& off,
                                            long img_stride, int pitch, int n, int y0, int x0, int wave, int /*lane*/) {
     using G = TileGeom<TH, KS>;
-    const char* origin = uniform_ptr(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32);
+    const char* origin = kPlanar<PREC> ? uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch) * 32) + (long)(x0 - G::R) * 16)
+                                       : uniform_ptr(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32);
 #pragma unroll
     for (int gi = 0; gi < TileOffsets<TH, KS, NW>::N; ++gi) {
         const int g = wave + NW * gi;  // wave-uniform
         if (g < G::NG) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr(tile) + g * 1024);
-            // channel group c lands in plane c; the immediate (16 c) applies to the LDS side too, hence the - 16 c
+            if constexpr (kPlanar<PREC>) {  // channel group c: its own row of the map, pitch x 16 bytes further on
+#pragma unroll
+                for (int c = 0; c < 8; ++c) lds_dma16_at(origin, (uint32_t)(c * pitch * 16), off.v[gi], dst + c * G::PLANE);
+            } else {
+                // channel group c lands in plane c; the immediate (16 c) applies to the LDS side too, hence the - 16 c
 #define SR_DMA16(c) lds_dma16<(c) * 16>(origin, off.v[gi], dst + (c) * (G::PLANE - 16))
-            SR_DMA16(0); SR_DMA16(1); SR_DMA16(2); SR_DMA16(3); SR_DMA16(4); SR_DMA16(5); SR_DMA16(6); SR_DMA16(7);
+                SR_DMA16(0); SR_DMA16(1); SR_DMA16(2); SR_DMA16(3); SR_DMA16(4); SR_DMA16(5); SR_DMA16(6); SR_DMA16(7);
 #undef SR_DMA16
+            }
         }
     }
 }
@@ -777,9 +814,9 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
                     });
                 }
             } else {
-                char* base = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h + (i & 1)) * 32) + (i & ~1) * 2;
-                if (full_x) store_belu_tile_split(base, acc[m], accx[m], bias[0], beta, i & 1);
-                else store_belu_tile_split_masked(base, acc[m], accx[m], bias[0], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)));
+                    char* base = split_store_base<PREC>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
+                if (full_x) store_belu_tile_split<PREC>(base, acc[m], accx[m], bias[0], beta, i & 1, a.pitch);
+                else store_belu_tile_split_masked<PREC>(base, acc[m], accx[m], bias[0], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch);
             }
         }
     } else {
@@ -930,15 +967,15 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
 
     TileOffsets<TH, KS0, NW> off0;
     TileOffsets<TH, 3, NW> off3;
-    off0.init(a.pitch, wave, lane);
-    if constexpr (NSRC >= 2) off3.init(a.pitch, wave, lane);
+    off0.template init<PREC>(a.pitch, wave, lane);
+    if constexpr (NSRC >= 2) off3.template init<PREC>(a.pitch, wave, lane);
     // everything the first phase needs: weight chunks 0..3 and the first source tile
     int n, tx, ty;
     tile_coords(grid, a.tiles_x, xcd_remap(blockIdx.x, gridDim.x), n, tx, ty);
     const int x0 = tx * kTW, y0 = grid.y0 + ty * TH;
 #pragma unroll
     for (int k = 0; k < kRingAhead; ++k) weight_chunk_async(ring + k * 4096, a.wpack + k * kChunkFloats, wave, lane);
-    stage_tile<TH, KS0, NW>(tile, a.src[0], off0, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+    stage_tile<TH, KS0, PREC, NW>(tile, a.src[0], off0, a.img_stride, a.pitch, n, y0, x0, wave, lane);
 
     f32x16 acc[NTN * T], accx[PREC == 1 ? NTN * T : 1];  // accx: the cross products of the split-half mode, x2048
 #pragma unroll
@@ -958,14 +995,14 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
     taps(std::integral_constant<int, KS0>{});
     if constexpr (NSRC >= 2) {
         __builtin_amdgcn_s_setprio(3);
-        stage_tile<TH, 3, NW>(tile, a.src[1], off3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+        stage_tile<TH, 3, PREC, NW>(tile, a.src[1], off3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
         ring_barrier<0>();
         __builtin_amdgcn_s_setprio(0);
         taps(std::integral_constant<int, 3>{});
     }
     if constexpr (NSRC >= 3) {
         __builtin_amdgcn_s_setprio(3);
-        stage_tile<TH, 3, NW>(tile, a.src[2], off3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
+        stage_tile<TH, 3, PREC, NW>(tile, a.src[2], off3, a.img_stride, a.pitch, n, y0, x0, wave, lane);
         ring_barrier<0>();
         __builtin_amdgcn_s_setprio(0);
         taps(std::integral_constant<int, 3>{});
@@ -1046,12 +1083,13 @@ struct HalfTile {
     static constexpr int STEPS = (KS * KS + 1) / 2;
     static_assert(TileGeom<4, KS>::TWH == G::TWH, "a small tile is the top of a big one");
     uint32_t off[G::NG];  // gather offset of tile pixel 64 g + lane (same for every wave: wave w moves plane w)
+    template <int PREC>
     __device__ __forceinline__ void init(int pitch, int lane) {
 #pragma unroll
         for (int g = 0; g < G::NG; ++g) {
             const int P = min(g * 64 + lane, G::NPIX - 1);
             const int prow = P / G::TWH, pcol = P - prow * G::TWH;
-            off[g] = (uint32_t)(prow * pitch + pcol) * 128u;
+            off[g] = kPlanar<PREC> ? (uint32_t)(prow * pitch) * 128u + (uint32_t)pcol * 16u : (uint32_t)(prow * pitch + pcol) * 128u;
         }
     }
     // 16-byte channel group wave `wave` moves for half `khalf`: f32 map = 8 groups of 4 channels; split map = 4 groups of
@@ -1064,8 +1102,7 @@ struct HalfTile {
     template <int PREC>
     __device__ __forceinline__ void stage(uint32_t buf, const float* __restrict__ src, int khalf, long img_stride, int pitch,
                                           int n, int y0, int x0, int wave) const {
-        const char* origin = uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) +
-                                         chunk_of<PREC>(khalf, wave) * 16);
+        const char* origin = origin_of<PREC>(src, khalf, img_stride, pitch, n, y0, x0, wave);
         const uint32_t dst = __builtin_amdgcn_readfirstlane(buf + wave * G::PLANE);
 #pragma unroll
         for (int g = 0; g < G::NG; ++g) lds_dma16<0>(origin, off[g], dst + g * 1024);
@@ -1074,8 +1111,12 @@ struct HalfTile {
     template <int PREC>
     static __device__ __forceinline__ const char* origin_of(const float* __restrict__ src, int khalf, long img_stride, int pitch, int n,
                                                             int y0, int x0, int wave) {
-        return uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) +
-                           chunk_of<PREC>(khalf, wave) * 16);
+        if constexpr (kPlanar<PREC>)  // row-planar map: the channel group's own row, pitch x 16 bytes per group
+            return uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch) * 32) + (long)(x0 - G::R) * 16 +
+                               (size_t)chunk_of<PREC>(khalf, wave) * pitch * 16);
+        else
+            return uniform_ptr((const char*)(src + ((size_t)n * img_stride + (long)(y0 - G::R) * pitch + (x0 - G::R)) * 32) +
+                               chunk_of<PREC>(khalf, wave) * 16);
     }
     static __device__ __forceinline__ uint32_t plane_of(uint32_t buf, int wave) { return __builtin_amdgcn_readfirstlane(buf + wave * G::PLANE); }
     // ... and one gather instruction of it: pixel group g (64 tile pixels)
@@ -1313,8 +1354,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     const float beta = FINAL ? 0.f : a.beta[i];
     H0 h0;
     H3 h3;
-    h0.init(a.pitch, lane);
-    if constexpr (NSRC >= 2) h3.init(a.pitch, lane);
+    h0.template init<PREC>(a.pitch, lane);
+    if constexpr (NSRC >= 2) h3.template init<PREC>(a.pitch, lane);
 
     // combined tile id (queue_resolve) -> image, tile origin, tile class.  The 16 dwords of the tile class's TileGrid (its divisors)
     // are needed once per tile; held in SGPRs across the tile they are spilled to VGPR lanes (102 SGPRs are all there are) and come
@@ -1472,9 +1513,19 @@ __global__ __launch_bounds__(256) void clear_borders_kernel(ClearArgs a) {
         for (long q = base * 8 + threadIdx.x; q < end * 8; q += 256) m[q] = z;   // 8 float4 per 32-channel pixel
         return;
     }
+    if (a.planar) {  // row-planar map: the row holds eight runs of `pitch` 16-byte groups, each with its own left and right border
+        const int edge = kFeatPad + (a.pitch - kFeatPad - a.W);  // border cells per run
+        for (int k = threadIdx.x; k < 8 * edge; k += 256) {
+            const int c = k / edge, e = k - c * edge;
+            m[base * 8 + (long)c * a.pitch + (e < kFeatPad ? e : a.W + e)] = z;
+        }
+        return;
+    }
     for (long q = base * 8 + threadIdx.x; q < (base + kFeatPad) * 8; q += 256) m[q] = z;
     for (long q = (base + kFeatPad + a.W) * 8 + threadIdx.x; q < end * 8; q += 256) m[q] = z;
 }
+
+bool sr_split_maps_planar() { return kPlanar<1>; }
 
 hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s) {
     const long rows = (a.total_px + a.pitch - 1) / a.pitch;
