@@ -123,6 +123,24 @@ void pack_conv0(std::vector<float>& dst, const float* w) {
                     }
 }
 
+// conv0 for the split-half mode's own stage-0 kernel (conv0_split_kernel): K slot s = 4 tap + channel, tap = 5 ky + kx (100 slots, the
+// fourth channel and slots 100-111 zero), seven K-blocks of 16: [b 7][hi | lo][h 2][o 32][e 8] halves with s = 16 b + 8 h + e.
+void pack_conv0_split(std::vector<float>& dst, const float* w) {
+    dst.assign(7 * 2 * 2 * 32 * 8 / 2, 0.0f);
+    _Float16* hp = (_Float16*)dst.data();
+    for (int b = 0; b < 7; ++b)
+        for (int h = 0; h < 2; ++h)
+            for (int o = 0; o < 32; ++o)
+                for (int e = 0; e < 8; ++e) {
+                    const int s = 16 * b + 8 * h + e, tap = s / 4, c = s % 4;
+                    if (tap >= 25 || c >= 3) continue;
+                    _Float16 hi, lo;
+                    split_half_host(w[((size_t)o * 25 + tap) * 3 + c], hi, lo);
+                    hp[(((b * 2 + 0) * 2 + h) * 32 + o) * 8 + e] = hi;
+                    hp[(((b * 2 + 1) * 2 + h) * 32 + o) * 8 + e] = lo;
+                }
+}
+
 // LinearInterp x f (network.rs:27) as a 3x3 convolution of the edge-replicated 3-channel
 // input onto the expand channels: 9 taps x N-tiles x [h 2][lane 32][q 2], cin = 2h+q.
 // Along one axis output phase p of pixel i sits at s - i = (2p+1-f)/(2f) (half-pixel centres,
@@ -283,6 +301,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         const ParamLayout L(factor);
         pack_conv0(w, params + L.conv0);
         c->off_w0 = push(w);
+        pack_conv0_split(w, params + L.conv0);
+        c->off_w0h = push(w);
         for (int split = 0; split < 2; ++split) {  // exact-f32 chunks, then the same stages in split-half form
             auto ident = [](int, int j) { return j; };
             auto expand = [&](int nt, int j) { return expand_channel(factor, nt, j); };
@@ -616,7 +636,7 @@ int StackJob::launch(int st) const {
     if (st == 0) {
         const int tiles_y = (y1 - y0 + l.th - 1) / l.th;
         Conv0Args a{};
-        a.img = d_img; a.wpack = P + c->off_w0; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
+        a.img = d_img; a.wpack = P + c->off_w0; a.wpack_split = P + c->off_w0h; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
         a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
         a.pitch = ws->pitch; a.img_stride = ws->img_stride;
         a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;

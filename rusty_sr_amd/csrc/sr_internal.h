@@ -14,7 +14,7 @@ struct sr_ctx {
     hipStream_t stream = nullptr;
     float* d_params = nullptr;  // all packed parameters, one allocation
     void* d_qtab = nullptr;     // bilinear_net / downsample_net: data_to_img(LinearToSrgb(l)) as a step table (sr_aux.hip)
-    size_t off_w0 = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
+    size_t off_w0 = 0, off_w0h = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;

@@ -19,6 +19,7 @@ inline TileDiv make_tile_div(uint32_t d) {
 struct Conv0Args {
     const void* img;      // n*H*W*3 f32, or n*H*W*img_ch u8
     const float* wpack;   // [ky 5][j/2 4][h 2][cout 32][2]: K packed per kernel row (15 of 16 slots), see pack_conv0
+    const void* wpack_split;  // split-half mode: [K-block 7][hi | lo][h 2][cout 32][8 halves], slot 16 b + 8 h + e = 4 tap + channel (pack_conv0_split)
     const float* bias;    // 32
     const float* beta;    // 32
     float* dst;           // padded feature map (see FeatGeom), pointer to pixel (0,0) of image 0

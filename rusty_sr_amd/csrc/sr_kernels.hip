@@ -368,6 +368,116 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
 }
 
 // ---------------------------------------------------------------------------
+// Stage 0 of the split-half mode, on the f16 matrix cores.  conv0_kernel<.., PREC = 1> computes exact f32 products on the vector ALU's
+// MFMA (80 per tile and wave = 5 120 cycles) and then pays BeLU + the hi / lo split of 32 outputs per input pixel on the same pipe:
+// 0.144 ms at 1080p, 9 % of the split-half frame (0.107 ms in the exact mode, whose epilogue is shorter).  Here the image tile is
+// split into halves once while it is staged ([pixel][R G B 0] as hi halves and as lo halves; a byte goes through a table of
+// split(byte / 255)), K runs over tap * 4 + channel (100 slots -> 7 K-blocks of 16; the 25 slots of the padding channel and the last
+// 12 carry zero weights and read pixels inside the 5x5 footprint), and a tile row is 7 x 3 v_mfma_f32_32x32x16_f16 = 672 matrix-pipe
+// cycles that run beside the epilogue's vector work instead of in front of it.  The weights (7 x (hi, lo) fragments, 14 KB) sit in LDS
+// for every tile the workgroup walks.  Same products as every other stage of this mode: hi.hi + (hi.lo + lo.hi) / 2048.
+// ---------------------------------------------------------------------------
+#ifndef SR_CONV0_SPLIT_MFMA
+#define SR_CONV0_SPLIT_MFMA 1
+#endif
+template <int TH, bool IMG_U8>
+__global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
+    constexpr int T = TH / 4;
+    constexpr int TWH = kTW + 4, THH = TH + 4, NPIX = THH * TWH;
+    constexpr int NB = 7;  // K-blocks of 16 slots: slot s = 4 tap + channel, tap = 5 ky + kx
+    __shared__ __attribute__((aligned(16))) uint32_t s_px[2][NPIX * 2];  // [hi | lo][pixel][R G | B 0] halves
+    __shared__ uint32_t s_lut[256];                                      // byte -> hi half | lo half << 16 of byte / 255 (img_to_data, main.rs:170)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    // the tile-queue heads of this call's four stage kernels (see conv0_kernel)
+    if (blockIdx.x == 0 && tid < 40) a.queue_reset[tid] = (a.queue_grid[tid >> 3] - (tid & 7) + 7) >> 3;
+    if constexpr (IMG_U8) {
+        uint32_t hi2, lo2;
+        split_half2(f32x2{__fdiv_rn((float)tid, 255.0f), 0.0f}, hi2, lo2);
+        s_lut[tid] = (hi2 & 0xffffu) | (lo2 << 16);
+    }
+    // B fragments: lane (output channel i, K half h) of block b holds slots 16 b + 8 h + (0..7), hi halves and lo halves (sr_api.cpp
+    // pack_conv0_split); 14 KB, copied into LDS once per workgroup (in registers they would cost 56 VGPRs and a third of the occupancy)
+    __shared__ __attribute__((aligned(16))) f16x8 s_w[NB * 2 * 64];
+    for (int k = tid; k < NB * 2 * 64; k += kThreads) s_w[k] = ((const f16x8*)a.wpack_split)[k];
+    const f16x8* wl = s_w + h * 32 + i;
+    // A fragments: the lane's two taps of block b (4 b + 2 h and the next; beyond the 25th: the 25th again, its weights are zero), as byte
+    // offsets of their pixels from the lane's own pixel (row 0, column i) in the staged tile
+    uint32_t off_a[NB], off_b[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int ta = min(4 * b + 2 * h, 24), tb = min(4 * b + 2 * h + 1, 24);
+        off_a[b] = (uint32_t)(((ta / 5) * TWH + ta % 5) * 8);
+        off_b[b] = (uint32_t)(((tb / 5) * TWH + tb % 5) * 8);
+    }
+    const char* abase = (const char*)&s_px[0][0] + ((wave * T) * TWH + i) * 8;
+    constexpr uint32_t LO = NPIX * 2 * 4;  // bytes from the hi array to the lo array
+    const float bias = a.bias[i], beta = a.beta[i];
+    for (int bid = blockIdx.x; bid < a.n_tiles; bid += gridDim.x) {
+        const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
+        const int ty = tile_div(t, a.div_tx), tx = t - ty * a.tiles_x;
+        const int x0 = tx * kTW, y0 = a.y_begin + ty * TH;
+        const size_t img_px0 = (size_t)n * a.H * a.W;
+        __syncthreads();  // the previous tile's reads of s_px are done (first tile: the table is written)
+        for (int p = tid; p < NPIX; p += kThreads) {
+            const int py = p / TWH, px = p - py * TWH;
+            const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+            uint32_t h0 = 0, h1 = 0, l0 = 0, l1 = 0;  // (R G), (B 0) as hi halves / lo halves; zero padding outside the image (Padding::Same)
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const size_t gp = img_px0 + (size_t)gy * a.W + gx;
+                if constexpr (IMG_U8) {
+                    const uint8_t* q = (const uint8_t*)a.img + gp * a.img_ch;
+                    const uint32_t wr = s_lut[q[0]], wg = s_lut[q[1]], wb = s_lut[q[2]];
+                    h0 = __builtin_amdgcn_perm(wg, wr, 0x05040100u); l0 = __builtin_amdgcn_perm(wg, wr, 0x07060302u);
+                    h1 = wb & 0xffffu; l1 = wb >> 16;
+                } else {
+                    const float* q = (const float*)a.img + gp * 3;
+                    split_half2(f32x2{q[0], q[1]}, h0, l0);
+                    split_half2(f32x2{q[2], 0.0f}, h1, l1);
+                }
+            }
+            *(uint2*)&s_px[0][p * 2] = make_uint2(h0, h1);
+            *(uint2*)&s_px[1][p * 2] = make_uint2(l0, l1);
+        }
+        __syncthreads();
+
+        f32x16 accm[T], accx[T];
+#pragma unroll
+        for (int m = 0; m < T; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[m][r] = 0.f; accx[m][r] = 0.f; }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const f16x8 bh = wl[(b * 2 + 0) * 64], bl = wl[(b * 2 + 1) * 64];
+#pragma unroll
+            for (int m = 0; m < T; ++m) {
+                const char* ra = abase + off_a[b] + m * TWH * 8;
+                const char* rb = abase + off_b[b] + m * TWH * 8;
+                const uint2 ha = *(const uint2*)ra, hb2 = *(const uint2*)rb;
+                const uint2 la = *(const uint2*)(ra + LO), lb2 = *(const uint2*)(rb + LO);
+                const uint32_t ahw[4] = {ha.x, ha.y, hb2.x, hb2.y}, alw[4] = {la.x, la.y, lb2.x, lb2.y};
+                const f16x8 ah = __builtin_bit_cast(f16x8, ahw), al = __builtin_bit_cast(f16x8, alw);
+                accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[m], 0, 0, 0);
+                accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[m], 0, 0, 0);
+                accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[m], 0, 0, 0);
+            }
+        }
+
+        const bool full_x = x0 + kTW <= a.W;
+#pragma unroll
+        for (int m = 0; m < T; ++m) {
+            const int y = y0 + wave * T + m;
+            if (y >= a.y_end) continue;
+            char* base = split_store_base<1>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
+            if (full_x) store_belu_tile_split<1>(base, accm[m], accx[m], bias, beta, i & 1, a.pitch);
+            else store_belu_tile_split_masked<1>(base, accm[m], accx[m], bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Stages 1-4: sum of up to three 32-channel convolutions (first KS0 x KS0,
 // the others 3x3) + bias, then BeLU -> NHWC feature map, or (FINAL) + the
 // bilinear residual as a fourth K-segment, depth-to-space -> output image.
@@ -1550,8 +1660,18 @@ static hipError_t launch_conv0_t(const Conv0Args& a, int nblk, bool img_u8, hipS
     return hipGetLastError();
 }
 
+template <int TH>
+static hipError_t launch_conv0_split_t(const Conv0Args& a, int nblk, bool img_u8, hipStream_t s) {
+    if (img_u8)
+        hipLaunchKernelGGL((conv0_split_kernel<TH, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv0_split_kernel<TH, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool img_u8, hipStream_t s) {
     if (prec == 0) return th == 8 ? launch_conv0_t<8, 0>(a, nblk, img_u8, s) : launch_conv0_t<4, 0>(a, nblk, img_u8, s);
+    if (SR_CONV0_SPLIT_MFMA && kPlanar<1>) return th == 8 ? launch_conv0_split_t<8>(a, nblk, img_u8, s) : launch_conv0_split_t<4>(a, nblk, img_u8, s);
     return th == 8 ? launch_conv0_t<8, 1>(a, nblk, img_u8, s) : launch_conv0_t<4, 1>(a, nblk, img_u8, s);
 }
 
