@@ -49,8 +49,10 @@ enum sr_status {
     SR_E_NOMEM = -6,
     SR_E_BYTEVEC = -7,     /* main.rs:138 "ByteVec conversion failed" */
     SR_E_HALO = -8,        /* band call with a halo that is neither 0 nor >= SR_HALO (or a band thinner than SR_HALO) */
-    SR_E_COMM = -9         /* librccl missing, no communicator on the context, or an RCCL call failed;
+    SR_E_COMM = -9,        /* librccl missing, no communicator on the context, or an RCCL call failed;
                               sr_last_comm_error() has the ncclResult_t */
+    SR_E_DOMAIN = -10      /* SR_PRECISION_SPLIT_F16 only: a weight, an input or an activation cannot be carried as a pair of
+                              halves (not finite, or 65504 and beyond); see sr_set_precision / sr_check_domain */
 };
 
 /* Replaces: `<Vec<f32>>::decode::<u32>(blob)` (bytevec 0.2.0; reference
@@ -214,13 +216,27 @@ int sr_upscale_sharded_rgba8_all(sr_ctx* const* ctxs, int n, const uint8_t* cons
 
 /* Arithmetic of the conv stack.
  *   SR_PRECISION_F32       (default) v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate --
- *                          the same arithmetic class as the reference's f32 CPU path.
+ *                          the same arithmetic class as the reference's f32 CPU path.  Domain: any f32, like
+ *                          graph.forward (main.rs:171); infinities and NaNs propagate as IEEE arithmetic has them.
  *   SR_PRECISION_SPLIT_F16 every activation / weight is carried as a pair of halves
  *                          (hi + lo/2048, ~2^-23 relative) and each product is three f16 MFMAs with
  *                          f32 accumulation on the matrix cores; outputs stay within the 1e-4 bar
- *                          (tests/test_gpu_parity.py runs every parity test in both modes). */
+ *                          (tests/test_gpu_parity.py runs every parity test in both modes).
+ *                          DOMAIN: every weight, input value and activation finite and below 65504 in magnitude
+ *                          (u8 images through the bundled weights stay below 100).  Nothing outside it is clamped
+ *                          silently:
+ *                            - sr_set_precision returns SR_E_DOMAIN for a parameter vector with such a weight and leaves
+ *                              the context in its previous mode;
+ *                            - the kernels notice an input or activation that leaves the domain.  The synchronous
+ *                              host-pointer entry points (sr_upscale_f32 / _rgba8 and their _multi / _batch_multi forms) then
+ *                              compute the whole call again in SR_PRECISION_F32 and return its result;
+ *                            - the asynchronous *_dev entry points cannot: their output is unspecified where the overflow
+ *                              reached, and the context keeps a fault that sr_check_domain reports. */
 enum sr_precision { SR_PRECISION_F32 = 0, SR_PRECISION_SPLIT_F16 = 1 };
 int sr_set_precision(sr_ctx* ctx, int mode);
+/* After the stream(s) of earlier *_dev calls have been synchronised: SR_E_DOMAIN if any of them left the domain of
+ * SR_PRECISION_SPLIT_F16 since the last check (the fault is cleared), else SR_OK.  Always SR_OK in SR_PRECISION_F32. */
+int sr_check_domain(sr_ctx* ctx);
 
 /* (A/B tuning switches that change no result bit, and their environment defaults, are NOT part of this interface:
  * include/srhip_experimental.h.) */

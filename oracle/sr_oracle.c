@@ -402,6 +402,7 @@ void SYM(sr_oracle_data_to_rgba8)(const real* v, size_t npx, uint8_t* out) {
         for (int c = 0; c < SR_CH; ++c) {
             real q = FLOOR((real)255 * v[p * SR_CH + c] + (real)0.5);
             q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            if (q != q) q = 0; /* NaN: Rust's float -> u8 `as` cast saturates and sends NaN to 0 (a C cast of NaN is undefined) */
             out[p * 4 + c] = (uint8_t)q;
         }
         out[p * 4 + 3] = 255;

@@ -20,6 +20,7 @@ pub const SR_PRECISION_F32: c_int = 0;
 pub const SR_PRECISION_SPLIT_F16: c_int = 1;
 pub const SR_FACTOR: c_int = 3;
 pub const SR_E_COMM: c_int = -9;
+pub const SR_E_DOMAIN: c_int = -10;
 pub const SR_HALO: c_int = 7;
 pub const SR_COMM_ID_BYTES: c_int = 128;
 
@@ -32,6 +33,7 @@ extern "C" {
     pub fn sr_num_params(graph: c_int) -> c_int;
     pub fn sr_num_params_factor(factor: c_int) -> c_int;
     pub fn sr_set_precision(ctx: *mut SrCtx, mode: c_int) -> c_int;
+    pub fn sr_check_domain(ctx: *mut SrCtx) -> c_int;
     pub fn sr_destroy(ctx: *mut SrCtx);
     pub fn sr_upscale_f32(ctx: *mut SrCtx, input: *const f32, n: c_int, h: c_int, w: c_int, out: *mut f32) -> c_int;
     pub fn sr_upscale_rgba8(ctx: *mut SrCtx, input: *const u8, in_channels: c_int, n: c_int, h: c_int, w: c_int,

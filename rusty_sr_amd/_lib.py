@@ -11,7 +11,7 @@ SR_NUM_PARAMS = 130459
 SR_HALO = 7
 
 SR_OK, SR_E_INVALID, SR_E_PARAM_COUNT, SR_E_FACTOR, SR_E_NO_DEVICE = 0, -1, -2, -3, -4
-SR_E_HIP, SR_E_NOMEM, SR_E_BYTEVEC, SR_E_HALO, SR_E_COMM = -5, -6, -7, -8, -9
+SR_E_HIP, SR_E_NOMEM, SR_E_BYTEVEC, SR_E_HALO, SR_E_COMM, SR_E_DOMAIN = -5, -6, -7, -8, -9, -10
 SR_COMM_ID_BYTES = 128
 SR_PRECISION_F32, SR_PRECISION_SPLIT_F16 = 0, 1
 SR_GRAPH_SR_NET, SR_GRAPH_BILINEAR, SR_GRAPH_DOWNSAMPLE = 0, 1, 2
@@ -37,6 +37,7 @@ SYMBOLS = {
     "sr_upscale_band_rgba8_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sr_read_feature": (_i, [_vp, _i, _fp, _sz]),
     "sr_set_precision": (_i, [_vp, _i]),
+    "sr_check_domain": (_i, [_vp]),
     "sr_upscale_f32_multi": (_i, [C.POINTER(_vp), _i, _fp, _i, _i, _fp]),
     "sr_upscale_rgba8_multi": (_i, [C.POINTER(_vp), _i, _u8p, _i, _i, _i, _u8p]),
     "sr_upscale_f32_batch_multi": (_i, [C.POINTER(_vp), _i, _fp, _i, _i, _i, _fp]),

@@ -187,6 +187,7 @@ const char* sr_strerror(int s) {
         case SR_E_BYTEVEC: return "ByteVec conversion failed";  // reference main.rs:138
         case SR_E_HALO: return "band halo must be 0 (true image edge) or >= SR_HALO, and a sharded band at least SR_HALO rows";
         case SR_E_COMM: return "RCCL communicator missing or failed (librccl not loadable, sr_comm_init_* not called, or an RCCL error)";
+        case SR_E_DOMAIN: return "outside the domain of SR_PRECISION_SPLIT_F16: a weight, an input or an activation is not finite or reaches 65504 in magnitude (use SR_PRECISION_F32)";
         default: return "unknown error";
     }
 }
@@ -333,7 +334,13 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
                 }
             c->off_bias[4] = push(eb);
         }
+        // the split-half mode carries every conv weight as a pair of halves: all of them finite and below the largest half, or the mode is refused
+        for (size_t k = L.conv1; k < L.end && c->split_ok; ++k) c->split_ok = std::fabs(params[k]) < 65504.0f;   // (false for NaN too)
+        for (size_t k = L.conv0; k < L.conv0 + 2400 && c->split_ok; ++k) c->split_ok = std::fabs(params[k]) < 65504.0f;
         mark("weight packing (host)");
+        HIPCHK(c, hipHostMalloc((void**)&c->h_domain, 64, hipHostMallocMapped));
+        *c->h_domain = 0;
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_domain, c->h_domain, 0));
         for (auto& w : c->ws) HIPCHK(c, hipMalloc((void**)&w.d_queue, 5 * 8 * sizeof(int)));
 
         HIPCHK(c, hipMalloc((void**)&c->d_params, host.size() * sizeof(float)));
@@ -364,6 +371,7 @@ void sr_destroy(sr_ctx* c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_qtab) (void)hipFree(c->d_qtab);
+    if (c->h_domain) (void)hipHostFree(c->h_domain);
     for (auto& p : c->d_in) if (p) (void)hipFree(p);
     for (auto& p : c->d_out) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -383,6 +391,7 @@ int sr_num_params(int graph) { return graph == SR_GRAPH_SR_NET ? SR_NUM_PARAMS :
 
 int sr_set_precision(sr_ctx* c, int mode) {
     if (!c || (mode != SR_PRECISION_F32 && mode != SR_PRECISION_SPLIT_F16)) return SR_E_INVALID;
+    if (mode == SR_PRECISION_SPLIT_F16 && !c->split_ok) return SR_E_DOMAIN;  // a weight that no pair of halves can carry: refused, not clamped
     if (mode != c->precision) {
         // the two modes lay their feature maps out differently (sr_kernels.h sr_split_maps_planar): what was interior for one is border
         // for the other, so the workspaces' borders are cleared again before the next pass (ensure_features)
@@ -643,6 +652,7 @@ int StackJob::launch(int st) const {
         a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
         a.n_tiles = n * tiles_x * tiles_y;
         a.queue_reset = ws->d_queue;
+        a.domain = c->d_domain;
         for (int k = 1; k < 5; ++k) a.queue_grid[k] = L[k].grid;
         // (grid: 8 workgroups per CU walking the tiles with a fixed stride; measured with 8 / 12 / 16 / 32 per CU, one per tile, and
         // a grid that divides the tile count evenly: conv0's time does not depend on it)
@@ -662,7 +672,7 @@ int StackJob::launch(int st) const {
     a.beta = st < 4 ? P + c->off_beta[st] : nullptr;
     a.H = H; a.W = W; a.img_ch = img_ch;
     a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x;
-    a.n_img = n; a.queue = ws->d_queue + st * 8;
+    a.n_img = n; a.queue = ws->d_queue + st * 8; a.domain = c->d_domain;
     a.grid[0] = make_tile_grid(8, y0, l.ty8, tiles_x, n, bw);
     a.grid[1] = make_tile_grid(4, y0 + 8 * l.ty8, l.ty4, tiles_x, n, bw);
     if (l.pipe) HIPCHK(c, sr_launch_stage_pipe(st, c->factor, a, c->precision, l.grid, img_u8, out_u8, s));
@@ -1080,6 +1090,17 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     c->h2d_ms = h2d; c->total_ms = ker; c->d2h_ms = d2h; c->band_pending = false;
     c->last_chunks = nch;
     if (nch > 1) c->last_h = c->last_w = 0;  // the feature maps hold one chunk only: sr_read_feature refuses
+    if (c->precision == SR_PRECISION_SPLIT_F16 && c->h_domain && *(volatile int*)c->h_domain) {
+        // Some value of this call left the split-half mode's domain (every stream has drained: the flag is final).  A synchronous
+        // call never hands out clamped pixels: the whole job is computed again in exact f32 -- graph.forward takes any f32 (main.rs:171).
+        *(volatile int*)c->h_domain = 0;
+        if (reserve) return SR_OK;
+        (void)sr_set_precision(c, SR_PRECISION_F32);
+        const int rc2 = run_host(c, in, img_u8, img_ch, deal, h, w, out, out_u8, y_lo, y_hi, false);
+        (void)sr_set_precision(c, SR_PRECISION_SPLIT_F16);
+        ++c->domain_fallbacks;
+        return rc2;
+    }
     return SR_OK;
 }
 
@@ -1246,6 +1267,13 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
         }
     }
     return SR_OK;
+}
+
+int sr_check_domain(sr_ctx* c) {
+    if (!c) return SR_E_INVALID;
+    if (!c->h_domain || !*(volatile int*)c->h_domain) return SR_OK;
+    *(volatile int*)c->h_domain = 0;
+    return SR_E_DOMAIN;
 }
 
 int sr_last_timing(sr_ctx* c, double* total_ms, double stage_ms[5], double* h2d_ms, double* d2h_ms) {

@@ -16,6 +16,13 @@ struct sr_ctx {
     void* d_qtab = nullptr;     // bilinear_net / downsample_net: data_to_img(LinearToSrgb(l)) as a step table (sr_aux.hip)
     size_t off_w0 = 0, off_w0h = 0, off_w[5] = {0}, off_wh[5] = {0}, off_bias[5] = {0}, off_beta[5] = {0};
     int precision = 0;  // SR_PRECISION_F32 / SR_PRECISION_SPLIT_F16
+    // Domain of the split-half mode (include/srhip.h, sr_set_precision): values are carried as pairs of HALVES, so every weight, input
+    // and activation must be finite and below 65504 in magnitude.  Weights are checked once (split_ok); inputs and activations by the
+    // kernels, which raise *h_domain -- one word of mapped host memory, read by the host without a copy once the stream has drained.
+    bool split_ok = true;
+    int* h_domain = nullptr;   // host address of the flag
+    int* d_domain = nullptr;   // the same word as the device sees it
+    int domain_fallbacks = 0;  // host-pointer calls that were recomputed in exact f32 because of it
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;
     // Device workspace of one pass of the conv stack.  Two of them: the host pipeline (run_host) alternates chunks between

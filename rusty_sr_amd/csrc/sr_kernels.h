@@ -32,6 +32,7 @@ struct Conv0Args {
     TileDiv div_tpi, div_tx;
     int* queue_reset;     // the 5 x 8 tile-queue heads of this call's stage kernels: conv0 is the call's first launch and sets
                           // them (they are first read by stage 1, a later launch of the same stream) -- no memset node per call
+    int* domain;          // split-half mode: the context's domain flag (mapped host memory), raised when a value leaves the f16 range
     int queue_grid[5];    // workgroups of each stage launch (entry 0 unused): head x of a stage starts at the number of its
                           // workgroups b with b % 8 == x, whose first tile is entry b / 8 of queue x without an atomic
 };
@@ -86,6 +87,7 @@ struct StageArgs {
     // workgroups' finishing times, which is what a launch loses at its end, halves.  The first kernel form runs one class.
     TileGrid grid[2];
     int* queue;           // persistent forms: 8 per-XCD tile-queue heads, set by conv0 (Conv0Args::queue_grid)
+    int* domain;          // split-half mode: the context's domain flag (see Conv0Args)
 };
 
 // Feature maps live in HBM with a zero border so tile staging never tests bounds:

@@ -183,6 +183,19 @@ __device__ __forceinline__ void split_half2(f32x2 v, uint32_t& hi2, uint32_t& lo
     lo2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r.x, r.y));
 }
 
+// Domain of the split-half mode: a value is carried as hi + lo / 2048 with hi a HALF, so it must be finite and below 65504 in
+// magnitude -- v_cvt_pkrtz saturates there, silently.  Every producer of split values therefore keeps the largest hi bit pattern it has
+// made (sign stripped; one v_and + one v_pk_max_u16 per PAIR of values: infinities and NaNs are the largest patterns of all) and, if a
+// half reached 0x7bff (65504), raises the context's domain flag -- a word of mapped host memory (sr_api.cpp: host-pointer calls then
+// recompute in exact f32, device-pointer calls leave it to sr_check_domain).  Natural images stay below 100.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void domain_track(uint32_t& dom, uint32_t hi2) {
+    dom = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, dom), __builtin_bit_cast(u16x2, hi2 & 0x7fff7fffu)));
+}
+__device__ __forceinline__ void domain_report(uint32_t dom, int* flag) {
+    if (((dom & 0xffffu) >= 0x7bffu) | ((dom >> 16) >= 0x7bffu)) *(volatile int*)flag = 1;
+}
+
 // BeLU(acc) of one 32x32 tile -> split-half NHWC rows.  A feature pixel is 128 B:
 // 32 hi halves then 32 lo halves.  Lane = channel j, register pair (r, r+1) = two
 // adjacent pixels: even lanes collect channels (j, j+1) of pixel `row` from their
@@ -194,7 +207,7 @@ __device__ __forceinline__ void split_half2(f32x2 v, uint32_t& hi2, uint32_t& lo
 // the 16-byte group; consecutive pixels are 16 bytes apart and the lo group's row lies `lo_off` = 4 x pitch x 16 bytes further on.
 template <bool MASKED, bool PLANAR>
 __device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16& accm, const f32x16& accx,
-                                                        float bias, float beta, bool odd, int limit, long lo_off) {
+                                                        float bias, float beta, bool odd, int limit, long lo_off, uint32_t& dom) {
     // v_perm_b32(src0 = partner, src1 = mine): bytes 0-3 = mine, 4-7 = partner
     const uint32_t sel = odd ? 0x03020706u   // (partner.hi16, mine.hi16)  = channels (j-1, j) of pixel row+1
                              : 0x05040100u;  // (mine.lo16, partner.lo16)  = channels (j, j+1) of pixel row
@@ -206,6 +219,7 @@ __device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16
         const f32x2 v = belu2(f32x2{accm[r], accm[r + 1]} + f32x2{accx[r], accx[r + 1]} * ks + bb, beta);
         uint32_t mh, ml;
         split_half2(v, mh, ml);
+        domain_track(dom, mh);
         const uint32_t ph = swap_lane_pair(mh), pl = swap_lane_pair(ml);
         const uint32_t oh = __builtin_amdgcn_perm(ph, mh, sel), ol = __builtin_amdgcn_perm(pl, ml, sel);
         const int row = (r & 3) + 8 * (r >> 2);
@@ -225,13 +239,13 @@ __device__ __forceinline__ char* split_store_base(float* dst, size_t n, long img
 }
 template <int PREC>
 __device__ __forceinline__ void store_belu_tile_split(char* base, const f32x16& accm, const f32x16& accx,
-                                                      float bias, float beta, bool odd, int pitch) {
-    store_belu_tile_split_t<false, kPlanar<PREC>>(base, accm, accx, bias, beta, odd, 0, (long)pitch * 64);
+                                                      float bias, float beta, bool odd, int pitch, uint32_t& dom) {
+    store_belu_tile_split_t<false, kPlanar<PREC>>(base, accm, accx, bias, beta, odd, 0, (long)pitch * 64, dom);
 }
 template <int PREC>
 __device__ __forceinline__ void store_belu_tile_split_masked(char* base, const f32x16& accm, const f32x16& accx,
-                                                             float bias, float beta, bool odd, int limit, int pitch) {
-    store_belu_tile_split_t<true, kPlanar<PREC>>(base, accm, accx, bias, beta, odd, limit, (long)pitch * 64);
+                                                             float bias, float beta, bool odd, int limit, int pitch, uint32_t& dom) {
+    store_belu_tile_split_t<true, kPlanar<PREC>>(base, accm, accx, bias, beta, odd, limit, (long)pitch * 64, dom);
 }
 
 // Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`
@@ -282,6 +296,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     __shared__ float s_lut[256];
     if constexpr (IMG_U8) s_lut[tid] = __fdiv_rn((float)tid, 255.0f);
     const float bias = a.bias[i], beta = a.beta[i];
+    uint32_t dom = 0;  // split-half mode: the largest hi half this thread has produced (domain_track)
   for (int bid = blockIdx.x; bid < a.n_tiles; bid += gridDim.x) {
     const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
     const int ty = tile_div(t, a.div_tx), tx = t - ty * a.tiles_x;
@@ -330,7 +345,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
             for (int m = 0; m < T; ++m) {
                 const float* row = xa + (m + ky) * TWH * 3;
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[4 * jj], b.x, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[4 * jj + 2], b.y, acc[m], 0, 0, 0);
+                // (slot 15 -- h = 1 of the row's last MFMA -- is the NEXT pixel's first channel under a zero weight: a true zero instead, or an
+                // Inf / NaN pixel outside the 5x5 footprint would reach this output as 0 x Inf = NaN where the reference has none)
+                const float a2 = (jj == 3 && h) ? 0.0f : row[4 * jj + 2];
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b.y, acc[m], 0, 0, 0);
             }
         }
     }
@@ -358,13 +376,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
             for (int r = 0; r < 16; ++r) zero[r] = 0.f;
             char* base = split_store_base<PREC>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
             if (full_x) {
-                store_belu_tile_split<PREC>(base, am, zero, bias, beta, i & 1, a.pitch);
+                store_belu_tile_split<PREC>(base, am, zero, bias, beta, i & 1, a.pitch, dom);
             } else {
-                store_belu_tile_split_masked<PREC>(base, am, zero, bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch);
+                store_belu_tile_split_masked<PREC>(base, am, zero, bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
             }
         }
     }
   }
+    if constexpr (PREC == 1) domain_report(dom, a.domain);
 }
 
 // ---------------------------------------------------------------------------
@@ -415,6 +434,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
     const char* abase = (const char*)&s_px[0][0] + ((wave * T) * TWH + i) * 8;
     constexpr uint32_t LO = NPIX * 2 * 4;  // bytes from the hi array to the lo array
     const float bias = a.bias[i], beta = a.beta[i];
+    uint32_t dom = 0;  // the largest hi half this thread has produced, inputs included (domain_track)
     for (int bid = blockIdx.x; bid < a.n_tiles; bid += gridDim.x) {
         const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
         const int ty = tile_div(t, a.div_tx), tx = t - ty * a.tiles_x;
@@ -436,6 +456,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
                     const float* q = (const float*)a.img + gp * 3;
                     split_half2(f32x2{q[0], q[1]}, h0, l0);
                     split_half2(f32x2{q[2], 0.0f}, h1, l1);
+                    domain_track(dom, h0);
+                    domain_track(dom, h1);
                 }
             }
             *(uint2*)&s_px[0][p * 2] = make_uint2(h0, h1);
@@ -471,10 +493,11 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
             const int y = y0 + wave * T + m;
             if (y >= a.y_end) continue;
             char* base = split_store_base<1>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
-            if (full_x) store_belu_tile_split<1>(base, accm[m], accx[m], bias, beta, i & 1, a.pitch);
-            else store_belu_tile_split_masked<1>(base, accm[m], accx[m], bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch);
+            if (full_x) store_belu_tile_split<1>(base, accm[m], accx[m], bias, beta, i & 1, a.pitch, dom);
+            else store_belu_tile_split_masked<1>(base, accm[m], accx[m], bias, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
         }
     }
+    domain_report(dom, a.domain);
 }
 
 // ---------------------------------------------------------------------------
@@ -906,7 +929,7 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], char* tile, cha
 // for the final stage, + expand_bias, depth-to-space (Expand, network.rs:39) and optionally the u8 quantiser.
 template <int TH, int T, int NTN, bool FINAL, bool OUT_U8, int PREC, int FACTOR>
 __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)[NTN * T], f32x16 (&accx)[PREC == 1 ? NTN * T : 1],
-                                               const float (&bias)[NTN], float beta, int n, int x0, int y0, int wave, int lane) {
+                                               const float (&bias)[NTN], float beta, int n, int x0, int y0, int wave, int lane, uint32_t& dom) {
     const int i = lane & 31, h = lane >> 5;
     const bool full_x = x0 + kTW <= a.W;
     if constexpr (!FINAL) {
@@ -925,8 +948,8 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
                 }
             } else {
                     char* base = split_store_base<PREC>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
-                if (full_x) store_belu_tile_split<PREC>(base, acc[m], accx[m], bias[0], beta, i & 1, a.pitch);
-                else store_belu_tile_split_masked<PREC>(base, acc[m], accx[m], bias[0], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch);
+                if (full_x) store_belu_tile_split<PREC>(base, acc[m], accx[m], bias[0], beta, i & 1, a.pitch, dom);
+                else store_belu_tile_split_masked<PREC>(base, acc[m], accx[m], bias[0], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
             }
         }
     } else {
@@ -1120,7 +1143,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
     __builtin_amdgcn_s_setprio(3);
     if constexpr (FINAL)
         lin_taps<TH, T, IMG_U8, NW * 64, NTN>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
-    stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
+    uint32_t dom = 0;
+    stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
+    if constexpr (PREC == 1 && !FINAL) domain_report(dom, a.domain);
 }
 
 // ---------------------------------------------------------------------------
@@ -1515,6 +1540,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
 
     int nn = 0, nx0 = 0, ny0 = 0;  // the tile after this one (known from half 1 on)
     bool nsmall_tile = false;
+    uint32_t dom = 0;  // split-half mode: the largest hi half this thread has stored (domain_track)
 
     // One tile: T tile rows per wave (2: an 8-row tile, 1: a 4-row tile in the first rows of the same buffers).
     auto tile_body = [&](auto tc) {
@@ -1584,7 +1610,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
             asm volatile("" ::: "memory");
         }
-        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane);
+        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
     };
 
     int budget = nbig + nsmall;  // no workgroup can be handed more tiles than the launch has: a bound on the loop, whatever happens
@@ -1601,6 +1627,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         }
         n = nn; x0 = nx0; y0 = ny0; small = nsmall_tile;
     }
+    if constexpr (PREC == 1 && !FINAL) domain_report(dom, a.domain);
     // (nothing is in flight towards LDS here: the last tile requested no successor; s_endpgm waits for the stores)
 }
 

@@ -77,6 +77,11 @@ class Engine:
         _lib.check(self._L.sr_set_precision(self._ctx, self.PRECISIONS[precision]))
         self.precision = precision
 
+    def check_domain(self):
+        """sr_check_domain: after the stream of earlier *_dev calls has been synchronised, raises SrError(SR_E_DOMAIN) if one of them
+        left the domain of "split_f16" (a non-finite value, or one of 65504 and beyond); the host-pointer calls recompute in f32 themselves."""
+        _lib.check(self._L.sr_check_domain(self._ctx))
+
     def _out_hw(self, h, w):
         return (h // 3, w // 3) if self.graph == "downsample" else (self.factor * h, self.factor * w)
 

@@ -180,7 +180,7 @@ int main(int argc, char** argv) {
     int rc = SR_OK;
     for (size_t k = 0; k < devices.size() && rc == SR_OK; ++k) {
         rc = sr_create_graph(&ctxs[k], graph, params.empty() ? nullptr : params.data(), params.size(), SR_FACTOR, devices[k]);
-        if (rc == SR_OK && graph == SR_GRAPH_SR_NET) sr_set_precision(ctxs[k], precision == "f32" ? SR_PRECISION_F32 : SR_PRECISION_SPLIT_F16);
+        if (rc == SR_OK && graph == SR_GRAPH_SR_NET) rc = sr_set_precision(ctxs[k], precision == "f32" ? SR_PRECISION_F32 : SR_PRECISION_SPLIT_F16);
     }
     const double t_create = ms_since(t_start);
     double t_prep = 0;
