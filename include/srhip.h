@@ -115,7 +115,7 @@ int sr_upscale_rgba8(sr_ctx* ctx, const uint8_t* in, int in_channels, int n, int
 
 /* Optional: everything the matching sr_upscale_* call of that shape would do EXCEPT touching caller memory -- the
  * workspace and staging allocations, the events, and one pass of its kernels over whatever the staging buffers hold
- * (code objects load, clocks come up).  The first real call then costs what every later one does; a host calls this at
+ * (code objects load, clocks come up) -- and what a sr_upscale_*_dev call of that shape creates on first use (see there).  The first real call then costs what every later one does; a host calls this at
  * start-up, or -- like the CLI -- on one thread while another still decodes the input file.  The reference has no
  * counterpart (alumina allocates inside graph.forward, main.rs:171). */
 int sr_reserve_f32(sr_ctx* ctx, int n, int h, int w);
@@ -141,13 +141,13 @@ int sr_upscale_rgba8_batch_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* 
                                  uint8_t* out_rgba);
 
 /* The host-pointer entry points (sr_upscale_f32 / sr_upscale_rgba8 and their _multi forms) run upload / conv stack / download as a software
- * pipeline on three HIP streams of the context's own (created on first need: a call that is one chunk uses one, the
- * device-pointer entry points none): a batch goes in chunks of whole images, one large sr_net image
- * goes as row bands with SR_HALO halo rows (bit-identical to the undivided pass, see
- * sr_upscale_band_*).  Results do not depend on the setting; 0 = one upload, one pass, one
- * download.  The reference has no counterpart (its tensors never leave host memory,
- * main.rs:168-175); buffers from sr_host_alloc are page-locked, which lets the copies run at
- * PCIe rate and truly overlap -- any host memory is accepted. */
+ * pipeline on up to four HIP streams of the context's own, created on first need (a call that is one chunk uses one): a batch goes in
+ * chunks of whole images, one large sr_net image as row bands with SR_HALO halo rows (bit-identical to the undivided pass, see
+ * sr_upscale_band_*).  Results do not depend on the setting; 0 = one upload, one pass, one download.  The reference has no counterpart
+ * (its tensors never leave host memory, main.rs:168-175); buffers from sr_host_alloc are page-locked, which lets the copies run at
+ * PCIe rate and truly overlap -- any host memory is accepted.
+ * (The device-pointer entry points below run on the CALLER'S stream; where they cut one image into two bands they also use one stream
+ * of the context's own and a second set of feature maps, see there.) */
 int sr_set_pipeline(sr_ctx* ctx, int enabled);         /* default: enabled */
 int sr_host_alloc(void** out, size_t bytes);           /* SR_E_NO_DEVICE without a GPU */
 void sr_host_free(void* p);
@@ -158,7 +158,10 @@ void sr_host_free(void* p);
  * its own producers / consumers of d_in / d_out on that stream.  These are what bench.py times and what the multi-GPU
  * driver calls after its halo exchange.  One image (n = 1) of enough rows may run as TWO row bands, the second on a stream
  * of the context's own that is forked from `stream` and joined back to it by events (one band's launches drain while the
- * other's fill; bit-identical): the call is still asynchronous and ordered on `stream` alone. */
+ * other's fill; bit-identical): the call is still asynchronous and ordered on `stream` alone.  What that costs:
+ * a second set of feature maps (each band's are half the size; should they not fit, the call runs undivided), and -- on its first
+ * use -- one stream creation and the allocations, inside the call (sr_reserve_* of the same shape does both ahead of time).
+ * After such a call sr_read_feature refuses (each workspace holds one band), as it does after a pipelined host call. */
 int sr_upscale_f32_dev(sr_ctx* ctx, const float* d_in, int n, int h, int w, float* d_out,
                        void* stream);
 int sr_upscale_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels, int n, int h, int w,

@@ -282,7 +282,11 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         mark("events");
 
         if (graph != SR_GRAPH_SR_NET) {  // parameter-free graphs: only the quantiser table of their u8 entry points
-            HIPCHK(c, sr_aux_build_tables(&c->d_qtab));
+            const hipError_t te = sr_aux_build_tables(&c->d_qtab);
+            // hipErrorUnknown: the builder's own plausibility checks of the device's powf failed -- no table, the u8 entry points of this
+            // context answer SR_E_HIP (sr_launch_aux), its f32 entry points need none; anything else is a real HIP error
+            if (te != hipSuccess && te != hipErrorUnknown) HIPCHK(c, te);
+            if (te == hipErrorUnknown) { (void)hipGetLastError(); c->last_hip = (int)te; }
             mark("quantiser table");
             return SR_OK;
         }
@@ -590,7 +594,8 @@ int StackJob::prepare() {
         //    split-half mode pays 17 % per 4-row tile (its B operands are re-read per tile row) and keeps 8-row tiles.
         //  conv0 and the first form run one class.
         const long tiles8 = (long)n * tiles_x * ((rows + 7) / 8);
-        const int forced = c->env_th[st];
+        // (the last stage of factor 4 in the split-half mode exists with 4-row tiles only: two N-tiles of accumulators, sr_kernels.hip kBigTiles)
+        const int forced = (st == 4 && c->factor == 4 && c->precision == SR_PRECISION_SPLIT_F16) ? 4 : c->env_th[st];
         const bool small_launch = tiles8 < 2L * resident;
         const bool split = c->precision == SR_PRECISION_SPLIT_F16;
         // (round 4: with the scalar overheads of the pipe form gone it also wins where every workgroup has exactly ONE 4-row tile and the
@@ -750,9 +755,10 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
 // and ~17 us of join / fork between consecutive calls.  Net, with the bands' launches free of 4-row tails: -0.8 ... -3.8 % for
 // exact-f32 images from 3.5 rounds of tiles on, -0.1 % at 3840x2160; a loss in the split-half mode: hence the rule below.  Costs a
 // second set of feature maps (each band's are half the size).
-int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
-                      void* d_out, bool out_u8, hipStream_t s) {
-    if (!c || !d_img || !d_out) return SR_E_INVALID;
+namespace {
+
+// Whether a device call of this shape runs as two bands (the automatic rule or sr_set_experiment("fork")), and the first band's rows.
+bool plan_fork(const sr_ctx* c, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot, int* rows_a_out) {
     const int own = H - halo_top - halo_bot;
     bool fork = c->graph == SR_GRAPH_SR_NET && n == 1 && !c->profiling && c->env_fork != 0 && W > 0 && own >= 4 * SR_HALO &&
                 (!img_u8 || img_ch == 3 || img_ch == 4) &&   // (anything sr_run_stack would refuse is left for it to refuse)
@@ -767,11 +773,7 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
         // image -0.4 %; 960x540 (4.0 rounds) ties.  The split-half mode (tiles of 14 us) loses 0.6-2.4 % (r4_fork_ab_split.jsonl).
         fork = c->precision == SR_PRECISION_F32 && rounds >= c->fork_min_rounds && rounds < c->fork_max_rounds;
     }
-    if (!fork) return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s);
-    sr_device_guard restore_device;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    for (auto& e : c->ev_fork) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!fork) return false;
     // The first band's own rows: near the requested share, at the cut (within +-8 rows of it) that wastes the least matrix work in
     // partly filled tile rows.  Stage s of the first band computes rows_a + margin rows from the band's top, of the second band
     // own - rows_a + margin rows; a remainder of 1-4 rows costs a row of 4-row tiles (0.52 of an 8-row one), 5-7 rows a full one.
@@ -796,6 +798,32 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
         }
         rows_a = best_rows;
     }
+    *rows_a_out = rows_a;
+    return true;
+}
+
+int ensure_fork_resources(sr_ctx* c) {
+    if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    for (auto& e : c->ev_fork) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return SR_OK;
+}
+
+}  // namespace
+
+int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
+                      void* d_out, bool out_u8, hipStream_t s) {
+    if (!c || !d_img || !d_out) return SR_E_INVALID;
+    c->band_pending = false;  // (the event pairs of an earlier sharded call are not this call's: sr_comm.cpp sets the flag again behind its own)
+    const int own = H - halo_top - halo_bot;
+    int rows_a = 0;
+    if (!plan_fork(c, img_u8, img_ch, n, H, W, halo_top, halo_bot, &rows_a))
+        return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s);
+    sr_device_guard restore_device;
+    HIPCHK(c, hipSetDevice(c->device));
+    {
+        const int rc = ensure_fork_resources(c);
+        if (rc != SR_OK) return rc;
+    }
     const int cut = halo_top + rows_a;  // first row of the second band, in the coordinates of the caller's buffer
     const size_t in_px = img_u8 ? (size_t)img_ch : 3 * sizeof(float), out_px = out_u8 ? 4 : 3 * sizeof(float);
     const int f = c->factor;
@@ -810,8 +838,16 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
     b.H = H - (cut - SR_HALO); b.top = SR_HALO; b.bot = b.H - halo_bot;
     HIPCHK(c, hipEventRecord(c->ev_fork[0], s));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork[0], 0));
+    // Both bands are planned (and their workspaces allocated) before anything is launched: should the second set of feature maps not fit,
+    // the undivided pass on the first workspace still may -- the call must not fail for want of an optimisation's memory.
     int rc = a.prepare();
     if (rc == SR_OK) rc = b.prepare();
+    if (rc == SR_E_NOMEM) {
+        for (auto& p : c->ws[1].d_feat) { if (p) (void)hipFree(p); p = nullptr; }
+        c->ws[1].feat_cap_px = 0; c->ws[1].geo_n = 0;
+        (void)hipStreamWaitEvent(s, c->ev_fork[0], 0);
+        return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s);
+    }
     for (int st = 0; st < 5 && rc == SR_OK; ++st) {
         rc = a.launch(st);
         if (rc == SR_OK) rc = b.launch(st);
@@ -822,6 +858,7 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
     if (rc != SR_OK) return rc;
     HIPCHK(c, e1); HIPCHK(c, e2);
     c->last_h = c->last_w = 0;  // each workspace holds one band: sr_read_feature refuses
+    (void)own;
     return SR_OK;
 }
 
@@ -976,6 +1013,7 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     if (c->graph != SR_GRAPH_SR_NET && img_u8 != out_u8) return SR_E_INVALID;
     sr_device_guard restore_device;
     HIPCHK(c, hipSetDevice(c->device));
+    c->band_pending = false;  // (an earlier sharded call's event pairs are not this call's timing)
     const size_t in_px = img_u8 ? (size_t)img_ch : 3 * sizeof(float), out_px = out_u8 ? 4 : 3 * sizeof(float);
     if (y_hi < 0) y_hi = h;
     if (y_lo < 0 || y_hi > h || y_lo >= y_hi) return SR_E_INVALID;
@@ -1155,12 +1193,38 @@ int sr_upscale_band_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, i
                              (hipStream_t)stream);
 }
 
+// ... and what a DEVICE-pointer call of that shape would create on its first use: if it runs as two bands (plan_fork), the second
+// stream, the fork / join events and both workspaces at the bands' geometry -- allocations and a stream creation that would
+// otherwise happen, synchronously, inside the first "asynchronous" sr_upscale_*_dev call after the reserve.
+static int reserve_fork(sr_ctx* c, bool img_u8, int img_ch, int n, int h, int w) {
+    int rows_a = 0;
+    if (!plan_fork(c, img_u8, img_ch, n, h, w, 0, 0, &rows_a)) return SR_OK;
+    sr_device_guard restore_device;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = sr_ensure_streams(c, false);
+    if (rc == SR_OK) rc = ensure_fork_resources(c);
+    if (rc != SR_OK) return rc;
+    StackJob a, b;
+    a.forked = b.forked = true;
+    a.c = b.c = c; a.W = b.W = w; a.img_u8 = b.img_u8 = img_u8; a.img_ch = b.img_ch = img_ch;
+    a.ws = &c->ws[0]; a.s = c->stream; a.H = rows_a + SR_HALO; a.top = 0; a.bot = rows_a;
+    b.ws = &c->ws[1]; b.s = c->stream; b.H = h - (rows_a - SR_HALO); b.top = SR_HALO; b.bot = b.H;
+    rc = a.prepare();
+    if (rc == SR_OK) rc = b.prepare();
+    if (rc == SR_E_NOMEM) return SR_OK;  // the device call will run undivided (sr_run_stack_auto)
+    if (rc != SR_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SR_OK;
+}
+
 int sr_reserve_f32(sr_ctx* c, int n, int h, int w) {
-    return run_host(c, nullptr, false, 3, Deal{0, 1, n}, h, w, nullptr, false, 0, -1, true);
+    const int rc = run_host(c, nullptr, false, 3, Deal{0, 1, n}, h, w, nullptr, false, 0, -1, true);
+    return rc == SR_OK ? reserve_fork(c, false, 3, n, h, w) : rc;
 }
 
 int sr_reserve_rgba8(sr_ctx* c, int in_channels, int n, int h, int w) {
-    return run_host(c, nullptr, true, in_channels, Deal{0, 1, n}, h, w, nullptr, true, 0, -1, true);
+    const int rc = run_host(c, nullptr, true, in_channels, Deal{0, 1, n}, h, w, nullptr, true, 0, -1, true);
+    return rc == SR_OK ? reserve_fork(c, true, in_channels, n, h, w) : rc;
 }
 
 int sr_upscale_f32(sr_ctx* c, const float* in, int n, int h, int w, float* out) {

@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t quant_lookup(const QEntry* tab, float l) {
     // (arithmetic shift: zero, everything below 2^-13 and negative values land at or below 0 -> bucket 0, whose base is 0.  No upper
     // clamp: the u8 entry points interpolate table values in [0, 1] with weights that sum to 1 +- an ulp, so l < 1 + 2^-7 and the
     // index stays within the seven spare entries behind bucket "1.0 and up"; one VALU instruction less on each of 36 lookups per item.)
-    const int idx = max(((int)__float_as_uint(l) >> 16) - (kQExp0 << 7), 0);
+    const int idx = min(max(((int)__float_as_uint(l) >> 16) - (kQExp0 << 7), 0), kQEntries - 1);  // (v_med3_i32: the upper clamp is free)
     const QEntry e = tab[idx];
     return e.base + (l >= e.step ? 1u : 0u);
 }
@@ -383,7 +383,7 @@ hipError_t sr_aux_build_tables(void** d_tab) {
     if (e == hipSuccess) {
         hipLaunchKernelGGL(lut_kernel, dim3(1), dim3(256), 0, nullptr, (float*)((QEntry*)*d_tab + tab.size()));
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // (the launch's own stream: other streams of the process are not waited for)
     }
     if (e != hipSuccess) { (void)hipFree(*d_tab); *d_tab = nullptr; }
     return e;

@@ -1613,10 +1613,19 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
     };
 
+    // The 48 expand channels of factor 4 are two N-tiles: in the split-half mode an 8-row tile body would hold 128 accumulator registers
+    // beside 96 of operands and spill (256 VGPRs + 124 B of scratch in round 4).  That one instantiation therefore has the 4-row body
+    // only; sr_api.cpp plans its launches with 4-row tiles (StackJob::prepare).
+    constexpr bool kBigTiles = !(FINAL && FACTOR == 4 && PREC == 1);
     int budget = nbig + nsmall;  // no workgroup can be handed more tiles than the launch has: a bound on the loop, whatever happens
     while (true) {
-        if (small) tile_body(std::integral_constant<int, 1>{});
-        else tile_body(std::integral_constant<int, 2>{});
+        if constexpr (kBigTiles) {
+            if (small) tile_body(std::integral_constant<int, 1>{});
+            else tile_body(std::integral_constant<int, 2>{});
+        } else {
+            if (!small) __builtin_trap();  // (never planned, see above)
+            tile_body(std::integral_constant<int, 1>{});
+        }
         if (!st.have_next) break;
         if (--budget <= 0) {
             // Unreachable while the queue is consistent.  A successor was announced, so its first half tile and weight chunks are on

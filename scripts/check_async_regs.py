@@ -10,6 +10,14 @@ instructions were issued after it on that path (memory instructions retire in or
 includes it among the retired ones; with a larger N it does not and the walk goes on).  Any instruction on the way that
 names the register as a source is flagged.
 
+A second lint covers the two inline-asm idioms whose correctness depends on instruction ENCODING SIZES (advisor, round 4):
+  * the run-time s_waitcnt table (sr_kernels.hip SR_WAIT_TABLE): `s_getpc_b64 vcc` must be followed by exactly `s_add_u32 vcc_lo, vcc_lo,
+    sN` / `s_addc_u32 vcc_hi, vcc_hi, 0` / `s_setpc_b64 vcc` (three 4-byte encodings: a literal operand or an inserted s_nop would
+    make the +12 in the index wrong) and then sixteen rows `s_waitcnt ...` / `s_branch ...` of 8 bytes each, nothing in between --
+    a jump that lands mid-row would under-wait silently;
+  * every `s_mov_b32 m0, ...` of an LDS-DMA statement must be followed by an s_nop before its global_load_lds (M0 written by the
+    scalar ALU needs a wait state before a memory instruction reads it).
+
     python scripts/check_async_regs.py [file.s]      (without an argument: compiles sr_kernels.hip to assembly, ~90 s)
 Exit status 1 when something is flagged."""
 import os
@@ -114,7 +122,38 @@ def main():
                     if ops[0].startswith(("global_load", "buffer_load", "scratch_load", "flat_load")) and "lds" not in ops[0] and dst in regs_of(ops[1]):
                         break  # the register is given a new value: the old result is dead on this path
     print(f"{checked} asynchronous asm results checked, {bad} read too early")
-    return 1 if bad else 0
+    tables, bad_layout = check_encoded_layouts(lines)
+    print(f"{tables[0]} wait tables and {tables[1]} LDS-DMA m0 writes checked, {bad_layout} with an unexpected layout")
+    return 1 if bad or bad_layout or not tables[0] else 0
+
+
+def check_encoded_layouts(lines):
+    """See the module docstring: the computed jump into the s_waitcnt table, and the wait state behind a write of m0."""
+    code = [(i, l.split(";")[0].strip()) for i, l in enumerate(lines)]
+    code = [(i, t) for i, t in code if t and not t.endswith(":") and not t.startswith((".", "#"))]
+    n_tab = n_m0 = bad = 0
+    for k, (i, t) in enumerate(code):
+        if t.startswith("s_getpc_b64"):
+            n_tab += 1
+            want = [r"s_add_u32 vcc_lo, vcc_lo, s\d+$", r"s_addc_u32 vcc_hi, vcc_hi, 0$", r"s_setpc_b64 vcc$"]
+            for row in range(16):
+                want += [r"s_waitcnt vmcnt\(%d\)( lgkmcnt\(0\))?$" % row, r"s_branch \S+$"]
+            got = [x[1] for x in code[k + 1:k + 1 + len(want)]]
+            ok = t == "s_getpc_b64 vcc" and len(got) == len(want) and all(re.match(w, g) for w, g in zip(want, got))
+            # the index arithmetic in front of it: ... << 3 (8-byte rows), + 12 (the three instructions behind s_getpc)
+            prev = [x[1] for x in code[max(0, k - 4):k]]
+            ok = ok and any(re.match(r"s_lshl_b32 s\d+, s\d+, 3$", x) for x in prev) and any(re.match(r"s_add_u32 s\d+, s\d+, 12$", x) for x in prev)
+            if not ok:
+                print(f"line {i + 1}: the s_waitcnt table behind `{t}` does not have the layout its computed jump assumes")
+                bad += 1
+        if re.match(r"s_mov_b32 m0, ", t):
+            nxt = [x[1] for x in code[k + 1:k + 3]]
+            if nxt and nxt[0].startswith("s_nop") and len(nxt) > 1 and nxt[1].startswith("global_load_lds"):
+                n_m0 += 1
+            elif any(x.startswith("global_load_lds") for x in nxt):
+                print(f"line {i + 1}: `{t}` is not followed by an s_nop before its global_load_lds")
+                bad += 1
+    return (n_tab, n_m0), bad
 
 
 if __name__ == "__main__":

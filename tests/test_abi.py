@@ -173,3 +173,5 @@ def test_async_asm_results_are_not_read_before_their_wait():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_async_regs.py"), asm], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "asynchronous asm results checked, 0 read too early" in res.stdout and not res.stdout.startswith("0 ")
+    # ... and the two idioms that depend on encoding sizes: the computed jump into the s_waitcnt table, the wait state behind an m0 write
+    assert re.search(r"[1-9]\d* wait tables and [1-9]\d* LDS-DMA m0 writes checked, 0 with an unexpected layout", res.stdout), res.stdout

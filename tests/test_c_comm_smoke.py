@@ -36,3 +36,14 @@ def test_comm_smoke_runs(tmp_path):
     assert res.stdout.rstrip().endswith("comm_smoke ok")
     assert "bit-identical" in res.stdout
     assert "config C, 3840x2160 over" in res.stdout and "halo exchange" in res.stdout  # the per-rank numbers a multi-GPU lease should yield
+
+
+def test_first_multigpu_script_is_runnable():
+    """scripts/first_multigpu.sh is what the first multi-GPU lease runs: it must at least parse, and name files that exist."""
+    script = os.path.join(ROOT, "scripts", "first_multigpu.sh")
+    subprocess.check_call(["bash", "-n", script])
+    text = open(script).read()
+    for path in ("tests/c/comm_smoke.c", "tests/test_gpu_multi.py", "bench.py", "rusty_sr_amd/res/imagenet.rsr"):
+        assert path in text and os.path.exists(os.path.join(ROOT, path)), path
+    for test in ("other_devices", "all_devices_with_rccl"):
+        assert test in text and test in open(os.path.join(ROOT, "tests", "test_gpu_multi.py")).read()

@@ -579,3 +579,42 @@ def test_forked_device_call_is_bit_identical(engines):
                 assert same8 and same32, (h, w, top, bot, cut)
     finally:
         eng.set_experiment("fork", "")
+
+
+def test_reference_image_pins_through_the_gpu(engines, params):
+    """The docs images the reference ships, fed to the ENGINE (tests/test_oracle_golden.py holds the same pins for the oracle, so
+    that no fixture is seen by the oracle alone): `-p bilinear` against logo_lin.png (made by an older alumina whose data_to_img
+    truncated: compared with a truncating quantiser, mismatches only at flat-region knife-edges), and imagenet.rsr on the 43 x 43
+    logo and the butterfly against logo_rs.png / butterfly_rs.png (an earlier weight snapshot: sanity floors, as SURVEY.md 4 says)."""
+    import rusty_sr_amd as r
+    src = load_png("logo_nn.png")[1::3, 1::3]
+    assert src.shape[:2] == (43, 43)
+    # LinearInterp alignment + sRGB transfer (network.rs:111-123), f32 entry point of the bilinear graph
+    bl = r.bilinear_net(r.FACTOR)
+    v = bl.upscale_f32(oracle.img_to_data(src)[None])[0].astype(np.float64)
+    gold = load_png("logo_lin.png")[..., :3].astype(int)
+    d = np.clip(np.floor(255 * v), 0, 255).astype(int) - gold
+    frac = 255 * v
+    # The old quantiser cut at the integers, and on the logo's flat areas 255 v IS an integer up to rounding noise: whether a sample
+    # reads k or k - 1 there is the sign of that noise (the oracle's f32 leg: 95 % equal, its f64 leg 99 %; the engine's v_log_f32 /
+    # v_exp_f32 pow: 87 %).  What pins LinearInterp's alignment and the transfer curve is that EVERY sample lies in the interval the
+    # golden byte stands for, give or take that noise -- and that every mismatch sits on such a knife-edge.
+    assert ((frac >= gold - 1e-3) & (frac < gold + 1 + 1e-3)).all()
+    assert np.abs(d).max() <= 1 and (d == 0).mean() >= 0.80
+    assert np.abs(frac - np.round(frac))[d != 0].max() < 1e-3
+    # ... and its u8 entry point (rounding quantiser) agrees with rounding the same values
+    got8 = bl.upscale_rgba8(src[None])[0]
+    want8 = np.clip(np.floor(255 * v + 0.5), 0, 255).astype(int)
+    d8 = got8[..., :3].astype(int) - want8
+    assert np.abs(d8).max() <= 1 and (d8 != 0).mean() < 1e-3
+    # sr_net with imagenet.rsr, both arithmetic modes (the fixture)
+    out = engines["imagenet"].upscale_rgba8(src[None])[0]
+    gold = load_png("logo_rs.png")
+    assert out.shape == gold.shape
+    assert (out[..., :3] == gold[..., :3]).mean() >= 0.80
+    assert np.abs(out[..., :3].astype(int) - gold[..., :3].astype(int)).max() <= 5
+    out = engines["imagenet"].upscale_rgba8(load_png("butterfly_lr.png"))
+    gold = load_png("butterfly_rs.png")
+    mse = np.mean((out[..., :3].astype(float) - gold[..., :3].astype(float)) ** 2)
+    assert 10 * np.log10(255 ** 2 / mse) >= 55.0
+    assert (out[..., :3] == gold[..., :3]).mean() >= 0.80 and np.abs(out[..., :3].astype(int) - gold[..., :3].astype(int)).max() <= 5
