@@ -47,18 +47,22 @@ __device__ __forceinline__ float fast_pow(float x, float p) { return __builtin_a
 __device__ __forceinline__ float srgb_to_linear_fast(float s) { return s <= 0.04045f ? s / 12.92f : fast_pow((s + 0.055f) / 1.055f, 2.4f); }
 __device__ __forceinline__ float linear_to_srgb_fast(float l) { return l <= 0.0031308f ? 12.92f * l : 1.055f * fast_pow(l, 1.0f / 2.4f) - 0.055f; }
 
-// ---- quantiser table: byte = base + (l >= step) for the bucket of l
+// ---- quantiser table: byte = base + (l >= step) for the bucket of l, one DWORD per bucket.
+// A bucket is the set of floats that share their top 16 bits, so a step inside it is known by its low 16 bits, and
+//     entry = base * 2^16 + (0x10000 - step_low16)        (no step in the bucket: base * 2^16)
+//     byte  = (entry + (bits(l) & 0xffff)) >> 16          (the carry out of the low half is the comparison)
+// Entry 0 serves everything below 2^-13 (zero, negative values: byte 0), the last entry everything from 1.0 up (and NaN: 255).
+// Rounds 1-4 kept (step, base) as 8 bytes: 64 random buckets per wave then fall on 32 bank pairs, and two thirds of the LDS array's
+// busy time in the u8 bilinear kernel were bank conflicts (profiles/r4_aux_pmc.txt); a dword entry spreads them over all 64 banks with
+// the same single LDS instruction per look-up (round 4's split into two dword arrays needed two: slower).
 constexpr int kQExp0 = 114;                       // biased exponent of 2^-13: below it every l quantises to 0
-constexpr int kQBuckets = (127 - kQExp0) * 128;   // [2^-13, 1) in 128 buckets per octave; entry kQBuckets: l >= 1 -> 255
-constexpr int kQEntries = kQBuckets + 8;          // ... and seven more of the same: the index has no upper clamp (see quant_lookup)
-struct QEntry { float step; uint32_t base; };
+constexpr int kQBuckets = (127 - kQExp0) * 128;   // [2^-13, 1) in 128 buckets per octave
+constexpr int kQEntries = kQBuckets + 2;          // + entry 0 (below the range) + the last entry (1.0 and up)
+typedef uint32_t QEntry;
 __device__ __forceinline__ uint32_t quant_lookup(const QEntry* tab, float l) {
-    // (arithmetic shift: zero, everything below 2^-13 and negative values land at or below 0 -> bucket 0, whose base is 0.  No upper
-    // clamp: the u8 entry points interpolate table values in [0, 1] with weights that sum to 1 +- an ulp, so l < 1 + 2^-7 and the
-    // index stays within the seven spare entries behind bucket "1.0 and up"; one VALU instruction less on each of 36 lookups per item.)
-    const int idx = min(max(((int)__float_as_uint(l) >> 16) - (kQExp0 << 7), 0), kQEntries - 1);  // (v_med3_i32: the upper clamp is free)
-    const QEntry e = tab[idx];
-    return e.base + (l >= e.step ? 1u : 0u);
+    const uint32_t bits = __float_as_uint(l);
+    const int idx = min(max(((int)bits >> 16) - (kQExp0 << 7) + 1, 0), kQEntries - 1);  // (arithmetic shift: negative values land below 0)
+    return (tab[idx] + (bits & 0xffffu)) >> 16;
 }
 
 // (Round 4 also tried the opposite balance -- estimate 255 LinearToSrgb(l) + 0.5 with v_log_f32 / v_exp_f32 and ask the table only
@@ -66,7 +70,7 @@ __device__ __forceinline__ uint32_t quant_lookup(const QEntry* tab, float l) {
 // pixel's channels alike (profiles/r4_aux_quantiser_estimate_first.txt).  The look-ups' bank conflicts cost less than 14 more vector
 // instructions per sample.  Likewise the table as two dword arrays (64 consecutive buckets over 64 banks instead of 32 over the 32
 // bank pairs of 8-byte entries): 39 us, profiles/r4_aux_quantiser_split_table.txt -- two LDS instructions per look-up cost more than
-// the conflicts they avoid.)
+// the conflicts they avoid.  Round 5: ONE dword per bucket, above.)
 
 // smallest float l in [0, 1] with quant_u8(linear_to_srgb(l)) >= k, for k = 1 .. 255 (thread k - 1): bisection over
 // the bit patterns (non-negative floats order like their bits), then a short downward scan in case the powf is not
@@ -109,7 +113,7 @@ template <bool IMG_U8, bool OUT_U8, bool ALIGNED>
 __global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
     __shared__ __attribute__((aligned(16))) float s_lin[kBlNPIX * 4];
     __shared__ float s_lut[IMG_U8 ? 256 : 1];
-    __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQEntries : 1];
+    __shared__ QEntry s_q[OUT_U8 ? kQEntries : 1];
     const int tid = threadIdx.x;
     if constexpr (IMG_U8) s_lut[tid] = ((const float*)((const QEntry*)a.qtab + kQEntries))[tid];  // SrgbToLinear(byte / 255): lut_kernel
     if constexpr (OUT_U8) {
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
     constexpr int ROW_BYTES = 3 * kDsTW * (IMG_U8 ? 4 : 12) + 16;   // a staged row segment (u8: up to 4 channels), + misalignment slack
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[3 * kDsTH * (ROW_BYTES / 4)];
     __shared__ float s_lut[IMG_U8 ? 256 : 1];
-    __shared__ __attribute__((aligned(8))) QEntry s_q[OUT_U8 ? kQEntries : 1];
+    __shared__ QEntry s_q[OUT_U8 ? kQEntries : 1];
     const int tid = threadIdx.x;
     if constexpr (IMG_U8) s_lut[tid] = ((const float*)((const QEntry*)a.qtab + kQEntries))[tid];
     if constexpr (OUT_U8) {
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
 }  // namespace
 
 // The quantiser table of a context of one of these graphs (sr_create_graph): 255 step positions from the device's own
-// powf, laid out by bucket on the host.  *d_tab: kQEntries entries of 8 bytes, then the 256 floats of the input table
+// powf, laid out by bucket on the host.  *d_tab: kQEntries dword entries, then the 256 floats of the input table
 // (lut_kernel), in device memory (hipFree'd by sr_destroy).
 hipError_t sr_aux_build_tables(void** d_tab) {
     *d_tab = nullptr;
@@ -356,26 +360,31 @@ hipError_t sr_aux_build_tables(void** d_tab) {
     (void)hipFree(d_steps);
     if (e != hipSuccess) return e;
     std::vector<QEntry> tab(kQEntries);
-    auto bucket_lo = [](int idx) {  // smallest float of bucket idx
-        const uint32_t bits = ((uint32_t)(kQExp0 << 7) + (uint32_t)idx) << 16;
+    auto bucket_lo = [](int b) {  // smallest float of bucket b (0 .. kQBuckets: the last is 1.0)
+        const uint32_t bits = ((uint32_t)(kQExp0 << 7) + (uint32_t)b) << 16;
         float f;
         memcpy(&f, &bits, 4);
         return f;
     };
     // byte(l) = #{k : steps[k] <= l}.  For a bucket [lo, hi): base = #{steps < lo}; the one step inside it (lo <= step < hi), if any,
-    // is the entry's `step`.  Bucket 0 also serves every l below 2^-13, the last bucket every l from 1.0 up.
+    // enters with its low 16 bits.  Entry 0: every l below 2^-13; entry kQBuckets + 1: every l from 1.0 up.
     for (int i = 1; i < 255; ++i)
         if (!(steps[i] > steps[i - 1])) return hipErrorUnknown;
+    if (steps[0] < bucket_lo(0) || !(steps[254] < 1.0f)) return hipErrorUnknown;  // a step outside [2^-13, 1): the layout does not hold
+    tab[0] = 0;
+    tab[kQEntries - 1] = 255u << 16;
     int k = 0;
-    for (int idx = 0; idx < kQEntries; ++idx) {
-        const float lo = idx > 0 ? bucket_lo(std::min(idx, kQBuckets)) : -INFINITY, hi = idx < kQBuckets ? bucket_lo(idx + 1) : INFINITY;
+    for (int b = 0; b < kQBuckets; ++b) {
+        const float lo = bucket_lo(b), hi = bucket_lo(b + 1);
         while (k < 255 && steps[k] < lo) ++k;
-        tab[idx].base = (uint32_t)k;
-        tab[idx].step = INFINITY;
+        uint32_t e = (uint32_t)k << 16;
         if (k < 255 && steps[k] < hi) {
-            tab[idx].step = steps[k];
+            uint32_t sb;
+            memcpy(&sb, &steps[k], 4);
+            e += 0x10000u - (sb & 0xffffu);
             if (k + 1 < 255 && steps[k + 1] < hi) return hipErrorUnknown;  // two steps in one bucket: cannot happen (see the header)
         }
+        tab[b + 1] = e;
     }
     e = hipMalloc(d_tab, tab.size() * sizeof(QEntry) + 256 * sizeof(float));
     if (e != hipSuccess) return e;
