@@ -109,6 +109,36 @@ void pack_steps(std::vector<float>& dst, const float* w, int ks, int ntn, bool s
             }
 }
 
+// Split-half weight chunks of stages 1-3 for the 16x16x32 step loop (sr_kernels.hip half_steps_h16): one 4 KB chunk per STEP,
+//   [hi | lo][output-channel half 2][lane 64][8 halves],  lane = 16 g + n:  output channel 16 ch + n,  K block g: taps[g >> 1],
+//   input channels 16 half + 8 (g & 1) + e  -- a step's K = 32 is two taps x the half's 16 channels.
+// Taps run column by column (t = kx * ks + ky, as in the 32x32x16 split loop).  Steps of one source: the first half's tap pairs
+// (0,1) (2,3) ..., then ONE step shared by the two halves' odd last tap (K 0-15: first half, K 16-31: second half), then the second
+// half's pairs: ks^2 steps per source, none half empty.
+void pack_steps_h16(std::vector<float>& dst, const float* w, int ks) {
+    const int nt = ks * ks, np = (nt - 1) / 2;
+    auto chunk = [&](int tap_a, int half_a, int tap_b, int half_b) {
+        const size_t base = dst.size();
+        dst.resize(base + kChunk, 0.0f);
+        _Float16* hp = (_Float16*)(dst.data() + base);
+        for (int ch = 0; ch < 2; ++ch)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int g = lane >> 4, o = 16 * ch + (lane & 15);
+                const int t = (g >> 1) ? tap_b : tap_a, half = (g >> 1) ? half_b : half_a;
+                const int tap = (t % ks) * ks + t / ks;  // column-major walk -> [ky][kx] index of w ([O][ks][ks][32])
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 hi, lo;
+                    split_half_host(w[((size_t)o * nt + tap) * 32 + 16 * half + 8 * (g & 1) + e], hi, lo);
+                    hp[(ch * 64 + lane) * 8 + e] = hi;
+                    hp[1024 + (ch * 64 + lane) * 8 + e] = lo;
+                }
+            }
+    };
+    for (int p = 0; p < np; ++p) chunk(2 * p, 0, 2 * p + 1, 0);
+    chunk(nt - 1, 0, nt - 1, 1);
+    for (int p = 0; p < np; ++p) chunk(2 * p, 1, 2 * p + 1, 1);
+}
+
 // conv0 [32][5][5][3]: K packed per kernel row -- slot k = 3 kx + c (15 used of 16) -- as
 // [ky 5][jj 4][h 2][o 32][e 2] with k = 2 (2 jj + e) + h  (conv0_kernel: B[k][o] for MFMA j = 2 jj + e).
 void pack_conv0(std::vector<float>& dst, const float* w) {
@@ -311,7 +341,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         for (int split = 0; split < 2; ++split) {  // exact-f32 chunks, then the same stages in split-half form
             auto ident = [](int, int j) { return j; };
             auto expand = [&](int nt, int j) { return expand_channel(factor, nt, j); };
-            auto conv = [&](const float* wp, int ks) { pack_steps(w, wp, ks, 1, split != 0, ident); };
+            const bool h16 = split && sr_split_stages_mfma16();  // stages 1-3 of the split-half mode on 16x16x32 MFMAs: their own step order
+            auto conv = [&](const float* wp, int ks) { if (h16) pack_steps_h16(w, wp, ks); else pack_steps(w, wp, ks, 1, split != 0, ident); };
             auto exp3 = [&](const float* wp) { pack_steps(w, wp, 3, expand_tiles(factor), split != 0, expand); };
             size_t* off = split ? c->off_wh : c->off_w;
             w.clear(); conv(params + L.conv1, 5);

@@ -109,6 +109,9 @@ hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s);
 // Layout of the split-half mode's maps: true = row-planar, [y][16-byte channel group c][x] (pixel (0,0) of group c sits
 // (kFeatPad * pitch) * 128 + c * pitch * 16 + kFeatPad * 16 bytes into the map); false = pixel-major like the exact-f32 maps.
 bool sr_split_maps_planar();
+// Step order / operand layout of the split-half weight chunks of stages 1-3: true = v_mfma_f32_16x16x32_f16 (sr_kernels.hip
+// half_steps_h16; sr_api.cpp pack_steps_h16), false = 32x32x16 like the last stage (pack_steps).
+bool sr_split_stages_mfma16();
 
 struct AuxArgs {          // bilinear_net / downsample_net (parameter-free graphs)
     const void* img;      // n*H*W*3 f32 or n*H*W*img_ch u8

@@ -76,6 +76,15 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #endif
 template <int PREC>
 constexpr bool kPlanar = PREC == 1 && SR_SPLIT_PLANAR != 0;
+// Stages 1-3 of the split-half mode run their products on v_mfma_f32_16x16x32_f16 (half_steps_h16 below) instead of 32x32x16: the same
+// FLOPs per cycle, but 17 % more of them per watt -- a stream of random operands sustains 2 090 TFLOP/s in that shape against 1 780 in
+// the other at the board's 1.37 kW (profiles/r5_ubench_split_floor.txt), and this mode is bound by exactly that.  The last stage
+// (whose residual taps and depth-to-space epilogue are written for 32x32 accumulators) keeps half_steps_h.
+#ifndef SR_SPLIT_MFMA16
+#define SR_SPLIT_MFMA16 1
+#endif
+template <int PREC, bool FINAL>
+constexpr bool kH16 = PREC == 1 && !FINAL && SR_SPLIT_MFMA16 != 0 && SR_SPLIT_PLANAR != 0;
 
 namespace {
 
@@ -229,6 +238,30 @@ __device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16
         }
     }
 }
+// The same for the 16x16 accumulators of half_steps_h16: one f32x4 = output channel (lane & 15) of its channel half for the four pixels
+// 4 (lane >> 4) + r of its pixel half.  `base`: the lane's first pixel (even lanes) or second (odd lanes) in the row of the channel
+// group, dword ((lane & 7) >> 1) of the 16-byte cell; row-planar maps only.  limit: image columns from that pixel on (MASKED).
+template <bool MASKED>
+__device__ __forceinline__ void store_belu_quad_split(char* base, const f32x4& accm, const f32x4& accx, float bias, float beta, bool odd,
+                                                      int limit, long lo_off, uint32_t& dom) {
+    const uint32_t sel = odd ? 0x03020706u : 0x05040100u;  // (see store_belu_tile_split_t)
+    const f32x2 bb = {bias, bias}, ks = {1.0f / kLoScale, 1.0f / kLoScale};
+    char* base_lo = base + lo_off;
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+        const f32x2 v = belu2(f32x2{accm[r], accm[r + 1]} + f32x2{accx[r], accx[r + 1]} * ks + bb, beta);
+        uint32_t mh, ml;
+        split_half2(v, mh, ml);
+        domain_track(dom, mh);
+        const uint32_t ph = swap_lane_pair(mh), pl = swap_lane_pair(ml);
+        const uint32_t oh = __builtin_amdgcn_perm(ph, mh, sel), ol = __builtin_amdgcn_perm(pl, ml, sel);
+        if (!MASKED || r < limit) {
+            *(uint32_t*)(base + r * 16) = oh;
+            *(uint32_t*)(base_lo + r * 16) = ol;
+        }
+    }
+}
+
 // Where lane i (channel pair (i & ~1, i | 1)) of pixel-row group h writes: the address of pixel x = x0 + 4 h + (i & 1) of map row y.
 template <int PREC>
 __device__ __forceinline__ char* split_store_base(float* dst, size_t n, long img_stride, long y, int pitch, int x, int i) {
@@ -843,6 +876,94 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
     }
 }
 
+// The split-half step loop on v_mfma_f32_16x16x32_f16 (kH16).  M = 16 pixels, N = 16 output channels, K = 32 = TWO TAPS x the half's 16
+// input channels: lanes 0-31 hold the step's first tap (lanes 0-15 channels 0-7 = hi plane 0, lanes 16-31 channels 8-15 = plane 1),
+// lanes 32-63 its second tap -- the per-lane LDS base carries the distance between the two taps' pixels, every read is still one
+// ds_read_b128 at an immediate offset.  A wave's 32 x 32 output tile row is 2 pixel halves x 2 channel halves, each product 3 MFMAs of
+// 16 cycles: 24 per step and tile row pair, the matrix cycles of the 12 it replaces; 12 operand reads per step as before.
+// A half has an ODD number of taps (25, 9).  Leaving one K half of the last MFMA group empty would waste 4-10 % of the matrix work,
+// so the lone last tap of BOTH halves of a source shares one step: the second half BEGINS with it, lanes 0-31 reading the first half's
+// buffer (XD bytes from its own), lanes 32-63 its own.  The first half is pairs only.  Steps per source: 12 + 13 (5x5), 4 + 5 (3x3)
+// -- 43 per stage-3 tile instead of 46 with three half steps gone.  The weight chunks are packed in this step order (sr_api.cpp
+// pack_steps_h16): [hi | lo][channel half 2][lane 64][8 halves], still 4 KB per step.
+// The first half's buffer must therefore survive the second half's first step: the gather pieces of the NEXT half tile (which land
+// there) are requested from the second step on, three per step in a short (3x3) half so that they still have two steps to land.
+template <int TWH, int PS, int LO, int KS, int T, bool SECOND, int XD, typename Stream>
+__device__ __forceinline__ void half_steps_h16(f32x4 (&accm)[T][2][2], f32x4 (&accx)[T][2][2], const char* hb, const char* ring, Stream& sm,
+                                               int wave, int lane) {
+    constexpr int NT = KS * KS, NP = (NT - 1) / 2;  // tap pairs of a half
+    constexpr int NS = NP + (SECOND ? 1 : 0);       // its steps
+    const int p16 = lane & 15, g = lane >> 4, tsel = g >> 1;
+    const char* base_s = hb + (g & 1) * PS + ((wave * T) * TWH + p16) * 16;
+    const char* base_v = base_s + tsel * (TWH * 16);                       // the pair's second tap is the next kernel row of the same column,
+    const char* base_c = base_s + tsel * (16 - (KS - 1) * TWH * 16);       // ... or the first row of the next column,
+    const char* base_x = base_s + (tsel ? 0 : XD);                         // ... or (shared step) the same tap of the other half's buffer
+    const char* wl = ring + lane * 16;
+    struct Ops { f16x8 bh[2], bl[2], ah[T][2], al[T][2]; };
+    constexpr int NI = 4 + 4 * T, NM = 12 * T;  // operand reads / MFMAs of a step
+    auto first_tap = [](int st) { return SECOND ? (st == 0 ? NT - 1 : 2 * (st - 1)) : 2 * st; };
+    auto load_item = [&](Ops& o, int st, int sl, int k) {
+        if (k < 4) {
+            const char* w = wl + sl * 4096 + (k >> 1) * 1024;
+            if (k & 1) o.bl[k >> 1] = *(const f16x8*)(w + 2048); else o.bh[k >> 1] = *(const f16x8*)w;
+            return;
+        }
+        const int kk = k - 4, m = kk >> 2, ph = (kk >> 1) & 1;
+        const bool lo = kk & 1, shared = SECOND && st == 0;
+        const int ta = first_tap(st), kx = ta / KS, ky = ta - kx * KS;
+        const char* b = shared ? base_x : (ky == KS - 1 ? base_c : base_v);
+        const char* ab = b + ((ky + m) * TWH + kx + 16 * ph) * 16 + (lo ? LO * PS : 0);
+        if (lo) o.al[m][ph] = *(const f16x8*)ab; else o.ah[m][ph] = *(const f16x8*)ab;
+    };
+    Ops cur, nxt;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) load_item(cur, 0, sm.slot(), k);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const bool last = st == NS - 1;
+        const int sln = sm.slot() == kRingSlots - 1 ? 0 : sm.slot() + 1;
+        // gather pieces of the half tile requested meanwhile: two per step (three in a 3x3 half), none in the shared step
+        constexpr int PPS = KS == 3 ? 3 : 2;
+        const int ps = SECOND ? st - 1 : st;  // piece slot of this step (< 0: none)
+        int q = 0;  // MFMAs issued so far in this step
+        auto after_mfma = [&]() {
+            if (q == 0) sm.begin_step();
+#pragma unroll
+            for (int k = 0; k < NI; ++k)
+                if (!last && k >= q * NI / NM && k < (q + 1) * NI / NM) load_item(nxt, st + 1, sln, k);
+            if (ps >= 0) {
+#pragma unroll
+                for (int pc = 0; pc < PPS; ++pc)
+                    if (q == (pc + 1) * NM / (PPS + 1) - 1) sm.piece(PPS * ps + pc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ++q;
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        // every accumulator is touched once per product round: 4 T independent MFMAs between two on the same registers
+#pragma unroll
+        for (int m = 0; m < T; ++m)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) { accm[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.ah[m][ph], cur.bh[ch], accm[m][ph][ch], 0, 0, 0); after_mfma(); }
+#pragma unroll
+        for (int m = 0; m < T; ++m)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) { accx[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.ah[m][ph], cur.bl[ch], accx[m][ph][ch], 0, 0, 0); after_mfma(); }
+#pragma unroll
+        for (int m = 0; m < T; ++m)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) { accx[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.al[m][ph], cur.bh[ch], accx[m][ph][ch], 0, 0, 0); after_mfma(); }
+        sm.template end_step<1>(last);
+        cur = nxt;
+    }
+}
+
 // Stream of the first kernel form: the whole tile is resident, chunks come through the ring in step order.
 struct RingStream {
     char* ring;
@@ -868,6 +989,16 @@ __device__ __forceinline__ void source_steps(f32x16 (&acc)[NTN * T], f32x16 (&ac
         if constexpr (PREC == 0) half_steps_f32<G::TWH, G::PLANE, KS, T, NTN>(acc, tile + half * 4 * G::PLANE, ring, sm, wave, lane);
         else half_steps_h<G::TWH, G::PLANE, 4, KS, T, NTN>(acc, accx, tile + half * 2 * G::PLANE, ring, sm, wave, lane);
     }
+}
+
+// ... and on 16x16 accumulators (kH16): first half pairs only, second half led by the step the two halves share
+template <int TH, int KS, int T>
+__device__ __forceinline__ void source_steps_h16(f32x4 (&accm)[T][2][2], f32x4 (&accx)[T][2][2], const char* tile, char* ring,
+                                                 const float* __restrict__ wpack, int& gtap, int& slot, int ntotal, int wave, int lane) {
+    using G = TileGeom<TH, KS>;
+    RingStream sm{ring, wpack, gtap, slot, ntotal, wave, lane};
+    half_steps_h16<G::TWH, G::PLANE, 4, KS, T, false, 0>(accm, accx, tile, ring, sm, wave, lane);
+    half_steps_h16<G::TWH, G::PLANE, 4, KS, T, true, -2 * G::PLANE>(accm, accx, tile + 2 * G::PLANE, ring, sm, wave, lane);
 }
 
 // The nine fixed-weight taps of the bilinear residual on a staged image tile s_x ([pixel][4] f32, edge-replicated)
@@ -1040,6 +1171,32 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
     }
 }
 
+// ... of a tile computed on 16x16 accumulators (kH16; row-planar split-half map): lane l holds output channel 16 ch + (l & 15) for the
+// pixels 16 ph + 4 (l >> 4) + (0..3) of tile row m.
+template <int T>
+__device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&accm)[T][2][2], f32x4 (&accx)[T][2][2], const float (&bias)[2],
+                                                   const float (&beta)[2], int n, int x0, int y0, int wave, int lane, uint32_t& dom) {
+    const int c16 = lane & 15, g = lane >> 4;
+    const bool full_x = x0 + kTW <= a.W;
+    const long lo_off = (long)a.pitch * 64;  // the lo group's row: four channel groups further on
+#pragma unroll
+    for (int m = 0; m < T; ++m) {
+        const int y = y0 + wave * T + m;
+        if (y >= a.y_end) continue;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            // channel group 2 ch + (c16 >> 3), dword (c16 & 7) >> 1 of its 16-byte cell; even lanes store the pair's first pixel, odd lanes its second
+            char* row = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch) * 32) + (size_t)(2 * ch + (c16 >> 3)) * a.pitch * 16 + ((c16 & 7) >> 1) * 4;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int x = x0 + 16 * ph + 4 * g + (c16 & 1);
+                if (full_x) store_belu_quad_split<false>(row + (long)x * 16, accm[m][ph][ch], accx[m][ph][ch], bias[ch], beta[ch], c16 & 1, 0, lo_off, dom);
+                else store_belu_quad_split<true>(row + (long)x * 16, accm[m][ph][ch], accx[m][ph][ch], bias[ch], beta[ch], c16 & 1, a.W - x, lo_off, dom);
+            }
+        }
+    }
+}
+
 // Dynamic tile queue of the persistent forms.  A launch has `nbig` 8-row tiles and `nsmall` 4-row tiles (either may be
 // 0).  Each class is cut into 8 contiguous runs, one per XCD (the dispatcher places block b on XCD b % 8: neighbouring
 // tiles share halo rows in that XCD's L2); an XCD's queue is its run of big tiles followed by its run of small ones, with
@@ -1091,7 +1248,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31;
-    constexpr int NTAPS = 2 * ((KS0 * KS0 + 1) / 2 + (NSRC - 1) * 5) * NTN;  // ring chunks: one per (step, N-tile), see half_steps_*
+    constexpr bool H16 = kH16<PREC, FINAL>;  // stages 1-3 of the split-half mode: 16x16x32 MFMAs, no half steps (half_steps_h16)
+    constexpr int NTAPS = H16 ? KS0 * KS0 + (NSRC - 1) * 9
+                              : 2 * ((KS0 * KS0 + 1) / 2 + (NSRC - 1) * 5) * NTN;  // ring chunks: one per (step, N-tile), see half_steps_*
     const TileGrid& grid = a.grid[TH == 8 ? 0 : 1];  // this form runs one tile class per launch
     float bias[NTN];
 #pragma unroll
@@ -1118,10 +1277,18 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
             acc[m][r] = 0.f;
             if constexpr (PREC == 1) accx[m][r] = 0.f;
         }
+    f32x4 qm[H16 ? T : 1][2][2], qx[H16 ? T : 1][2][2];  // ... or, kH16, the same tile as 16x16 accumulators
+    if constexpr (H16) {
+#pragma unroll
+        for (int m = 0; m < T; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { qm[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; qx[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
     int gtap = 0, slot = 0;
     auto taps = [&](auto ks_tag) {
         constexpr int KS = decltype(ks_tag)::value;
-        source_steps<TH, KS, T, NTN, PREC>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+        if constexpr (H16) source_steps_h16<TH, KS, T>(qm, qx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
+        else source_steps<TH, KS, T, NTN, PREC>(acc, accx, tile, ring, a.wpack, gtap, slot, NTAPS, wave, lane);
     };
     ring_barrier<0>();  // every wave's tile + weight DMAs have landed
     __builtin_amdgcn_s_setprio(0);
@@ -1144,7 +1311,12 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
     if constexpr (FINAL)
         lin_taps<TH, T, IMG_U8, NW * 64, NTN>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
     uint32_t dom = 0;
-    stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
+    if constexpr (H16) {
+        const float bias2[2] = {a.bias[lane & 15], a.bias[16 + (lane & 15)]}, beta2[2] = {a.beta[lane & 15], a.beta[16 + (lane & 15)]};
+        stage_epilogue_h16<T>(a, qm, qx, bias2, beta2, n, x0, y0, wave, lane, dom);
+    } else {
+        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
+    }
     if constexpr (PREC == 1 && !FINAL) domain_report(dom, a.domain);
 }
 
@@ -1468,7 +1640,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     using H3 = HalfTile<3>;
     constexpr int HB = H0::BYTES;  // KS0 >= 3: the first source has the largest half tile
     constexpr int NH = 2 * NSRC;
-    constexpr int NSTEPS = 2 * (H0::STEPS + (NSRC - 1) * H3::STEPS) * NTN;  // weight chunks per tile: one per (step, N-tile)
+    constexpr bool H16 = kH16<PREC, FINAL>;  // stages 1-3 of the split-half mode: 16x16x32 MFMAs, a source's halves share their odd tap's step
+    constexpr int NSTEPS = H16 ? KS0 * KS0 + (NSRC - 1) * 9
+                               : 2 * (H0::STEPS + (NSRC - 1) * H3::STEPS) * NTN;  // weight chunks per tile: one per (step, N-tile)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem + 2 * HB;
     volatile int* s_next = (volatile int*)(ring + kRingBytes);
@@ -1487,6 +1661,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NTN; ++nt) bias[nt] = a.bias[nt * 32 + i];
     const float beta = FINAL ? 0.f : a.beta[i];
+    // (kH16: lane l holds output channels (l & 15) and 16 + (l & 15))
+    const float bias2[2] = {H16 ? a.bias[lane & 15] : 0.f, H16 ? a.bias[16 + (lane & 15)] : 0.f};
+    const float beta2[2] = {H16 ? a.beta[lane & 15] : 0.f, H16 ? a.beta[16 + (lane & 15)] : 0.f};
     H0 h0;
     H3 h3;
     h0.template init<PREC>(a.pitch, lane);
@@ -1554,6 +1731,13 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
                 acc[m][r] = 0.f;
                 if constexpr (PREC == 1) accx[m][r] = 0.f;
             }
+        f32x4 qm[H16 ? T : 1][2][2], qx[H16 ? T : 1][2][2];  // kH16: the same tile as 16x16 accumulators
+        if constexpr (H16) {
+#pragma unroll
+            for (int m = 0; m < T; ++m)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { qm[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; qx[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
         // (local to the tile ON PURPOSE: the registers the asynchronous atomic / load return into must not be live across the
         // tile loop's merge of the two tile bodies -- the compiler then copies them right after the asm statement, i.e. before
         // the data has arrived; it cannot know these asm outputs land later)
@@ -1588,10 +1772,14 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             const HalfTile<KSN>* htn;
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
             using GJ = TileGeom<8, KSJ>;
-            constexpr int STEPS_J = HalfTile<KSJ>::STEPS * NTN;
-            constexpr int GS0 = (j == 0 ? 0 : j == 1 ? H0::STEPS : 2 * H0::STEPS + (j - 2) * H3::STEPS) * NTN;  // steps of the halves before this one
+            // steps of this half / of the halves before it (kH16: a source's first half is its tap pairs, the second one step more)
+            constexpr int PAIRS_J = (KSJ * KSJ - 1) / 2;
+            constexpr int STEPS_J = H16 ? PAIRS_J + (j & 1) : HalfTile<KSJ>::STEPS * NTN;
+            constexpr int GS0 = H16 ? (src == 0 ? 0 : KS0 * KS0 + (src - 1) * 9) + (j & 1) * PAIRS_J
+                                    : (j == 0 ? 0 : j == 1 ? H0::STEPS : 2 * H0::STEPS + (j - 2) * H3::STEPS) * NTN;
             PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring_lds, wbase, GS0, wave, lane, (j == 0 && !single) ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0};
             if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN>(acc, hb, ring, sm, wave, lane);
+            else if constexpr (H16) half_steps_h16<GJ::TWH, GJ::PLANE, 2, KSJ, T, (j & 1) != 0, -HB>(qm, qx, hb, ring, sm, wave, lane);
             else half_steps_h<GJ::TWH, GJ::PLANE, 2, KSJ, T, NTN>(acc, accx, hb, ring, sm, wave, lane);
         };
         do_half(std::integral_constant<int, 0>{});
@@ -1610,7 +1798,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
             asm volatile("" ::: "memory");
         }
-        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
+        if constexpr (H16) stage_epilogue_h16<T>(a, qm, qx, bias2, beta2, n, x0, y0, wave, lane, dom);
+        else stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
     };
 
     // The 48 expand channels of factor 4 are two N-tiles: in the split-half mode an 8-row tile body would hold 128 accumulator registers
@@ -1672,6 +1861,7 @@ __global__ __launch_bounds__(256) void clear_borders_kernel(ClearArgs a) {
 }
 
 bool sr_split_maps_planar() { return kPlanar<1>; }
+bool sr_split_stages_mfma16() { return kH16<1, false>; }
 
 hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s) {
     const long rows = (a.total_px + a.pitch - 1) / a.pitch;
