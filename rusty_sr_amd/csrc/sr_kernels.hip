@@ -1793,7 +1793,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#ifndef SR_EXP_NO_LIN
             lin_mfma<TH, T, NTN>(acc, s_x, s_wlin, wave, lane);
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
             asm volatile("" ::: "memory");
