@@ -199,6 +199,34 @@ void pack_lin(std::vector<float>& dst, int f) {
                 }
 }
 
+// The same residual for the split-half mode's last stage (sr_kernels.hip lin_mfma_h): the staged pixels are divided by (2 f)^2, which
+// makes every weight a small integer -- exact in a half, no lo part.  K slot = 4 tap + colour (36 of 48 used), three K-blocks of 16:
+// [b 3][N-tile][h 2][lane 32][e 8] halves, slot 16 b + 8 h + e.
+void pack_lin_split(std::vector<float>& dst, int f) {
+    float w1[4][3] = {};
+    for (int p = 0; p < f; ++p) {
+        const int nn = 2 * p + 1 - f;
+        const float t = (float)(nn < 0 ? nn + 2 * f : nn) / (float)(2 * f);
+        if (nn < 0) { w1[p][0] = 1.0f - t; w1[p][1] = t; }
+        else { w1[p][1] = 1.0f - t; w1[p][2] = t; }
+    }
+    const int ntn = expand_tiles(f);
+    const float scale = 4.0f * f * f;
+    const size_t base = dst.size();
+    dst.resize(base + (size_t)3 * ntn * 256, 0.0f);
+    _Float16* hp = (_Float16*)(dst.data() + base);
+    for (int b = 0; b < 3; ++b)
+        for (int nt = 0; nt < ntn; ++nt)
+            for (int h = 0; h < 2; ++h)
+                for (int j = 0; j < 32; ++j)
+                    for (int e = 0; e < 8; ++e) {
+                        const int s = 16 * b + 8 * h + e, tap = s / 4, c = s % 4, ch = expand_channel(f, nt, j);
+                        if (tap >= 9 || c >= 3 || ch < 0 || ch % 3 != c) continue;
+                        const int tr = ch / 3, dy = tr / f, dx = tr % f;
+                        hp[(((size_t)(b * ntn + nt) * 2 + h) * 32 + j) * 8 + e] = (_Float16)std::nearbyint(w1[dy][tap / 3] * w1[dx][tap % 3] * scale);
+                    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -353,7 +381,8 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
             off[3] = push(w);
             w.clear();
             exp3(params + L.conv7); exp3(params + L.conv9); exp3(params + L.conv10);
-            pack_lin(w, factor);  // f32 in both modes: the residual is the signal, it stays on the exact path
+            if (split) pack_lin_split(w, factor);  // the split-half mode: on the f16 pipe too, with exact integer weights (lin_mfma_h)
+            else pack_lin(w, factor);
             off[4] = push(w);
         }
         const size_t boff[4] = {L.f_bias, L.l_bias[0], L.l_bias[1], L.l_bias[2]};

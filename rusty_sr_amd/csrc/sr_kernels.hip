@@ -1027,19 +1027,92 @@ __device__ __forceinline__ void lin_mfma(f32x16 (&acc)[NTN * T], const float* s_
     }
 }
 
+// The same residual in the split-half mode, on the f16 matrix cores (round 5: on the f32 MFMA of the vector ALU the nine taps were
+// 9.7 % of this mode's last stage, profiles/r5_ab_nolin.txt).  The phase weights of LinearInterp x f are products of multiples of
+// 1 / (2 f), so (2 f)^2 times a weight is a small INTEGER, exact in a half: the staged pixels are divided by (2 f)^2 once (and split
+// into hi / lo halves, [pixel][R G B 0] each), the weights need no lo part, and a K-block is two MFMAs -- x_hi . k into the main
+// accumulators, x_lo . k into the cross accumulators (both already carry the conv taps in these scales).  K slot = 4 tap + channel:
+// 36 slots = 3 K-blocks of 16 (the 12 padding slots under zero weights read the ninth tap's pixel: inside the footprint).
+template <int TH, int T, int NTN>
+__device__ __forceinline__ void lin_mfma_h(f32x16 (&accm)[NTN * T], f32x16 (&accx)[NTN * T], const char* s_hi, int lo_off, const f16x8* s_w, int wave, int lane) {
+    constexpr int TWH = kTW + 2;
+    const int i = lane & 31, h = lane >> 5;
+    const char* xa = s_hi + ((wave * T) * TWH + i) * 8;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int ta = min(4 * b + 2 * h, 8), tb = min(4 * b + 2 * h + 1, 8);
+        const int oa = ((ta / 3) * TWH + ta % 3) * 8, ob = ((tb / 3) * TWH + tb % 3) * 8;
+        f16x8 ah[T], al[T];
+#pragma unroll
+        for (int m = 0; m < T; ++m) {
+            const char* ra = xa + oa + m * TWH * 8;
+            const char* rb = xa + ob + m * TWH * 8;
+            const uint2 ha = *(const uint2*)ra, hb2 = *(const uint2*)rb, la = *(const uint2*)(ra + lo_off), lb2 = *(const uint2*)(rb + lo_off);
+            const uint32_t ahw[4] = {ha.x, ha.y, hb2.x, hb2.y}, alw[4] = {la.x, la.y, lb2.x, lb2.y};
+            ah[m] = __builtin_bit_cast(f16x8, ahw); al[m] = __builtin_bit_cast(f16x8, alw);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+            const f16x8 bw = s_w[((b * NTN + nt) * 2 + h) * 32 + i];
+#pragma unroll
+            for (int m = 0; m < T; ++m) {
+                accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bw, accm[nt * T + m], 0, 0, 0);
+                accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bw, accx[nt * T + m], 0, 0, 0);
+            }
+        }
+    }
+}
+// one staged pixel of that tile: (R, G, B) / (2 f)^2 as hi halves and lo halves.  u8: through the table lin_split_table_entry fills.
+__device__ __forceinline__ uint32_t lin_split_table_entry(int byte, float scale) {
+    uint32_t hi2, lo2;
+    split_half2(f32x2{__fdiv_rn(__fdiv_rn((float)byte, 255.0f), scale), 0.0f}, hi2, lo2);
+    return (hi2 & 0xffffu) | (lo2 << 16);
+}
+__device__ __forceinline__ void lin_split_store_u8(char* s_hi, int lo_off, int p, uint32_t wr, uint32_t wg, uint32_t wb) {
+    *(uint2*)(s_hi + p * 8) = make_uint2(__builtin_amdgcn_perm(wg, wr, 0x05040100u), wb & 0xffffu);
+    *(uint2*)(s_hi + lo_off + p * 8) = make_uint2(__builtin_amdgcn_perm(wg, wr, 0x07060302u), wb >> 16);
+}
+__device__ __forceinline__ void lin_split_store_f32(char* s_hi, int lo_off, int p, float r, float g, float b, float scale) {
+    uint32_t h0, l0, h1, l1;
+    split_half2(f32x2{__fdiv_rn(r, scale), __fdiv_rn(g, scale)}, h0, l0);
+    split_half2(f32x2{__fdiv_rn(b, scale), 0.0f}, h1, l1);
+    *(uint2*)(s_hi + p * 8) = make_uint2(h0, h1);
+    *(uint2*)(s_hi + lo_off + p * 8) = make_uint2(l0, l1);
+}
+
 // Final stage only: the bilinear x3 residual (LinearInterp, network.rs:27) as nine
 // more taps of a 4-channel (RGB + zero) source.  The image tile is staged with
 // edge-REPLICATED coordinates (the interp clamps indices, it does not zero-pad),
 // the fixed weights (phase products {1/3, 2/3, 1}^2, built on the host) sit in the
 // weight pack behind the conv chunks: 9 x [cin/2][cout 32][2] floats.
-template <int TH, int T, bool IMG_U8, int NTHREADS, int NTN>
-__device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], char* tile, char* ring, const StageArgs& a,
+template <int TH, int T, bool IMG_U8, int NTHREADS, int NTN, int PREC, int FACTOR>
+__device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], f32x16 (&accx)[PREC == 1 ? NTN * T : 1], char* tile, char* ring, const StageArgs& a,
                                          const float* __restrict__ wlin, int n, int y0, int x0, int wave,
                                          int lane, int tid) {
     constexpr int TWH = kTW + 2, THH = TH + 2, NPIX = THH * TWH;
     float* s_x = (float*)tile;   // [pixel][4]
     float* s_w = (float*)ring;   // 9 x NTN x 128 floats
     const size_t img_px0 = (size_t)n * a.H * a.W;
+    if constexpr (PREC == 1) {  // split-half mode: the taps on the f16 pipe (lin_mfma_h), weights 3 x NTN x 256 floats' worth of halves
+        constexpr float kScale = 4.0f * FACTOR * FACTOR;
+        constexpr int LO = NPIX * 8;
+        for (int k = tid; k < 3 * NTN * 256; k += NTHREADS) s_w[k] = wlin[k];
+        for (int p = tid; p < NPIX; p += NTHREADS) {
+            const int py = p / TWH, px = p - py * TWH;
+            const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
+            const size_t gp = img_px0 + (size_t)gy * a.W + gx;
+            if constexpr (IMG_U8) {
+                const uint8_t* q = (const uint8_t*)a.img + gp * a.img_ch;
+                lin_split_store_u8(tile, LO, p, lin_split_table_entry(q[0], kScale), lin_split_table_entry(q[1], kScale), lin_split_table_entry(q[2], kScale));
+            } else {
+                const float* q = (const float*)a.img + gp * 3;
+                lin_split_store_f32(tile, LO, p, q[0], q[1], q[2], kScale);
+            }
+        }
+        __syncthreads();
+        lin_mfma_h<TH, T, NTN>(acc, accx, tile, LO, (const f16x8*)s_w, wave, lane);
+        return;
+    }
     for (int k = tid; k < 9 * NTN * 128; k += NTHREADS) s_w[k] = wlin[k];
     for (int p = tid; p < NPIX; p += NTHREADS) {
         const int py = p / TWH, px = p - py * TWH;
@@ -1309,7 +1382,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
     }
     __builtin_amdgcn_s_setprio(3);
     if constexpr (FINAL)
-        lin_taps<TH, T, IMG_U8, NW * 64, NTN>(acc, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
+        lin_taps<TH, T, IMG_U8, NW * 64, NTN, PREC, FACTOR>(acc, accx, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
     uint32_t dom = 0;
     if constexpr (H16) {
         const float bias2[2] = {a.bias[lane & 15], a.bias[16 + (lane & 15)]}, beta2[2] = {a.beta[lane & 15], a.beta[16 + (lane & 15)]};
@@ -1516,6 +1589,22 @@ struct LinPrefetch {
         st.issued += 3 * PER;
         seq = st.issued;
     }
+    // split-half mode: the same pixels divided by `scale` = (2 f)^2 and split into hi / lo halves (lin_mfma_h); s_lut2: lin_split_table_entry per byte
+    __device__ __forceinline__ void store_split(char* s_hi, int lo_off, const uint32_t* s_lut2, float scale, int tid, const StepStream& st) {
+        wait_vm(st.issued - seq);
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) asm volatile("" : "+v"(raw[k][ch]));  // (see store: no use before the wait)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int p = tid + 256 * k;
+            if (p < NPIX) {
+                if constexpr (IMG_U8) lin_split_store_u8(s_hi, lo_off, p, s_lut2[raw[k][0]], s_lut2[raw[k][1]], s_lut2[raw[k][2]]);
+                else lin_split_store_f32(s_hi, lo_off, p, __uint_as_float(raw[k][0]), __uint_as_float(raw[k][1]), __uint_as_float(raw[k][2]), scale);
+            }
+        }
+    }
     // wait for the pixels, convert (img_to_data: u8 / 255, true division) and write the [pixel][4] tile
     // (u8: through the table of byte / 255 -- the division itself is ~10 vector-ALU instructions per sample, in the matrix stream)
     __device__ __forceinline__ void store(float* s_x, const float* s_lut, int tid, const StepStream& st) {
@@ -1693,8 +1782,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
 
     if constexpr (FINAL) {  // (read after the tile's steps, many barriers later)
         const float* wlin = a.wpack + (size_t)NSTEPS * kChunkFloats;
-        for (int k = tid; k < 9 * NTN * 128; k += 256) s_wlin[k] = wlin[k];
-        if constexpr (IMG_U8) s_lut[tid] = __fdiv_rn((float)tid, 255.0f);
+        // (split-half mode: the residual's integer weights as halves, 3 K-blocks of 1 KB per N-tile, and byte -> split(byte / 255 / (2 f)^2))
+        for (int k = tid; k < (PREC == 1 ? 3 * NTN * 256 : 9 * NTN * 128); k += 256) s_wlin[k] = wlin[k];
+        if constexpr (IMG_U8) s_lut[tid] = PREC == 1 ? __uint_as_float(lin_split_table_entry(tid, 4.0f * FACTOR * FACTOR)) : __fdiv_rn((float)tid, 255.0f);
     }
     const int first = queue_first(blockIdx.x, nbig, nsmall);
     if (first < 0) return;
@@ -1789,13 +1879,14 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         if constexpr (FINAL) {
             // bilinear residual: the image tile goes into the buffer the last half has just left (buffer 1)
             float* s_x = (float*)(smem + HB);
-            linpx.store(s_x, s_lut, tid, st);
+            constexpr int LIN_LO = LinPrefetch<IMG_U8, TH>::NPIX * 8;  // split-half mode: bytes from the hi halves of the tile to its lo halves
+            if constexpr (PREC == 1) linpx.store_split((char*)s_x, LIN_LO, (const uint32_t*)s_lut, 4.0f * FACTOR * FACTOR, tid, st);
+            else linpx.store(s_x, s_lut, tid, st);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-#ifndef SR_EXP_NO_LIN
-            lin_mfma<TH, T, NTN>(acc, s_x, s_wlin, wave, lane);
-#endif
+            if constexpr (PREC == 1) lin_mfma_h<TH, T, NTN>(acc, accx, (const char*)s_x, LIN_LO, (const f16x8*)s_wlin, wave, lane);
+            else lin_mfma<TH, T, NTN>(acc, s_x, s_wlin, wave, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
             asm volatile("" ::: "memory");
