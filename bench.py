@@ -78,6 +78,8 @@ def kernel_matches(name, stage, precision):
     first form: conv_stage_kernel<TH, NSRC, KS0, FINAL, IMG_U8, OUT_U8, PREC, PERSIST, NW[, FACTOR]>"""
     prec = 0 if precision == "f32" else 1
     if stage == 0:
+        if name.startswith("void conv0_split_kernel<8, "):  # the split-half mode's own stage-0 kernel (round 5)
+            return prec == 1
         return name.startswith("void conv0_kernel<8, ") and name[name.index("<") + 1:name.rindex(">")].split(", ")[-1] == str(prec)
     nsrc, ks = STAGE_SHAPE[stage]
     if f"conv_stage_pipe_kernel<{nsrc}, {ks}, " in name:
@@ -120,11 +122,11 @@ def pmc_traffic(stage, H, W, precision="f32"):
 
 
 def n1_reference(ms_c, world, precision, io):
-    """config_C at N > 1: speed-up over the committed one-GPU time of the same 3840x2160 image (profiles/r4_bench.json, else
+    """config_C at N > 1: speed-up over the committed one-GPU time of the same 3840x2160 image (profiles/r5_bench.json, else
     an earlier round's record) -- measured on another box of the same kind, so good to the box-to-box spread (~1.5 %)."""
     if world == 1:
         return {}
-    for name in ("r4_bench.json", "r3_bench.json", "r2_bench.json"):
+    for name in ("r5_bench.json", "r4_bench.json", "r3_bench.json", "r2_bench.json"):
         d = _profile_json(name)
         ref = d and d.get("config_C", {})
         same = d and d.get("config", {}).get("precision") == precision and d.get("config", {}).get("io") == io
