@@ -590,7 +590,7 @@ def main():
             if args.precision == "f32":
                 note = "v_mfma_f32_32x32x2_f32; algorithmic FLOPs = issued FLOPs"
             else:
-                note = ("v_mfma_f32_32x32x16_f16, 3 products per algorithmic product: achieved counts ALGORITHMIC FLOPs "
+                note = ("v_mfma_f32_16x16x32_f16 (stages 1-3; the last stage 32x32x16), 3 products per algorithmic product: achieved counts ALGORITHMIC FLOPs "
                         f"against the f16 dense peak (issued rate {3 * ach:.1f} TFLOP/s); the ceiling of this scheme is peak/3")
             pe = pmc_entry(k, H, W, args.precision) if world == 1 else None
             result["roofline"] = {
