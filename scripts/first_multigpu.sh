@@ -58,9 +58,9 @@ for f in sorted(glob.glob("profiles/r5_scale_[0-9]*.json")):
     out[str(d.get("n_gpus"))] = {
         "value_mp_s": d.get("value"), "ms_per_step": d.get("ms_per_step"), "scaling": d.get("scaling"), "exchange": (d.get("config") or {}).get("exchange"),
         "exchange_check": d.get("exchange_check"), "comm_ms": d.get("comm_ms"),
-        "config_C": {k: c.get(k) for k in ("ms", "mp_s", "speedup_vs_n1", "roofline_frac_per_rank", "recompute_overhead")},
+        "config_C": {k: c.get(k) for k in ("ms_per_step", "value", "speedup_vs_n1", "efficiency_vs_n1", "roofline_frac_per_rank", "recompute_overhead")},
         "config_C_per_rank": [{k: p.get(k) for k in ("rank", "rows", "roofline_frac", "comm_ms")} for p in (c.get("per_rank") or []) if p],
-        "config_D": {k: (d.get("config_D") or {}).get(k) for k in ("ms", "mp_s", "images_per_rank")},
+        "config_D": {k: (d.get("config_D") or {}).get(k) for k in ("ms_per_step", "value", "images_per_rank")},
     }
 json.dump(out, open("profiles/r5_scale_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
