@@ -463,6 +463,16 @@ def test_cli_end_to_end(png, tmp_path, params):
     bad.write_bytes(b"\x03\x00\x00\x00" + b"\x04\x00\x00\x00" * 3 + b"\x00" * 12)  # 3 params: count mismatch
     r = _run(os.path.join(GOLDEN, "cartoon_lr.png"), str(out2), "-c", str(bad))
     assert r.returncode == 1 and "Parameters selected do not have the size required" in r.stderr  # main.rs:162
+    # user weights the split-half mode cannot carry as pairs of halves are refused by name, not clamped; the exact mode takes them
+    import rusty_sr_amd as r_
+    wild = params["anime"].copy()
+    wild[2683 + 5] = 1e5
+    big = tmp_path / "wild.rsr"
+    big.write_bytes(r_.rsr.encode(wild))
+    r = _run(os.path.join(GOLDEN, "cartoon_lr.png"), str(out2), "-c", str(big), "--precision", "split_f16")
+    assert r.returncode == 1 and "SR_PRECISION_SPLIT_F16" in r.stderr
+    r = _run(os.path.join(GOLDEN, "cartoon_lr.png"), str(out2), "-c", str(big))
+    assert r.returncode == 0
     # a JPEG input (image::open sniffs the format, main.rs:164): same pixels in, same pixels out
     from PIL import Image
     jpg = tmp_path / "in.jpg"
