@@ -242,17 +242,22 @@ __global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
     }
 }
 
-// downsample_net: a thread per output pixel (two for u8: tiles of 64 x 8); a workgroup owns 64 x 4 output pixels = 192 x 12 input pixels (f32), whose rows
-// are staged raw in LDS by coalesced dword loads (an input row segment starts at any byte: loaded from the 4-byte word
-// that holds its first byte on, the misalignment added back at the read).  No input sample is read twice (the 3x3
-// windows do not overlap), the 9 samples are summed in the reference's order (rows, then columns) and divided by 9.
-constexpr int kDsTW = 64;
-constexpr int ds_tile_rows(bool) { return 4; }  // output rows per tile (8 for u8 was tried: -3 % at 5760x3240, +8 % at 1920x1080)
-template <bool IMG_U8, bool OUT_U8>
+// downsample_net: a thread per output pixel, a workgroup walks tiles of 64 x 4 output pixels.  The 3x3 windows do not overlap, so
+// no input sample is needed twice and nothing is staged: a thread reads the 3 x (3 px) of its window straight from global memory --
+// consecutive lanes read consecutive 9 / 12 / 36-byte pieces of a row, so a wave's load covers one contiguous run.  A u8 piece starts
+// at any byte: it is read as the aligned dwords that hold it (all of them hold a byte of the piece: nothing outside the image's words
+// is touched) and shifted into place with v_alignbyte; the channel count is a template parameter, so that every sample's byte
+// position is a constant.  The 9 samples are summed in the reference's order (rows, then columns) and divided by 9.  Rounds 3-4 staged
+// the raw rows through LDS (two barriers and 27 ds_read_u8 per pixel on top of the 27 table look-ups): 51 us at 5760 x 3240.
+constexpr int kDsTW = 64, kDsTH = 4;
+struct __attribute__((packed, aligned(4))) DsF3 { float v[3]; };
+template <bool IMG_U8, int CH> struct DsWindow {
+    static constexpr int WORDS = IMG_U8 ? (CH == 3 ? 3 : 4) : 9;
+    uint32_t w[3][WORDS];
+    uint32_t mis[3];
+};
+template <bool IMG_U8, bool OUT_U8, int CH>
 __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
-    constexpr int kDsTH = ds_tile_rows(IMG_U8);
-    constexpr int ROW_BYTES = 3 * kDsTW * (IMG_U8 ? 4 : 12) + 16;   // a staged row segment (u8: up to 4 channels), + misalignment slack
-    __shared__ __attribute__((aligned(16))) uint32_t s_raw[3 * kDsTH * (ROW_BYTES / 4)];
     __shared__ float s_lut[IMG_U8 ? 256 : 1];
     __shared__ QEntry s_q[OUT_U8 ? kQEntries : 1];
     const int tid = threadIdx.x;
@@ -263,82 +268,85 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
     }
     const int OH = a.H / 3, OW = a.W / 3;  // remainder rows / columns dropped (unpinned, see oracle)
     const int tiles_x = (OW + kDsTW - 1) / kDsTW, tiles_y = (OH + kDsTH - 1) / kDsTH;
-    const long ntiles = (long)a.n * tiles_x * tiles_y;
-    const size_t px_bytes = IMG_U8 ? (size_t)a.img_ch : 12;
-    // The raw row segments of a tile travel global -> registers -> LDS; those of the NEXT tile are requested before this tile's
-    // arithmetic and land under it (every workgroup of the launch starts at the same moment: without this they all sit out the same
-    // load latency together, once per tile).  Thread t carries words t, t + 256, ... of each of the tile's (up to) 12 rows.
-    constexpr int ROW_WORDS = ROW_BYTES / 4, LOADS = (ROW_WORDS + 255) / 256;
-    uint32_t raw[3 * kDsTH][LOADS];
-    auto fetch = [&](long tile) {
-        const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
-        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
-        const int ox0 = tx * kDsTW, oy0 = ty * kDsTH;
-        const int tw = min(kDsTW, OW - ox0), th = min(kDsTH, OH - oy0);
-        const int seg = 3 * tw * (int)px_bytes;
+    const int per_img = tiles_x * tiles_y;
+    const long ntiles = (long)a.n * per_img;
+    const int lx = tid & (kDsTW - 1), ly = tid / kDsTW;
+    typedef DsWindow<IMG_U8, CH> Win;
+    // output pixel of this thread in a tile (-1: outside the image) and its window, requested one tile ahead
+    auto place = [&](long tile, int& n, int& ox, int& oy) {
+        n = (int)(tile / per_img);
+        const int tr = (int)(tile - (long)n * per_img), ty = tr / tiles_x;
+        ox = (tr - ty * tiles_x) * kDsTW + lx;
+        oy = ty * kDsTH + ly;
+        return ox < OW && oy < OH;
+    };
+    auto fetch = [&](long tile, Win& win) {
+        int n, ox, oy;
+        if (!place(tile, n, ox, oy)) return;
 #pragma unroll
-        for (int r = 0; r < 3 * kDsTH; ++r) {
-            if (r < 3 * th) {  // wave-uniform
-                const uintptr_t addr = (uintptr_t)a.img + (((size_t)n * a.H + 3 * oy0 + r) * a.W + 3 * ox0) * px_bytes;
+        for (int dy = 0; dy < 3; ++dy) {
+            const size_t px = ((size_t)n * a.H + 3 * oy + dy) * a.W + 3 * ox;
+            if constexpr (IMG_U8) {
+                const uintptr_t addr = (uintptr_t)a.img + px * CH;
                 const uint32_t* src = (const uint32_t*)(addr & ~(uintptr_t)3);
-                const int words = (int)((addr & 3) + seg + 3) / 4;
+                win.mis[dy] = (uint32_t)(addr & 3);
+                win.w[dy][0] = src[0];
+                win.w[dy][1] = src[1];
+                win.w[dy][2] = src[2];  // (byte 8 of the piece lies in it for every misalignment)
+                if constexpr (CH == 4) win.w[dy][3] = win.mis[dy] ? src[3] : 0u;
+            } else {
+                const DsF3* src = (const DsF3*)((const float*)a.img + px * 3);
 #pragma unroll
-                for (int i = 0; i < LOADS; ++i)
-                    if (tid + 256 * i < words) raw[r][i] = src[tid + 256 * i];
+                for (int dx = 0; dx < 3; ++dx) {
+                    const DsF3 v = src[dx];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) win.w[dy][3 * dx + c] = __float_as_uint(v.v[c]);
+                }
             }
         }
     };
-    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    Win cur, nxt;
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x, nxt);
+    __syncthreads();  // the tables
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
-        const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
-        const int ox0 = tx * kDsTW, oy0 = ty * kDsTH;
-        const int tw = min(kDsTW, OW - ox0), th = min(kDsTH, OH - oy0);
-        const int seg = 3 * tw * (int)px_bytes;  // bytes of one input row segment
-        __syncthreads();
+        cur = nxt;
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
+        int n, ox, oy;
+        if (!place(tile, n, ox, oy)) continue;
+        float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 3 * kDsTH; ++r) {
-            if (r < 3 * th) {
-                const uintptr_t addr = (uintptr_t)a.img + (((size_t)n * a.H + 3 * oy0 + r) * a.W + 3 * ox0) * px_bytes;
-                const int words = (int)((addr & 3) + seg + 3) / 4;
-#pragma unroll
-                for (int i = 0; i < LOADS; ++i)
-                    if (tid + 256 * i < words) s_raw[r * ROW_WORDS + tid + 256 * i] = raw[r][i];
+        for (int dy = 0; dy < 3; ++dy) {
+            uint32_t al[3];
+            if constexpr (IMG_U8) {  // the piece's bytes 0 .. 11 in place
+                al[0] = __builtin_amdgcn_alignbyte(cur.w[dy][1], cur.w[dy][0], cur.mis[dy]);
+                al[1] = __builtin_amdgcn_alignbyte(cur.w[dy][2], cur.w[dy][1], cur.mis[dy]);
+                al[2] = __builtin_amdgcn_alignbyte(CH == 4 ? cur.w[dy][3] : 0u, cur.w[dy][2], cur.mis[dy]);
             }
-        }
-        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
-        __syncthreads();
-        const int lx = tid & (kDsTW - 1);
 #pragma unroll
-        for (int ly = tid / kDsTW; ly < kDsTH; ly += 256 / kDsTW)
-        if (lx < tw && ly < th) {
-            float acc[3] = {0.f, 0.f, 0.f};
+            for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int r = 3 * ly + dy;
-                const uintptr_t addr = (uintptr_t)a.img + (((size_t)n * a.H + 3 * oy0 + r) * a.W + 3 * ox0) * px_bytes;
-                const unsigned char* row = (const unsigned char*)(s_raw + r * (ROW_BYTES / 4)) + (addr & 3);
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float v;
-                        if constexpr (IMG_U8) v = s_lut[row[(3 * lx + dx) * a.img_ch + c]];
-                        else v = srgb_to_linear_fast(*(const float*)(row + ((3 * lx + dx) * 3 + c) * 4));
-                        acc[c] += v;
+                for (int c = 0; c < 3; ++c) {
+                    float v;
+                    if constexpr (IMG_U8) {
+                        const int b = CH * dx + c;
+                        v = s_lut[(al[b >> 2] >> (8 * (b & 3))) & 0xffu];
+                    } else {
+                        v = srgb_to_linear_fast(__uint_as_float(cur.w[dy][3 * dx + c]));
                     }
-            }
-            const size_t op = ((size_t)n * OH + oy0 + ly) * OW + ox0 + lx;
-            if constexpr (OUT_U8) {
-                uint32_t pk = 0xff000000u;
+                    acc[c] += v;
+                }
+        }
+        const size_t op = ((size_t)n * OH + oy) * OW + ox;
+        if constexpr (OUT_U8) {
+            uint32_t pk = 0xff000000u;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) pk |= quant_lookup(s_q, acc[c] / 9.0f) << (8 * c);
-                ((uint32_t*)a.out)[op] = pk;
-            } else {
-                float* d = (float*)a.out + op * 3;
+            for (int c = 0; c < 3; ++c) pk |= quant_lookup(s_q, acc[c] / 9.0f) << (8 * c);
+            ((uint32_t*)a.out)[op] = pk;
+        } else {
+            DsF3 o;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) d[c] = linear_to_srgb_fast(acc[c] / 9.0f);
-            }
+            for (int c = 0; c < 3; ++c) o.v[c] = linear_to_srgb_fast(acc[c] / 9.0f);
+            ((DsF3*)a.out)[op] = o;
         }
     }
 }
@@ -420,13 +428,14 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
         }
     } else {
         const int OH = a.H / 3, OW = a.W / 3;
-        const int th = ds_tile_rows(img_u8);
-        const long tiles = (long)a.n * ((OW + kDsTW - 1) / kDsTW) * ((OH + th - 1) / th);
+        const long tiles = (long)a.n * ((OW + kDsTW - 1) / kDsTW) * ((OH + kDsTH - 1) / kDsTH);
         if (tiles == 0) return hipSuccess;
         const long per = (tiles + 8L * cus - 1) / (8L * cus);  // (8 workgroups per CU: 3 / 4 / 6 measured 10-60 % slower at 5760x3240)
         const int grid = (int)((tiles + per - 1) / per);
-        if (img_u8) hipLaunchKernelGGL((downsample_tile_kernel<true, true>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((downsample_tile_kernel<false, false>), dim3(grid), dim3(256), 0, s, a);
+        if (img_u8 && a.img_ch == 3) hipLaunchKernelGGL((downsample_tile_kernel<true, true, 3>), dim3(grid), dim3(256), 0, s, a);
+        else if (img_u8 && a.img_ch == 4) hipLaunchKernelGGL((downsample_tile_kernel<true, true, 4>), dim3(grid), dim3(256), 0, s, a);
+        else if (img_u8) return hipErrorInvalidValue;
+        else hipLaunchKernelGGL((downsample_tile_kernel<false, false, 3>), dim3(grid), dim3(256), 0, s, a);
     }
     return hipGetLastError();
 }

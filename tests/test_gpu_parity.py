@@ -453,6 +453,31 @@ def test_bilinear_and_downsample_graphs(params):
         ds.upscale_f32(np.zeros((2, 2, 3), np.float32))
 
 
+def test_downsample_reads_any_channel_count_and_alignment():
+    """downsample_net's threads read their 3x3 windows straight from global memory as the aligned words that hold them
+    (sr_aux.hip): 3- and 4-channel u8 input, device pointers at every byte offset, widths with remainder columns, batches
+    (so that rows start at every misalignment), against the oracle; the bilinear graph on the same views."""
+    import torch
+    import rusty_sr_amd as r
+    bl, ds = r.bilinear_net(r.FACTOR), r.downsample_net(r.FACTOR)
+    for k, (n, h, w, c) in enumerate(((1, 9, 9, 3), (2, 13, 71, 3), (3, 31, 200, 4), (1, 12, 193, 4), (2, 7, 65, 3))):
+        px = synth_u8(900 + k, n, h, w)
+        if c == 4:
+            px = np.concatenate([px, synth_u8(950 + k, n, h, w)[..., :1]], axis=-1)  # an alpha channel nobody reads
+        x = oracle.img_to_data(px[..., :3])
+        want_ds, want_bl = oracle.downsample(x), oracle.bilinear(x)
+        _check_u8(ds.upscale_rgba8(px), want_ds)
+        for off in range(4):
+            buf = torch.zeros(px.size + 8, dtype=torch.uint8, device="cuda")
+            view = buf[off:off + px.size].view(n, h, w, c)
+            view.copy_(torch.from_numpy(px))
+            assert view.data_ptr() % 4 == (buf.data_ptr() + off) % 4
+            _check_u8(ds.upscale_rgba8_dev(view).cpu().numpy(), want_ds)
+            _check_u8(bl.upscale_rgba8_dev(view).cpu().numpy(), want_bl)
+    ds.close()
+    bl.close()
+
+
 def test_geometry_changes_keep_borders_clean(engines, params):
     """The feature maps carry their zero padding as a border in HBM that is only re-zeroed
     when (n, H, W) changes: interleave big / small / ragged / batched calls on ONE engine and
