@@ -11,13 +11,18 @@
 //    smallest float l that quantises to k, k = 1..255) are found ONCE per context by bisection over the float bit
 //    patterns with the same powf expression (threshold_kernel), and laid out as a table indexed by the top 16 bits of
 //    l (exponent + 7 mantissa bits: 128 buckets per octave, at most one step per bucket -- the builder checks): a
-//    lookup is one ds_read_b64, one compare and one add instead of a powf, and gives the powf's answer;
+//    lookup is one ds_read_b32 and an add instead of a powf, and gives the powf's answer;
 //  * f32 in / out: powf(x, p) = exp2(p * log2(x)) on v_log_f32 / v_exp_f32 (1 ulp each; measured 1.8e-7 absolute
 //    against the oracle's libm, inside the 1e-5 the tests ask of these graphs and far inside north_star's 1e-4);
-//  * every input sample is linearised once per tile (staged, edge-replicated, in LDS as [pixel][4] f32), the
-//    interpolation runs in the reference's operation order ((1-t) a + t b, rows then columns), one workgroup owns an
-//    output tile and a thread stores 16 bytes at a time (4 RGBA pixels / 4 floats) whenever the rows are 16-byte aligned
-//    (W % 4 == 0), dwords otherwise.
+//  * the interpolation runs in the reference's operation order ((1-t) a + t b, rows then columns); a work item is a 16-byte
+//    chunk (4 RGBA pixels / 4 floats) of the three output rows of an input row, consecutive lanes own consecutive chunks, so a
+//    store instruction writes one contiguous run (16 bytes per lane whenever the rows are 16-byte aligned -- W % 4 == 0 --
+//    dwords otherwise);
+//  * f32 bilinear: every input sample is linearised once per tile (staged, edge-replicated, in LDS as [pixel][4] f32), one
+//    workgroup per output tile;
+//  * u8 bilinear and both downsample kernels: nothing staged, no barrier after the tables -- a lane reads the few bytes its
+//    item needs straight from global memory as aligned dwords (the windows of neighbouring lanes are contiguous), the next
+//    item's before this item's arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -59,10 +64,27 @@ constexpr int kQExp0 = 114;                       // biased exponent of 2^-13: b
 constexpr int kQBuckets = (127 - kQExp0) * 128;   // [2^-13, 1) in 128 buckets per octave
 constexpr int kQEntries = kQBuckets + 2;          // + entry 0 (below the range) + the last entry (1.0 and up)
 typedef uint32_t QEntry;
-__device__ __forceinline__ uint32_t quant_lookup(const QEntry* tab, float l) {
+// entry + low 16 bits of l: the byte is bits 16..23 of the sum (bits 24.. are zero: base <= 255)
+// UNIT: the caller guarantees 0 <= l <= 1 (and not -0), so only the lower clamp is needed.  That holds for everything the u8 kernels
+// quantise: convex combinations (1 - t) a + t b and means of table values in [0, 1] -- fl((1 - t) a) <= 1 - t and fl(t b) <= t by
+// monotonicity of rounding, 1 - t is exact for these t, so the sum rounds to at most 1; products and sums of non-negative values are
+// never -0.
+template <bool UNIT = false>
+__device__ __forceinline__ uint32_t quant_sum(const QEntry* tab, float l) {
     const uint32_t bits = __float_as_uint(l);
-    const int idx = min(max(((int)bits >> 16) - (kQExp0 << 7) + 1, 0), kQEntries - 1);  // (arithmetic shift: negative values land below 0)
-    return (tab[idx] + (bits & 0xffffu)) >> 16;
+    constexpr int LO = (kQExp0 << 7) - 1;                                  // top 16 bits of the floats of entry 0
+    if constexpr (UNIT) {
+        const uint32_t top = max(bits >> 16, (uint32_t)LO);
+        return tab[top - LO] + (bits & 0xffffu);
+    } else {
+        const int top = min(max((int)bits >> 16, LO), LO + kQEntries - 1);  // (arithmetic shift: negative values land below LO)
+        return tab[top - LO] + (bits & 0xffffu);
+    }
+}
+// RGBA8 pixel (alpha 255) of three channels in [0, 1]: two v_perm_b32 pick byte 2 of each sum
+__device__ __forceinline__ uint32_t quant_pixel(const QEntry* tab, float r, float g, float b) {
+    const uint32_t rg = __builtin_amdgcn_perm(quant_sum<true>(tab, g), quant_sum<true>(tab, r), 0x0c0c0602u);
+    return __builtin_amdgcn_perm(quant_sum<true>(tab, b), rg, 0x0d060100u);
 }
 
 // (Round 4 also tried the opposite balance -- estimate 255 LinearToSrgb(l) + 0.5 with v_log_f32 / v_exp_f32 and ask the table only
@@ -104,28 +126,21 @@ __device__ __forceinline__ void phase(int o, int& i0, float& t) {
     t = p == 0 ? 2.0f / 3.0f : (p == 1 ? 0.0f : 1.0f / 3.0f);
 }
 
-// One work item = one 16-byte chunk column (4 RGBA pixels / 4 floats) of the THREE output rows of one input row y: the
-// horizontal interpolation of input rows y-1, y, y+1 is done once and shared by the three output rows (vertical phases
+// bilinear_net, f32 in / f32 out.  One work item = one 16-byte chunk column (4 floats) of the THREE output rows of one input row y:
+// the horizontal interpolation of input rows y-1, y, y+1 is done once and shared by the three output rows (vertical phases
 // t = 2/3 of (y-1, y), 0 of (y, y+1), 1/3 of (y, y+1)), in the expression and order of the one-thread-per-pixel kernel
 // this replaces: ra = (1-tx) v00 + tx v01, rb = ..., out = (1-ty) ra + ty rb.  Consecutive lanes own consecutive chunks
-// of a row, so every store instruction writes one contiguous run.
-template <bool IMG_U8, bool OUT_U8, bool ALIGNED>
+// of a row, so every store instruction writes one contiguous run.  (Rounds 4-5 ran the u8 entry points through this kernel too:
+// bilinear_u8_kernel below replaced that.)
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
     __shared__ __attribute__((aligned(16))) float s_lin[kBlNPIX * 4];
-    __shared__ float s_lut[IMG_U8 ? 256 : 1];
-    __shared__ QEntry s_q[OUT_U8 ? kQEntries : 1];
     const int tid = threadIdx.x;
-    if constexpr (IMG_U8) s_lut[tid] = ((const float*)((const QEntry*)a.qtab + kQEntries))[tid];  // SrgbToLinear(byte / 255): lut_kernel
-    if constexpr (OUT_U8) {
-        const QEntry* q = (const QEntry*)a.qtab;
-        for (int k = tid; k < kQEntries; k += 256) s_q[k] = q[k];
-    }
     const int tiles_x = (a.W + kBlTW - 1) / kBlTW, tiles_y = (a.H + kBlTH - 1) / kBlTH;
     const long ntiles = (long)a.n * tiles_x * tiles_y;
     const int OW = 3 * a.W, OH = 3 * a.H;
-    constexpr int EPP = OUT_U8 ? 1 : 3;               // 4-byte elements per output pixel
-    constexpr int CPR = 3 * kBlTW * EPP / 4;          // chunks per output row of a full tile
-    // The input pixels of a tile travel global -> registers -> (table) -> LDS.  The loads of the NEXT tile are issued before this tile's
+    constexpr int CPR = 3 * kBlTW * 3 / 4;            // chunks per output row of a full tile (3 floats per output pixel)
+    // The input pixels of a tile travel global -> registers -> LDS.  The loads of the NEXT tile are issued before this tile's
     // arithmetic and land under it: every workgroup of the launch starts at the same moment, so without this all of them sit out the
     // same load latency together, twice per tile pair.
     constexpr int PER = (kBlNPIX + 255) / 256;
@@ -138,14 +153,8 @@ __global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
         for (int k = 0; k < PER; ++k) {
             const int p = min(tid + 256 * k, kBlNPIX - 1), py = p / kBlTWH, px = p - py * kBlTWH;
             const int gy = min(max(y0 - 1 + py, 0), a.H - 1), gx = min(max(x0 - 1 + px, 0), a.W - 1);
-            const size_t gp = ((size_t)n * a.H + gy) * a.W + gx;
-            if constexpr (IMG_U8) {
-                const uint8_t* q = (const uint8_t*)a.img + gp * a.img_ch;
-                raw[k][0] = q[0]; raw[k][1] = q[1]; raw[k][2] = q[2];
-            } else {
-                const uint32_t* q = (const uint32_t*)a.img + gp * 3;
-                raw[k][0] = q[0]; raw[k][1] = q[1]; raw[k][2] = q[2];
-            }
+            const uint32_t* q = (const uint32_t*)a.img + (((size_t)n * a.H + gy) * a.W + gx) * 3;
+            raw[k][0] = q[0]; raw[k][1] = q[1]; raw[k][2] = q[2];
         }
     };
     if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -153,92 +162,230 @@ __global__ __launch_bounds__(256) void bilinear_tile_kernel(AuxArgs a) {
         const int n = (int)(tile / (tiles_x * tiles_y)), tr = (int)(tile - (long)n * tiles_x * tiles_y);
         const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
         const int x0 = tx * kBlTW, y0 = ty * kBlTH;
-        __syncthreads();  // the previous tile's readers are done (and the tables are in place)
+        __syncthreads();  // the previous tile's readers are done
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int p = tid + 256 * k;
-            if (p < kBlNPIX) {
-                f32x4 v;
-                if constexpr (IMG_U8) v = f32x4{s_lut[raw[k][0]], s_lut[raw[k][1]], s_lut[raw[k][2]], 0.f};
-                else v = f32x4{srgb_to_linear_fast(__uint_as_float(raw[k][0])), srgb_to_linear_fast(__uint_as_float(raw[k][1])),
-                               srgb_to_linear_fast(__uint_as_float(raw[k][2])), 0.f};
-                *(f32x4*)&s_lin[p * 4] = v;
-            }
+            if (p < kBlNPIX)
+                *(f32x4*)&s_lin[p * 4] = f32x4{srgb_to_linear_fast(__uint_as_float(raw[k][0])), srgb_to_linear_fast(__uint_as_float(raw[k][1])),
+                                               srgb_to_linear_fast(__uint_as_float(raw[k][2])), 0.f};
         }
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         __syncthreads();
         const int tw = min(kBlTW, a.W - x0), th = min(kBlTH, a.H - y0);  // this tile's own input pixels
-        const int elems = 3 * tw * EPP;                                  // 4-byte elements per output row of this tile
+        const int elems = 3 * tw * 3;                                    // floats per output row of this tile
         for (int q = tid; q < CPR * kBlTH; q += 256) {
             const int y = q / CPR, cx = q - y * CPR;
             if (y >= th || 4 * cx >= elems) continue;
             const float* row = s_lin + (y * kBlTWH) * 4;   // input row y - 1 (tile row y); y and y + 1 follow
             float h[3][4];                                  // horizontally interpolated: [input row][element of the chunk]
-            if constexpr (OUT_U8) {
-                uint32_t px4[3][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int xa; float txv;
-                    phase(4 * cx + e, xa, txv);
-                    // (R, G) as a packed pair, B alone: the fourth lane of the staged pixel is padding
-                    f32x2 hxy[3]; float hz[3];
+            for (int e = 0; e < 4; ++e) {
+                const int fi = 4 * cx + e, ox = fi / 3, c = fi - 3 * ox;   // [x][c] interleaved: 9 floats per input pixel
+                int xa; float txv;
+                phase(ox, xa, txv);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const f32x4 v0 = *(const f32x4*)(row + (r * kBlTWH + xa) * 4), v1 = *(const f32x4*)(row + (r * kBlTWH + xa) * 4 + 4);
-                        hxy[r] = (1.0f - txv) * f32x2{v0.x, v0.y} + txv * f32x2{v1.x, v1.y};
-                        hz[r] = (1.0f - txv) * v0.z + txv * v1.z;
-                    }
+                for (int r = 0; r < 3; ++r) h[r][e] = (1.0f - txv) * row[(r * kBlTWH + xa) * 4 + c] + txv * row[(r * kBlTWH + xa) * 4 + 4 + c];
+            }
 #pragma unroll
-                    for (int py = 0; py < 3; ++py) {
-                        f32x2 oxy; float oz;
-                        if (py == 1) {  // t = 0: (1 - 0) a + 0 b = a exactly (every value here is finite and >= 0)
-                            oxy = hxy[1]; oz = hz[1];
-                        } else {
-                            const float tyv = py == 0 ? 2.0f / 3.0f : 1.0f / 3.0f;
-                            oxy = (1.0f - tyv) * hxy[py == 0 ? 0 : 1] + tyv * hxy[py == 0 ? 1 : 2];
-                            oz = (1.0f - tyv) * hz[py == 0 ? 0 : 1] + tyv * hz[py == 0 ? 1 : 2];
-                        }
-                        px4[py][e] = 0xff000000u | quant_lookup(s_q, oxy.x) | (quant_lookup(s_q, oxy.y) << 8) | (quant_lookup(s_q, oz) << 16);
-                    }
-                }
-                (void)h;
+            for (int py = 0; py < 3; ++py) {
+                const float tyv = py == 0 ? 2.0f / 3.0f : (py == 1 ? 0.0f : 1.0f / 3.0f);
+                float o[4];
 #pragma unroll
-                for (int py = 0; py < 3; ++py) {
-                    uint32_t* dst = (uint32_t*)a.out + ((size_t)n * OH + 3 * (y0 + y) + py) * OW + 3 * x0 + 4 * cx;
-                    if (ALIGNED || 4 * cx + 4 <= elems) {
-                        if constexpr (ALIGNED) *(u32x4*)dst = u32x4{px4[py][0], px4[py][1], px4[py][2], px4[py][3]};
-                        else { dst[0] = px4[py][0]; dst[1] = px4[py][1]; dst[2] = px4[py][2]; dst[3] = px4[py][3]; }
-                    } else {
+                for (int e = 0; e < 4; ++e) o[e] = linear_to_srgb_fast((1.0f - tyv) * h[py == 0 ? 0 : 1][e] + tyv * h[py == 0 ? 1 : 2][e]);
+                float* dst = (float*)a.out + (((size_t)n * OH + 3 * (y0 + y) + py) * OW + 3 * x0) * 3 + 4 * cx;
+                if (ALIGNED || 4 * cx + 4 <= elems) {
+                    if constexpr (ALIGNED) *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
+                    else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
+                } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (4 * cx + e < elems) dst[e] = px4[py][e];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int fi = 4 * cx + e, ox = fi / 3, c = fi - 3 * ox;   // [x][c] interleaved: 9 floats per input pixel
-                    int xa; float txv;
-                    phase(ox, xa, txv);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) h[r][e] = (1.0f - txv) * row[(r * kBlTWH + xa) * 4 + c] + txv * row[(r * kBlTWH + xa) * 4 + 4 + c];
-                }
-#pragma unroll
-                for (int py = 0; py < 3; ++py) {
-                    const float tyv = py == 0 ? 2.0f / 3.0f : (py == 1 ? 0.0f : 1.0f / 3.0f);
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = linear_to_srgb_fast((1.0f - tyv) * h[py == 0 ? 0 : 1][e] + tyv * h[py == 0 ? 1 : 2][e]);
-                    float* dst = (float*)a.out + (((size_t)n * OH + 3 * (y0 + y) + py) * OW + 3 * x0) * 3 + 4 * cx;
-                    if (ALIGNED || 4 * cx + 4 <= elems) {
-                        if constexpr (ALIGNED) *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
-                        else { dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3]; }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (4 * cx + e < elems) dst[e] = o[e];
-                    }
+                    for (int e = 0; e < 4; ++e) if (4 * cx + e < elems) dst[e] = o[e];
                 }
             }
         }
+    }
+}
+
+// bilinear_net, u8 in / RGBA8 out (round 5): the same work item -- a 16-byte chunk (4 output pixels) of the three output rows of input
+// row y -- but nothing staged and no barrier after the tables are in place.  A WAVE owns 64 consecutive chunks of one input row's output
+// rows (every store instruction: one contiguous 1 KB run), walks such blocks with a uniform stride, and requests the next block's
+// pixels before the arithmetic of this one.  The four output pixels o0 .. o0 + 3 (o0 = 4 cx, i0 = o0 / 3, p0 = o0 % 3) read the three
+// input pixels ws, ws + 1, ws + 2 with ws = i0 - (p0 == 0) and no others, so a lane reads the 9 (12) bytes of that window from each of
+// the rows y - 1, y, y + 1 as the aligned dwords that hold them (as downsample_net does; all of them hold a byte of the window) and
+// sends each byte through the SrgbToLinear table: 27 look-ups per item instead of 24 ds_read_b128 of staged pixels.  With w0, w1, w2 the
+// window's pixels the old kernel's (1 - t) a + t b become, bit for bit (0 * w = +0 and x + 0 = x: every w is finite and >= 0):
+//     e = 0: (1 - t) w0 + t w1        e = 3: (1 - t) w1 + t w2         t = 2/3, 0, 1/3 for p0 = 0, 1, 2
+//     e = 1: a w0 + b w1              (a, b) = (0, 1), (1 - 1/3, 1/3), (1 - 2/3, 2/3)
+//     e = 2: (c0 w0 + c1 w1) + c2 w2  (c0, c1, c2) = (0, 1 - 1/3, 1/3), (1 - 2/3, 2/3, 0), (0, 1, 0)
+// At the image's left and right edges the window is loaded from inside the row (columns clamp(ws, 0, W - 3) ...) and its pixels are
+// re-selected after the table; only waves that hold such a lane run that code.  Images narrower than 3 pixels read byte by byte.
+template <int CH> struct BlWindow {
+    static constexpr int WORDS = CH == 3 ? 3 : 4;
+    uint32_t w[3][WORDS];
+    uint32_t mis[3];
+};
+template <int CH, bool ALIGNED>
+__global__ __launch_bounds__(256, ALIGNED ? 5 : 4) void bilinear_u8_kernel(AuxArgs a) {
+    __shared__ float s_lut[256];
+    __shared__ QEntry s_q[kQEntries];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int W = a.W, H = a.H, OW = 3 * W, OH = 3 * H;
+    const int chunks = (OW + 3) / 4, nb = (chunks + 63) / 64;   // 16-byte chunks per output row; blocks of 64 of them
+    const int total = a.n * H * nb;                             // (the host checks that this fits)
+    const int nw = (int)gridDim.x * 4;
+    int wi = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (tid >> 6));
+    // (image, input row, block) of this wave's item and the stride to the next, all wave-uniform
+    int row = wi / nb, b = wi - row * nb, n = row / H, y = row - n * H;
+    const int rstep = nw / nb, db = nw - rstep * nb, dn = rstep / H, dy = rstep - dn * H;
+    typedef BlWindow<CH> Win;
+    auto geometry = [&](int bb, int& cx, int& p0, int& ws) {
+        cx = min(64 * bb + lane, chunks - 1);  // (lanes past the row's end redo its last chunk: same bytes to the same place, no branch)
+        const int o0 = 4 * cx, i0 = (int)(((uint32_t)o0 * 43691u) >> 17);  // o0 / 3 (exact below 2^17; o0 < 3 * 16384 + 256)
+        p0 = o0 - 3 * i0;
+        ws = i0 - (p0 == 0 ? 1 : 0);
+    };
+    auto fetch = [&](int nn, int yy, int bb, Win& win) {
+        int cx, p0, ws;
+        geometry(bb, cx, p0, ws);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int gy = min(max(yy - 1 + r, 0), H - 1);
+            // (pointer arithmetic on the kernel argument, not integers cast back: the loads stay global_load, whose returns are counted
+            // in order -- a flat_load would make every wait a wait for the previous item's stores too)
+            const uint8_t* rowp = (const uint8_t*)a.img + ((size_t)nn * H + gy) * W * CH;  // uniform
+            if (W >= 3) {
+                const uint32_t m = (uint32_t)(uintptr_t)rowp & 3u;
+                const uint32_t t = m + (uint32_t)(min(max(ws, 0), W - 3) * CH);
+                const uint32_t* src = (const uint32_t*)((rowp - m) + (t & ~3u));
+                win.mis[r] = t & 3u;
+                win.w[r][0] = src[0];
+                win.w[r][1] = src[1];
+                win.w[r][2] = src[2];  // (byte 8 of the window lies in it for every misalignment)
+                if constexpr (CH == 4) win.w[r][3] = (t & 3u) ? src[3] : 0u;
+            } else {  // W = 1 or 2: the window's pixels one by one, already in place
+                win.mis[r] = 0;
+#pragma unroll
+                for (int i = 0; i < Win::WORDS; ++i) win.w[r][i] = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint8_t* q = rowp + min(max(ws + k, 0), W - 1) * CH;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) win.w[r][(CH * k + c) >> 2] |= (uint32_t)q[c] << (8 * ((CH * k + c) & 3));
+                }
+            }
+        }
+    };
+    // The next window is consumed (as far as the compiler's wait-count bookkeeping goes) at the END of a pass, after the item's stores
+    // and on a path without branches: the wait placed there is "all but the last 3 memory operations".  Consumed at the loop's head it
+    // would be "all" -- the first pass arrives there with nothing but loads in flight -- and every pass would sit out the write
+    // acknowledgements of the one before.
+    auto arrived = [](Win& win) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int i = 0; i < Win::WORDS; ++i) asm volatile("" : "+v"(win.w[r][i]));
+        }
+    };
+    Win cur, nxt;
+    if (wi < total) fetch(n, y, b, nxt);
+    s_lut[tid] = ((const float*)((const QEntry*)a.qtab + kQEntries))[tid];  // SrgbToLinear(byte / 255): lut_kernel
+    for (int k = tid; k < kQEntries; k += 256) s_q[k] = ((const QEntry*)a.qtab)[k];
+    arrived(nxt);
+    __syncthreads();  // the tables: the only barrier
+    while (wi < total) {
+        cur = nxt;
+        const int cn = n, cy = y, cb = b;
+        wi += nw;
+        b += db;
+        if (b >= nb) { b -= nb; ++y; }
+        y += dy;
+        if (y >= H) { y -= H; ++n; }
+        n += dn;
+        if (wi < total) fetch(n, y, b, nxt);
+        int cx, p0, ws;
+        geometry(cb, cx, p0, ws);
+        // the window's pixels, linear: [row][pixel] as (R, G) and B
+        f32x2 wxy[3][3];
+        float wz[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            uint32_t al[3];
+            al[0] = __builtin_amdgcn_alignbyte(cur.w[r][1], cur.w[r][0], cur.mis[r]);
+            al[1] = __builtin_amdgcn_alignbyte(cur.w[r][2], cur.w[r][1], cur.mis[r]);
+            al[2] = __builtin_amdgcn_alignbyte(CH == 4 ? cur.w[r][3] : 0u, cur.w[r][2], cur.mis[r]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int bi = CH * k + c;
+                    v[c] = s_lut[(al[bi >> 2] >> (8 * (bi & 3))) & 0xffu];
+                }
+                wxy[r][k] = f32x2{v[0], v[1]};
+                wz[r][k] = v[2];
+            }
+        }
+        if (W >= 3) {
+            const int wl = min(max(ws, 0), W - 3);
+            if (__builtin_amdgcn_ballot_w64(ws != wl) != 0) {  // a lane at the left or right edge: its pixels by clamped column
+                const int s0 = min(max(ws, 0), W - 1) - wl, s1 = min(max(ws + 1, 0), W - 1) - wl, s2 = min(max(ws + 2, 0), W - 1) - wl;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x2 x0 = wxy[r][0], x1 = wxy[r][1], x2 = wxy[r][2];
+                    const float z0 = wz[r][0], z1 = wz[r][1], z2 = wz[r][2];
+                    wxy[r][0] = s0 == 0 ? x0 : (s0 == 1 ? x1 : x2);
+                    wxy[r][1] = s1 == 0 ? x0 : (s1 == 1 ? x1 : x2);
+                    wxy[r][2] = s2 == 0 ? x0 : (s2 == 1 ? x1 : x2);
+                    wz[r][0] = s0 == 0 ? z0 : (s0 == 1 ? z1 : z2);
+                    wz[r][1] = s1 == 0 ? z0 : (s1 == 1 ? z1 : z2);
+                    wz[r][2] = s2 == 0 ? z0 : (s2 == 1 ? z1 : z2);
+                }
+            }
+        }
+        constexpr float T23 = 2.0f / 3.0f, T13 = 1.0f / 3.0f;
+        const float t03 = p0 == 0 ? T23 : (p0 == 1 ? 0.0f : T13), u03 = 1.0f - t03;
+        const float b1 = p0 == 0 ? 1.0f : (p0 == 1 ? T13 : T23), a1 = p0 == 0 ? 0.0f : 1.0f - b1;
+        const float c0 = p0 == 1 ? 1.0f - T23 : 0.0f, c1 = p0 == 0 ? 1.0f - T13 : (p0 == 1 ? T23 : 1.0f), c2 = p0 == 0 ? T13 : 0.0f;
+        uint32_t px4[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x2 hxy[3];
+            float hz[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (e == 0) {
+                    hxy[r] = u03 * wxy[r][0] + t03 * wxy[r][1];
+                    hz[r] = u03 * wz[r][0] + t03 * wz[r][1];
+                } else if (e == 1) {
+                    hxy[r] = a1 * wxy[r][0] + b1 * wxy[r][1];
+                    hz[r] = a1 * wz[r][0] + b1 * wz[r][1];
+                } else if (e == 2) {
+                    hxy[r] = (c0 * wxy[r][0] + c1 * wxy[r][1]) + c2 * wxy[r][2];
+                    hz[r] = (c0 * wz[r][0] + c1 * wz[r][1]) + c2 * wz[r][2];
+                } else {
+                    hxy[r] = u03 * wxy[r][1] + t03 * wxy[r][2];
+                    hz[r] = u03 * wz[r][1] + t03 * wz[r][2];
+                }
+            }
+            // vertical phases: t = 2/3 of (y - 1, y); 0 of (y, y + 1): (1 - 0) a + 0 b = a exactly; 1/3 of (y, y + 1)
+            const f32x2 o0xy = (1.0f - T23) * hxy[0] + T23 * hxy[1], o2xy = (1.0f - T13) * hxy[1] + T13 * hxy[2];
+            const float o0z = (1.0f - T23) * hz[0] + T23 * hz[1], o2z = (1.0f - T13) * hz[1] + T13 * hz[2];
+            px4[0][e] = quant_pixel(s_q, o0xy.x, o0xy.y, o0z);
+            px4[1][e] = quant_pixel(s_q, hxy[1].x, hxy[1].y, hz[1]);
+            px4[2][e] = quant_pixel(s_q, o2xy.x, o2xy.y, o2z);
+        }
+#pragma unroll
+        for (int py = 0; py < 3; ++py) {
+            uint32_t* rowo = (uint32_t*)a.out + ((size_t)cn * OH + 3 * cy + py) * OW;  // uniform
+            uint32_t* dst = rowo + 4 * cx;
+            if constexpr (ALIGNED) {
+                *(u32x4*)dst = u32x4{px4[py][0], px4[py][1], px4[py][2], px4[py][3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (4 * cx + e < OW) dst[e] = px4[py][e];
+            }
+        }
+        arrived(nxt);
     }
 }
 
@@ -272,30 +419,31 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
     const long ntiles = (long)a.n * per_img;
     const int lx = tid & (kDsTW - 1), ly = tid / kDsTW;
     typedef DsWindow<IMG_U8, CH> Win;
-    // output pixel of this thread in a tile (-1: outside the image) and its window, requested one tile ahead
+    // output pixel of this thread in a tile (threads past the image's edge redo the edge's pixel: same bytes to the same place, and no
+    // branch around the store -- see `arrived` in bilinear_u8_kernel) and its window, requested one tile ahead
     auto place = [&](long tile, int& n, int& ox, int& oy) {
         n = (int)(tile / per_img);
         const int tr = (int)(tile - (long)n * per_img), ty = tr / tiles_x;
-        ox = (tr - ty * tiles_x) * kDsTW + lx;
-        oy = ty * kDsTH + ly;
-        return ox < OW && oy < OH;
+        ox = min((tr - ty * tiles_x) * kDsTW + lx, OW - 1);
+        oy = min(ty * kDsTH + ly, OH - 1);
     };
     auto fetch = [&](long tile, Win& win) {
         int n, ox, oy;
-        if (!place(tile, n, ox, oy)) return;
+        place(tile, n, ox, oy);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const size_t px = ((size_t)n * a.H + 3 * oy + dy) * a.W + 3 * ox;
             if constexpr (IMG_U8) {
-                const uintptr_t addr = (uintptr_t)a.img + px * CH;
-                const uint32_t* src = (const uint32_t*)(addr & ~(uintptr_t)3);
-                win.mis[dy] = (uint32_t)(addr & 3);
+                const uint8_t* rowp = (const uint8_t*)a.img + (((size_t)n * a.H + 3 * oy + dy) * a.W) * CH;  // (global pointer arithmetic:
+                const uint32_t m = (uint32_t)(uintptr_t)rowp & 3u;                                         //  see bilinear_u8_kernel)
+                const uint32_t t = m + (uint32_t)(3 * ox * CH);
+                const uint32_t* src = (const uint32_t*)((rowp - m) + (t & ~3u));
+                win.mis[dy] = t & 3u;
                 win.w[dy][0] = src[0];
                 win.w[dy][1] = src[1];
                 win.w[dy][2] = src[2];  // (byte 8 of the piece lies in it for every misalignment)
                 if constexpr (CH == 4) win.w[dy][3] = win.mis[dy] ? src[3] : 0u;
             } else {
-                const DsF3* src = (const DsF3*)((const float*)a.img + px * 3);
+                const DsF3* src = (const DsF3*)((const float*)a.img + (((size_t)n * a.H + 3 * oy + dy) * a.W + 3 * ox) * 3);
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const DsF3 v = src[dx];
@@ -305,14 +453,22 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
             }
         }
     };
+    auto arrived = [](Win& win) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int i = 0; i < Win::WORDS; ++i) asm volatile("" : "+v"(win.w[r][i]));
+        }
+    };
     Win cur, nxt;
     if ((long)blockIdx.x < ntiles) fetch(blockIdx.x, nxt);
+    arrived(nxt);
     __syncthreads();  // the tables
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         cur = nxt;
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, nxt);
         int n, ox, oy;
-        if (!place(tile, n, ox, oy)) continue;
+        place(tile, n, ox, oy);
         float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
@@ -338,16 +494,14 @@ __global__ __launch_bounds__(256) void downsample_tile_kernel(AuxArgs a) {
         }
         const size_t op = ((size_t)n * OH + oy) * OW + ox;
         if constexpr (OUT_U8) {
-            uint32_t pk = 0xff000000u;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) pk |= quant_lookup(s_q, acc[c] / 9.0f) << (8 * c);
-            ((uint32_t*)a.out)[op] = pk;
+            ((uint32_t*)a.out)[op] = quant_pixel(s_q, acc[0] / 9.0f, acc[1] / 9.0f, acc[2] / 9.0f);
         } else {
             DsF3 o;
 #pragma unroll
             for (int c = 0; c < 3; ++c) o.v[c] = linear_to_srgb_fast(acc[c] / 9.0f);
             ((DsF3*)a.out)[op] = o;
         }
+        arrived(nxt);
     }
 }
 
@@ -415,17 +569,37 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
         const long tiles = (long)a.n * ((a.W + kBlTW - 1) / kBlTW) * ((a.H + kBlTH - 1) / kBlTH);
         if (tiles == 0) return hipSuccess;
         // a few workgroups per CU walk the tiles -- the tables are read once per workgroup, not once per tile -- and every workgroup
-        // gets the same number of them (+-1)
-        const long per = (tiles + 6L * cus - 1) / (6L * cus);
-        const int grid = (int)((tiles + per - 1) / per);
+        // gets the same number of them (+-1); never more workgroups than are resident at once (a second round of a few would
+        // run with most of the chip idle)
         const bool aligned = a.W % 4 == 0 && ((uintptr_t)a.out & 15) == 0;
-        if (img_u8) {
-            if (aligned) hipLaunchKernelGGL((bilinear_tile_kernel<true, true, true>), dim3(grid), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((bilinear_tile_kernel<true, true, false>), dim3(grid), dim3(256), 0, s, a);
-        } else {
-            if (aligned) hipLaunchKernelGGL((bilinear_tile_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((bilinear_tile_kernel<false, false, false>), dim3(grid), dim3(256), 0, s, a);
+        if (img_u8) {  // bilinear_u8_kernel: a wave per block of 64 chunks of one input row, every wave the same number of blocks (+-1)
+            if (a.img_ch != 3 && a.img_ch != 4) return hipErrorInvalidValue;
+            const long items = (long)a.n * a.H * (((3L * a.W + 3) / 4 + 63) / 64);
+            if (items >= (1L << 31)) return hipErrorInvalidValue;
+            const void* fn = a.img_ch == 3 ? (aligned ? (const void*)bilinear_u8_kernel<3, true> : (const void*)bilinear_u8_kernel<3, false>)
+                                           : (aligned ? (const void*)bilinear_u8_kernel<4, true> : (const void*)bilinear_u8_kernel<4, false>);
+            int resident = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, fn, 256, 0) != hipSuccess || resident < 1) resident = 4;
+            const long slots = 4L * resident * cus;                 // waves resident at once
+            const long per = (items + slots - 1) / slots;           // blocks per wave
+            const int grid = (int)((items + 4 * per - 1) / (4 * per));
+            if (a.img_ch == 3) {
+                if (aligned) hipLaunchKernelGGL((bilinear_u8_kernel<3, true>), dim3(grid), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((bilinear_u8_kernel<3, false>), dim3(grid), dim3(256), 0, s, a);
+            } else {
+                if (aligned) hipLaunchKernelGGL((bilinear_u8_kernel<4, true>), dim3(grid), dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((bilinear_u8_kernel<4, false>), dim3(grid), dim3(256), 0, s, a);
+            }
+            return hipGetLastError();
         }
+        const void* fn = aligned ? (const void*)bilinear_tile_kernel<true> : (const void*)bilinear_tile_kernel<false>;
+        int resident = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, fn, 256, 0) != hipSuccess || resident < 1) resident = 4;
+        const long slots = (long)std::min(resident, 6) * cus;
+        const long per = (tiles + slots - 1) / slots;
+        const int grid = (int)((tiles + per - 1) / per);
+        if (aligned) hipLaunchKernelGGL((bilinear_tile_kernel<true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((bilinear_tile_kernel<false>), dim3(grid), dim3(256), 0, s, a);
     } else {
         const int OH = a.H / 3, OW = a.W / 3;
         const long tiles = (long)a.n * ((OW + kDsTW - 1) / kDsTW) * ((OH + kDsTH - 1) / kDsTH);
