@@ -225,7 +225,7 @@ template <int CH> struct BlWindow {
     uint32_t mis[3];
 };
 template <int CH, bool ALIGNED>
-__global__ __launch_bounds__(256, ALIGNED ? 5 : 4) void bilinear_u8_kernel(AuxArgs a) {
+__global__ __launch_bounds__(256, ALIGNED ? (CH == 3 ? 7 : 6) : 4) void bilinear_u8_kernel(AuxArgs a) {
     __shared__ float s_lut[256];
     __shared__ QEntry s_q[kQEntries];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -275,44 +275,37 @@ __global__ __launch_bounds__(256, ALIGNED ? 5 : 4) void bilinear_u8_kernel(AuxAr
             }
         }
     };
-    // The next window is consumed (as far as the compiler's wait-count bookkeeping goes) at the END of a pass, after the item's stores
-    // and on a path without branches: the wait placed there is "all but the last 3 memory operations".  Consumed at the loop's head it
-    // would be "all" -- the first pass arrives there with nothing but loads in flight -- and every pass would sit out the write
-    // acknowledgements of the one before.
-    auto arrived = [](Win& win) {
+    // The next window is requested as soon as this item's window has gone through the table -- into the same registers -- and consumed
+    // (as far as the compiler's wait-count bookkeeping goes) at the END of the pass, after the item's stores and on a path without
+    // branches: the wait placed there is "all but the last 3 memory operations".  Consumed at the loop's head it would be "all" -- the
+    // first pass arrives there with nothing but loads in flight -- and every pass would sit out the write acknowledgements of the one
+    // before.
+    auto arrived = [](Win& w) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
-            for (int i = 0; i < Win::WORDS; ++i) asm volatile("" : "+v"(win.w[r][i]));
+            for (int i = 0; i < Win::WORDS; ++i) asm volatile("" : "+v"(w.w[r][i]));
         }
     };
-    Win cur, nxt;
-    if (wi < total) fetch(n, y, b, nxt);
+    Win win;
+    if (wi < total) fetch(n, y, b, win);
     s_lut[tid] = ((const float*)((const QEntry*)a.qtab + kQEntries))[tid];  // SrgbToLinear(byte / 255): lut_kernel
     for (int k = tid; k < kQEntries; k += 256) s_q[k] = ((const QEntry*)a.qtab)[k];
-    arrived(nxt);
+    arrived(win);
     __syncthreads();  // the tables: the only barrier
     while (wi < total) {
-        cur = nxt;
-        const int cn = n, cy = y, cb = b;
-        wi += nw;
-        b += db;
-        if (b >= nb) { b -= nb; ++y; }
-        y += dy;
-        if (y >= H) { y -= H; ++n; }
-        n += dn;
-        if (wi < total) fetch(n, y, b, nxt);
+        const int cn = n, cy = y;
         int cx, p0, ws;
-        geometry(cb, cx, p0, ws);
+        geometry(b, cx, p0, ws);
         // the window's pixels, linear: [row][pixel] as (R, G) and B
         f32x2 wxy[3][3];
         float wz[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             uint32_t al[3];
-            al[0] = __builtin_amdgcn_alignbyte(cur.w[r][1], cur.w[r][0], cur.mis[r]);
-            al[1] = __builtin_amdgcn_alignbyte(cur.w[r][2], cur.w[r][1], cur.mis[r]);
-            al[2] = __builtin_amdgcn_alignbyte(CH == 4 ? cur.w[r][3] : 0u, cur.w[r][2], cur.mis[r]);
+            al[0] = __builtin_amdgcn_alignbyte(win.w[r][1], win.w[r][0], win.mis[r]);
+            al[1] = __builtin_amdgcn_alignbyte(win.w[r][2], win.w[r][1], win.mis[r]);
+            al[2] = __builtin_amdgcn_alignbyte(CH == 4 ? win.w[r][3] : 0u, win.w[r][2], win.mis[r]);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float v[3];
@@ -325,6 +318,13 @@ __global__ __launch_bounds__(256, ALIGNED ? 5 : 4) void bilinear_u8_kernel(AuxAr
                 wz[r][k] = v[2];
             }
         }
+        wi += nw;
+        b += db;
+        if (b >= nb) { b -= nb; ++y; }
+        y += dy;
+        if (y >= H) { y -= H; ++n; }
+        n += dn;
+        if (wi < total) fetch(n, y, b, win);
         if (W >= 3) {
             const int wl = min(max(ws, 0), W - 3);
             if (__builtin_amdgcn_ballot_w64(ws != wl) != 0) {  // a lane at the left or right edge: its pixels by clamped column
@@ -347,32 +347,35 @@ __global__ __launch_bounds__(256, ALIGNED ? 5 : 4) void bilinear_u8_kernel(AuxAr
         const float b1 = p0 == 0 ? 1.0f : (p0 == 1 ? T13 : T23), a1 = p0 == 0 ? 0.0f : 1.0f - b1;
         const float c0 = p0 == 1 ? 1.0f - T23 : 0.0f, c1 = p0 == 0 ? 1.0f - T13 : (p0 == 1 ? T23 : 1.0f), c2 = p0 == 0 ? T13 : 0.0f;
         uint32_t px4[3][4];
+        // Two output pixels at a time -- (e0, e3), then (e1, e2) -- so that the B channel of the two travels as a packed pair like
+        // (R, G) of each does; the expressions and their order are the ones above.
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f32x2 hxy[3];
-            float hz[3];
+        for (int pair = 0; pair < 2; ++pair) {
+            f32x2 hxyA[3], hxyB[3], hzAB[3];   // [row]: (R, G) of the pair's first and second pixel, B of both
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                if (e == 0) {
-                    hxy[r] = u03 * wxy[r][0] + t03 * wxy[r][1];
-                    hz[r] = u03 * wz[r][0] + t03 * wz[r][1];
-                } else if (e == 1) {
-                    hxy[r] = a1 * wxy[r][0] + b1 * wxy[r][1];
-                    hz[r] = a1 * wz[r][0] + b1 * wz[r][1];
-                } else if (e == 2) {
-                    hxy[r] = (c0 * wxy[r][0] + c1 * wxy[r][1]) + c2 * wxy[r][2];
-                    hz[r] = (c0 * wz[r][0] + c1 * wz[r][1]) + c2 * wz[r][2];
+                if (pair == 0) {
+                    hxyA[r] = u03 * wxy[r][0] + t03 * wxy[r][1];
+                    hxyB[r] = u03 * wxy[r][1] + t03 * wxy[r][2];
+                    hzAB[r] = u03 * f32x2{wz[r][0], wz[r][1]} + t03 * f32x2{wz[r][1], wz[r][2]};
                 } else {
-                    hxy[r] = u03 * wxy[r][1] + t03 * wxy[r][2];
-                    hz[r] = u03 * wz[r][1] + t03 * wz[r][2];
+                    hxyA[r] = a1 * wxy[r][0] + b1 * wxy[r][1];
+                    hxyB[r] = (c0 * wxy[r][0] + c1 * wxy[r][1]) + c2 * wxy[r][2];
+                    hzAB[r] = f32x2{a1, c0} * wz[r][0] + f32x2{b1, c1} * wz[r][1];
+                    hzAB[r].y = hzAB[r].y + c2 * wz[r][2];
                 }
             }
             // vertical phases: t = 2/3 of (y - 1, y); 0 of (y, y + 1): (1 - 0) a + 0 b = a exactly; 1/3 of (y, y + 1)
-            const f32x2 o0xy = (1.0f - T23) * hxy[0] + T23 * hxy[1], o2xy = (1.0f - T13) * hxy[1] + T13 * hxy[2];
-            const float o0z = (1.0f - T23) * hz[0] + T23 * hz[1], o2z = (1.0f - T13) * hz[1] + T13 * hz[2];
-            px4[0][e] = quant_pixel(s_q, o0xy.x, o0xy.y, o0z);
-            px4[1][e] = quant_pixel(s_q, hxy[1].x, hxy[1].y, hz[1]);
-            px4[2][e] = quant_pixel(s_q, o2xy.x, o2xy.y, o2z);
+            const f32x2 o0A = (1.0f - T23) * hxyA[0] + T23 * hxyA[1], o2A = (1.0f - T13) * hxyA[1] + T13 * hxyA[2];
+            const f32x2 o0B = (1.0f - T23) * hxyB[0] + T23 * hxyB[1], o2B = (1.0f - T13) * hxyB[1] + T13 * hxyB[2];
+            const f32x2 o0z = (1.0f - T23) * hzAB[0] + T23 * hzAB[1], o2z = (1.0f - T13) * hzAB[1] + T13 * hzAB[2];
+            const int eA = pair == 0 ? 0 : 1, eB = pair == 0 ? 3 : 2;
+            px4[0][eA] = quant_pixel(s_q, o0A.x, o0A.y, o0z.x);
+            px4[1][eA] = quant_pixel(s_q, hxyA[1].x, hxyA[1].y, hzAB[1].x);
+            px4[2][eA] = quant_pixel(s_q, o2A.x, o2A.y, o2z.x);
+            px4[0][eB] = quant_pixel(s_q, o0B.x, o0B.y, o0z.y);
+            px4[1][eB] = quant_pixel(s_q, hxyB[1].x, hxyB[1].y, hzAB[1].y);
+            px4[2][eB] = quant_pixel(s_q, o2B.x, o2B.y, o2z.y);
         }
 #pragma unroll
         for (int py = 0; py < 3; ++py) {
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256, ALIGNED ? 5 : 4) void bilinear_u8_kernel(AuxAr
                 for (int e = 0; e < 4; ++e) if (4 * cx + e < OW) dst[e] = px4[py][e];
             }
         }
-        arrived(nxt);
+        arrived(win);
     }
 }
 
@@ -560,6 +563,23 @@ hipError_t sr_aux_build_tables(void** d_tab) {
     return e;
 }
 
+// Workgroups for `units` equal pieces of work (a workgroup walks every grid-th piece) when `resident` workgroups fit on the chip at
+// once: never more than that (a second round of a few would run with most of the chip idle), and of the few candidates above the
+// minimum number of pieces per workgroup the one whose busiest CU -- ceil(grid / cus) workgroups -- gets clearly less work.  (1920x1080
+// through bilinear_u8_kernel: 4 blocks per wave make 1553 workgroups = 7 on some CUs, 6 on the others, 112 blocks on the busiest; 5
+// per wave make 1242 = 5 on each, 100.)
+static int balanced_grid(long units, long resident, int cus) {
+    const long per0 = std::max(1L, (units + resident - 1) / resident);
+    long load0 = 0, best_load = -1, best_grid = 1;
+    for (long per = per0; per < per0 + 8; ++per) {
+        const long grid = (units + per - 1) / per, load = ((grid + cus - 1) / cus) * per;
+        if (per == per0) load0 = load;
+        if (best_load < 0 || load < best_load) { best_load = load; best_grid = grid; }
+    }
+    // (fewer, longer workgroups also mean fewer waves in flight: 5760x3240 lost 4 % to a 0.5 % better balance, so it has to pay)
+    return (int)(100 * best_load <= 97 * load0 ? best_grid : (units + per0 - 1) / per0);
+}
+
 hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, hipStream_t s) {
     if (img_u8 != out_u8) return hipErrorInvalidValue;
     if (out_u8 && !a.qtab) return hipErrorInvalidValue;
@@ -580,9 +600,7 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
                                            : (aligned ? (const void*)bilinear_u8_kernel<4, true> : (const void*)bilinear_u8_kernel<4, false>);
             int resident = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, fn, 256, 0) != hipSuccess || resident < 1) resident = 4;
-            const long slots = 4L * resident * cus;                 // waves resident at once
-            const long per = (items + slots - 1) / slots;           // blocks per wave
-            const int grid = (int)((items + 4 * per - 1) / (4 * per));
+            const int grid = balanced_grid((items + 3) / 4, (long)resident * cus, cus);  // (a workgroup: 4 waves, 4 blocks at a time)
             if (a.img_ch == 3) {
                 if (aligned) hipLaunchKernelGGL((bilinear_u8_kernel<3, true>), dim3(grid), dim3(256), 0, s, a);
                 else hipLaunchKernelGGL((bilinear_u8_kernel<3, false>), dim3(grid), dim3(256), 0, s, a);
@@ -595,17 +613,14 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
         const void* fn = aligned ? (const void*)bilinear_tile_kernel<true> : (const void*)bilinear_tile_kernel<false>;
         int resident = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, fn, 256, 0) != hipSuccess || resident < 1) resident = 4;
-        const long slots = (long)std::min(resident, 6) * cus;
-        const long per = (tiles + slots - 1) / slots;
-        const int grid = (int)((tiles + per - 1) / per);
+        const int grid = balanced_grid(tiles, (long)std::min(resident, 6) * cus, cus);
         if (aligned) hipLaunchKernelGGL((bilinear_tile_kernel<true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((bilinear_tile_kernel<false>), dim3(grid), dim3(256), 0, s, a);
     } else {
         const int OH = a.H / 3, OW = a.W / 3;
         const long tiles = (long)a.n * ((OW + kDsTW - 1) / kDsTW) * ((OH + kDsTH - 1) / kDsTH);
         if (tiles == 0) return hipSuccess;
-        const long per = (tiles + 8L * cus - 1) / (8L * cus);  // (8 workgroups per CU: 3 / 4 / 6 measured 10-60 % slower at 5760x3240)
-        const int grid = (int)((tiles + per - 1) / per);
+        const int grid = balanced_grid(tiles, 8L * cus, cus);  // (8 workgroups per CU: 3 / 4 / 6 measured 10-60 % slower at 5760x3240)
         if (img_u8 && a.img_ch == 3) hipLaunchKernelGGL((downsample_tile_kernel<true, true, 3>), dim3(grid), dim3(256), 0, s, a);
         else if (img_u8 && a.img_ch == 4) hipLaunchKernelGGL((downsample_tile_kernel<true, true, 4>), dim3(grid), dim3(256), 0, s, a);
         else if (img_u8) return hipErrorInvalidValue;
