@@ -474,6 +474,19 @@ def test_downsample_reads_any_channel_count_and_alignment():
             assert view.data_ptr() % 4 == (buf.data_ptr() + off) % 4
             _check_u8(ds.upscale_rgba8_dev(view).cpu().numpy(), want_ds)
             _check_u8(bl.upscale_rgba8_dev(view).cpu().numpy(), want_bl)
+    # ragged sizes around every boundary of the two u8 kernels: W < 3 (the byte-wise window), W % 4 (16-byte or dword stores), blocks of
+    # 64 chunks (3 W / 4 around 64, 128), one-row images, remainder rows / columns of the 3x3 mean
+    rng = np.random.default_rng(1234)
+    shapes = [(1, 1, 2, 3), (2, 2, 1, 4), (1, 3, 2, 3), (1, 1, 85, 3), (1, 2, 86, 3), (1, 1, 171, 4), (1, 5, 172, 3)]
+    shapes += [(int(rng.integers(1, 4)), int(rng.integers(1, 40)), int(rng.integers(1, 300)), int(rng.integers(3, 5))) for _ in range(24)]
+    for k, (n, h, w, c) in enumerate(shapes):
+        px = synth_u8(2000 + k, n, h, w)
+        if c == 4:
+            px = np.concatenate([px, synth_u8(2100 + k, n, h, w)[..., :1]], axis=-1)
+        x = oracle.img_to_data(px[..., :3])
+        _check_u8(bl.upscale_rgba8(px), oracle.bilinear(x))
+        if h >= 3 and w >= 3:
+            _check_u8(ds.upscale_rgba8(px), oracle.downsample(x))
     ds.close()
     bl.close()
 
