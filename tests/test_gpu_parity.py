@@ -491,6 +491,42 @@ def test_downsample_reads_any_channel_count_and_alignment():
     bl.close()
 
 
+def test_parameter_free_graphs_soak():
+    """A bounded soak of the two parameter-free graphs (the stage kernels have scripts/soak.py): random shapes, batches and channel
+    counts against the oracle, u8 and f32; then whole frames repeated, which must reproduce themselves bit for bit (the u8 kernels
+    prefetch the next item's pixels under sequence-counted waits: a missed wait shows up as a flicker)."""
+    import time
+    import torch
+    import rusty_sr_amd as r
+    bl, ds = r.bilinear_net(r.FACTOR), r.downsample_net(r.FACTOR)
+    rng = np.random.default_rng(4321)
+    t_end = time.time() + 12.0
+    shapes = 0
+    while time.time() < t_end and shapes < 60:
+        n, h, w, c = int(rng.integers(1, 3)), int(rng.integers(1, 160)), int(rng.integers(1, 1200)), int(rng.integers(3, 5))
+        px = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)
+        x = oracle.img_to_data(px[..., :3])
+        want_bl = oracle.bilinear(x)
+        _check_u8(bl.upscale_rgba8(px), want_bl)
+        assert np.abs(bl.upscale_f32(x) - want_bl).max() < 1e-5
+        if h >= 3 and w >= 3:
+            want_ds = oracle.downsample(x)
+            _check_u8(ds.upscale_rgba8(px), want_ds)
+            assert np.abs(ds.upscale_f32(x) - want_ds).max() < 1e-5
+        shapes += 1
+    assert shapes >= 10
+    for (h, w) in ((1080, 1920), (2160, 3840), (1081, 1923)):
+        px = torch.from_numpy(rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)).cuda()
+        for eng in (bl, ds):
+            first = eng.upscale_rgba8_dev(px).clone()
+            out = torch.empty_like(first)
+            for _ in range(25):
+                eng.upscale_rgba8_dev(px, out=out)
+                assert torch.equal(out, first), (eng.graph if hasattr(eng, "graph") else "", h, w)
+    ds.close()
+    bl.close()
+
+
 def test_geometry_changes_keep_borders_clean(engines, params):
     """The feature maps carry their zero padding as a border in HBM that is only re-zeroed
     when (n, H, W) changes: interleave big / small / ragged / batched calls on ONE engine and
