@@ -353,7 +353,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     // load per pixel, no bounds tests: 0.114 ms against 0.108 for this loop, and 0.127 with byte loads: profiles/r4_ab_variants_f32.txt.
     // A second attempt kept the kernel at its 64 VGPRs = 8 waves per SIMD (the first had silently dropped to 7: 66-68 VGPRs) with the
     // offsets parked in LDS: 0.1070 against 0.1073 ms (profiles/r4_ab_conv0_second_attempt.txt).  conv0's time is not in its staging
-    // arithmetic.)
+    // arithmetic.  Round 5: nor in the staging loads' latency -- the next tile's pixels requested under this tile's matrix work and
+    // consumed before its stores (what bought the u8 parameter-free graphs 20 %, sr_aux.hip) costs this kernel its 8th wave per SIMD
+    // (74 VGPRs; held to 64 it spills): 0.1093 -> 0.1200 ms, profiles/r5_ab_conv0_prefetch.txt.)
     for (int p = tid; p < NPIX; p += kThreads) {
         const int py = p / TWH, px = p - py * TWH;
         const int gy = y0 - 2 + py, gx = x0 - 2 + px;
