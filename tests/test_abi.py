@@ -175,3 +175,38 @@ def test_async_asm_results_are_not_read_before_their_wait():
     assert "asynchronous asm results checked, 0 read too early" in res.stdout and not res.stdout.startswith("0 ")
     # ... and the two idioms that depend on encoding sizes: the computed jump into the s_waitcnt table, the wait state behind an m0 write
     assert re.search(r"[1-9]\d* wait tables and [1-9]\d* LDS-DMA m0 writes checked, 0 with an unexpected layout", res.stdout), res.stdout
+
+
+def test_parameter_free_kernels_keep_their_loads_global():
+    """What made the round-5 kernels of sr_aux.hip fast is visible in their assembly, and easy to lose in an edit: the pixel
+    windows must be read with global_load (an integer cast back to a pointer turns them into flat_load, and then every wait the
+    compiler places is vmcnt(0): each pass sits out the previous pass's write acknowledgements), nothing may spill, and the
+    prefetched window of the aligned u8 bilinear kernel must be consumed behind its three stores with `vmcnt(3)`."""
+    import subprocess
+    from rusty_sr_amd.build import CSRC, FLAGS
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    res = subprocess.run([hipcc, *FLAGS, "--cuda-device-only", "-S", "-x", "hip", os.path.join(CSRC, "sr_aux.hip"), "-o", "-"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.split("\n")
+    bodies, cur = {}, None
+    for l in lines:
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur = m.group(1)
+            bodies[cur] = []
+        elif l.startswith(".Lfunc_end"):
+            cur = None
+        elif cur:
+            bodies[cur].append(l.split(";")[0].strip() if not l.strip().startswith(";;#ASM") else l.strip())
+    direct = {k: v for k, v in bodies.items() if "bilinear_u8_kernel" in k or "downsample_tile_kernel" in k}
+    assert len(direct) == 7, sorted(bodies)   # 4 u8 bilinear (3 / 4 channels x aligned or not) + 3 downsample (u8 3 / 4 channels, f32)
+    for name, body in direct.items():
+        assert not [t for t in body if t.startswith(("flat_load", "flat_store", "scratch_"))], name
+        assert any(t.startswith("global_load_dword") for t in body), name
+    assert all(int(m) == 0 for m in re.findall(r"\.vgpr_spill_count:\s*(\d+)", res.stdout))
+    aligned3 = [v for k, v in direct.items() if "bilinear_u8_kernelILi3ELb1E" in k]
+    assert len(aligned3) == 1
+    body = [t for t in aligned3[0] if t]
+    waits = [body[i - 1] for i, t in enumerate(body) if t.startswith(";;#ASMSTART") and body[i - 1].startswith("s_waitcnt")]
+    assert "s_waitcnt vmcnt(3)" in waits, waits
