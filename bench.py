@@ -80,7 +80,10 @@ def kernel_matches(name, stage, precision):
     if stage == 0:
         if name.startswith("void conv0_split_kernel<8, "):  # the split-half mode's own stage-0 kernel (round 5)
             return prec == 1
-        return name.startswith("void conv0_kernel<8, ") and name[name.index("<") + 1:name.rindex(">")].split(", ")[-1] == str(prec)
+        if name.startswith("void conv0_kernel<8, "):  # exact mode only since round 6 (<TH, IMG_U8>; rounds 1-5: <TH, IMG_U8, PREC>)
+            args = name[name.index("<") + 1:name.rindex(">")].split(", ")
+            return (int(args[2]) if len(args) > 2 else 0) == prec
+        return False
     nsrc, ks = STAGE_SHAPE[stage]
     if f"conv_stage_pipe_kernel<{nsrc}, {ks}, " in name:
         args = name[name.index("<") + 1:name.rindex(">")].split(", ")

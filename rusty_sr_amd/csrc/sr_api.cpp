@@ -369,7 +369,7 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         for (int split = 0; split < 2; ++split) {  // exact-f32 chunks, then the same stages in split-half form
             auto ident = [](int, int j) { return j; };
             auto expand = [&](int nt, int j) { return expand_channel(factor, nt, j); };
-            const bool h16 = split && sr_split_stages_mfma16();  // stages 1-3 of the split-half mode on 16x16x32 MFMAs: their own step order
+            const bool h16 = split != 0;  // stages 1-3 of the split-half mode on 16x16x32 MFMAs: their own step order
             auto conv = [&](const float* wp, int ks) { if (h16) pack_steps_h16(w, wp, ks); else pack_steps(w, wp, ks, 1, split != 0, ident); };
             auto exp3 = [&](const float* wp) { pack_steps(w, wp, 3, expand_tiles(factor), split != 0, expand); };
             size_t* off = split ? c->off_wh : c->off_w;
@@ -457,7 +457,7 @@ int sr_set_precision(sr_ctx* c, int mode) {
     if (!c || (mode != SR_PRECISION_F32 && mode != SR_PRECISION_SPLIT_F16)) return SR_E_INVALID;
     if (mode == SR_PRECISION_SPLIT_F16 && !c->split_ok) return SR_E_DOMAIN;  // a weight that no pair of halves can carry: refused, not clamped
     if (mode != c->precision) {
-        // the two modes lay their feature maps out differently (sr_kernels.h sr_split_maps_planar): what was interior for one is border
+        // the two modes lay their feature maps out differently (sr_kernels.h: row-planar against pixel-major): what was interior for one is border
         // for the other, so the workspaces' borders are cleared again before the next pass (ensure_features)
         for (auto& w : c->ws) w.geo_n = 0;
         c->last_h = c->last_w = 0;
@@ -570,7 +570,7 @@ int ensure_features(sr_ctx* c, sr_ctx::Workspace& w, int n, int H, int W, int ti
         ClearArgs ca{};
         for (int k = 0; k < 4; ++k) ca.map[k] = w.d_feat[k];
         ca.n = n; ca.H = H; ca.W = W; ca.pitch = pitch; ca.img_stride = img_stride; ca.total_px = (long)npx;
-        ca.planar = c->precision == SR_PRECISION_SPLIT_F16 && sr_split_maps_planar();
+        ca.planar = c->precision == SR_PRECISION_SPLIT_F16;
         HIPCHK(c, sr_launch_clear_borders(ca, s));
         w.geo_n = n; w.geo_h = H; w.geo_w = W;
     }
@@ -629,7 +629,7 @@ int StackJob::prepare() {
     const int resident = 2 * cus;  // workgroups of a stage kernel that fit the chip at once (2 per CU: 76-78 KB of LDS each)
     // pointers to pixel (0,0) of image 0 inside the zero-bordered maps
     // (row-planar maps of the split-half mode: pixel (0,0) of channel group 0 -- kFeatPad rows down, kFeatPad 16-byte cells in)
-    const bool planar = c->precision == SR_PRECISION_SPLIT_F16 && sr_split_maps_planar();
+    const bool planar = c->precision == SR_PRECISION_SPLIT_F16;
     for (int k = 0; k < 4; ++k) feat[k] = ws->d_feat[k] + (planar ? (size_t)kFeatPad * ws->pitch * 32 + kFeatPad * 4 : ((size_t)kFeatPad * ws->pitch + kFeatPad) * 32);
     // ---- plan every launch first: conv0 (the call's first launch) sets the tile-queue heads of the four stage kernels
     for (int st = 0; st < 5; ++st) {
@@ -1367,7 +1367,7 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
     const size_t pitch = (size_t)c->ws[0].pitch;
-    if (c->precision == SR_PRECISION_SPLIT_F16 && sr_split_maps_planar()) {
+    if (c->precision == SR_PRECISION_SPLIT_F16) {
         // row-planar map: row y = 8 runs of `pitch` 16-byte groups (4 x 8 hi halves, then their lo halves); whole padded rows come over
         std::vector<_Float16> rows((size_t)c->last_h * pitch * 64);
         HIPCHK(c, hipMemcpy(rows.data(), c->ws[0].d_feat[which] + (size_t)kFeatPad * pitch * 32, rows.size() * sizeof(_Float16), hipMemcpyDeviceToHost));
@@ -1383,13 +1383,6 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
     const float* src = c->ws[0].d_feat[which] + ((size_t)kFeatPad * pitch + kFeatPad) * 32;
     HIPCHK(c, hipMemcpy2D(out_host, (size_t)c->last_w * 128, src, pitch * 128, (size_t)c->last_w * 128,
                           c->last_h, hipMemcpyDeviceToHost));
-    if (c->precision == SR_PRECISION_SPLIT_F16) {  // pixel = 32 hi halves + 32 lo halves -> 32 f32, in place
-        for (size_t p = 0; p < (size_t)c->last_h * c->last_w; ++p) {
-            _Float16 hl[64];
-            memcpy(hl, out_host + p * 32, 128);
-            for (int k = 0; k < 32; ++k) out_host[p * 32 + k] = (float)hl[k] + (float)hl[32 + k] * (1.0f / 2048.0f);
-        }
-    }
     return SR_OK;
 }
 

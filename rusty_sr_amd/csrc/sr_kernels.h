@@ -101,17 +101,15 @@ constexpr int kFeatPadBottom = 12;   // last tile row may start at H-1: + 8 rows
 struct ClearArgs {
     float* map[4];
     int n, H, W, pitch;
-    int planar;       // the maps are row-planar (split-half mode, see sr_split_maps_planar)
+    int planar;       // the maps are row-planar (split-half mode)
     long img_stride;  // pixels
     long total_px;    // n * img_stride + the rows above image 0 + slack
 };
 hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s);
-// Layout of the split-half mode's maps: true = row-planar, [y][16-byte channel group c][x] (pixel (0,0) of group c sits
-// (kFeatPad * pitch) * 128 + c * pitch * 16 + kFeatPad * 16 bytes into the map); false = pixel-major like the exact-f32 maps.
-bool sr_split_maps_planar();
-// Step order / operand layout of the split-half weight chunks of stages 1-3: true = v_mfma_f32_16x16x32_f16 (sr_kernels.hip
-// half_steps_h16; sr_api.cpp pack_steps_h16), false = 32x32x16 like the last stage (pack_steps).
-bool sr_split_stages_mfma16();
+// The split-half mode's maps are row-planar: [y][16-byte channel group c][x] (pixel (0,0) of group c sits
+// (kFeatPad * pitch) * 128 + c * pitch * 16 + kFeatPad * 16 bytes into the map); the exact-f32 maps are pixel-major.  The split-half
+// weight chunks of stages 1-3 are in the step order of v_mfma_f32_16x16x32_f16 (sr_kernels.hip half_steps_h16; sr_api.cpp
+// pack_steps_h16), those of the last stage in that of 32x32x16 (pack_steps).
 
 struct AuxArgs {          // bilinear_net / downsample_net (parameter-free graphs)
     const void* img;      // n*H*W*3 f32 or n*H*W*img_ch u8

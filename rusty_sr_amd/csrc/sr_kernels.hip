@@ -69,22 +69,17 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // (scripts/experiments/ubench_split_floor.hip, profiles/r5_ubench_split_floor.txt: the same step loop sustains 1 170 TFLOP/s with
 // line-per-lane gathers and 1 269 with contiguous ones at the same 1 370 W), so what the memory system moves per MFMA is what counts.
 // The exact-f32 mode runs at the full clock and keeps the layout whose stores are whole 128-B lines.  Measured, interleaved A/B at 1080p
-// (profiles/r5_ab_planar.txt): 1.683 -> 1.625 ms per frame (stages 2 / 3 / 4: -4 / -4.6 / -6 %; the producers' stores, now 32-byte
-// runs per channel group, cost nothing measurable -- a pixel permutation that made them 64-byte runs again changed nothing and was removed).
-#ifndef SR_SPLIT_PLANAR
-#define SR_SPLIT_PLANAR 1
-#endif
+// (profiles/r5_ab_planar.txt): 1.683 -> 1.625 ms per frame (stages 2 / 3 / 4: -4 / -4.6 / -6 %).  (The pixel-major split maps, the
+// 32x32x16 form of stages 1-3 and the f32-MFMA stage 0 of the split-half mode were compile-time variants until round 6; their A/B
+// records are profiles/r5_ab_planar.txt, r5_ab_mfma16.txt, r5_ab_conv0_split.txt.)
 template <int PREC>
-constexpr bool kPlanar = PREC == 1 && SR_SPLIT_PLANAR != 0;
+constexpr bool kPlanar = PREC == 1;
 // Stages 1-3 of the split-half mode run their products on v_mfma_f32_16x16x32_f16 (half_steps_h16 below) instead of 32x32x16: the same
 // FLOPs per cycle, but 17 % more of them per watt -- a stream of random operands sustains 2 090 TFLOP/s in that shape against 1 780 in
 // the other at the board's 1.37 kW (profiles/r5_ubench_split_floor.txt), and this mode is bound by exactly that.  The last stage
 // (whose residual taps and depth-to-space epilogue are written for 32x32 accumulators) keeps half_steps_h.
-#ifndef SR_SPLIT_MFMA16
-#define SR_SPLIT_MFMA16 1
-#endif
 template <int PREC, bool FINAL>
-constexpr bool kH16 = PREC == 1 && !FINAL && SR_SPLIT_MFMA16 != 0 && SR_SPLIT_PLANAR != 0;
+constexpr bool kH16 = PREC == 1 && !FINAL;
 
 namespace {
 
@@ -223,19 +218,17 @@ __device__ __forceinline__ void domain_report(uint32_t dom, int* flag) {
 // 32 hi halves then 32 lo halves.  Lane = channel j, register pair (r, r+1) = two
 // adjacent pixels: even lanes collect channels (j, j+1) of pixel `row` from their
 // odd neighbour, odd lanes channels (j-1, j) of pixel `row+1` (one DPP swap + one
-// v_perm_b32 each), so every store is a full dword and 16 even (odd) lanes write
-// one contiguous 64-byte half line.  `base` already points at this lane's pixel
-// (x0 + 4h + (j&1)) and channel pair; `limit` = image columns left of it.
-// PLANAR (row-planar map, see kPlanar): `base` points at this lane's pixel in the row of its hi channel group, dword (j % 8) / 2 of
-// the 16-byte group; consecutive pixels are 16 bytes apart and the lo group's row lies `lo_off` = 4 x pitch x 16 bytes further on.
-template <bool MASKED, bool PLANAR>
+// v_perm_b32 each), so every store is a full dword.  `base` points at this lane's pixel (x0 + 4h + (j&1)) in the row of its hi
+// channel group (row-planar map, see kPlanar), dword (j % 8) / 2 of the 16-byte group; consecutive pixels are 16 bytes apart and the
+// lo group's row lies `lo_off` = 4 x pitch x 16 bytes further on; `limit` = image columns left of the lane's pixel.
+template <bool MASKED>
 __device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16& accm, const f32x16& accx,
                                                         float beta, bool odd, int limit, long lo_off, uint32_t& dom) {
     // v_perm_b32(src0 = partner, src1 = mine): bytes 0-3 = mine, 4-7 = partner
     const uint32_t sel = odd ? 0x03020706u   // (partner.hi16, mine.hi16)  = channels (j-1, j) of pixel row+1
                              : 0x05040100u;  // (mine.lo16, partner.lo16)  = channels (j, j+1) of pixel row
-    constexpr int PX = PLANAR ? 16 : 128;
-    char* base_lo = base + (PLANAR ? lo_off : 64);
+    constexpr int PX = 16;
+    char* base_lo = base + lo_off;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         const f32x2 v = belu2_fused(split_value(f32x2{accm[r], accm[r + 1]}, f32x2{accx[r], accx[r + 1]}), beta);  // (the bias is in accm: see split_value)
@@ -275,22 +268,16 @@ __device__ __forceinline__ void store_belu_quad_split(char* base, const f32x4& a
 }
 
 // Where lane i (channel pair (i & ~1, i | 1)) of pixel-row group h writes: the address of pixel x = x0 + 4 h + (i & 1) of map row y.
-template <int PREC>
 __device__ __forceinline__ char* split_store_base(float* dst, size_t n, long img_stride, long y, int pitch, int x, int i) {
-    if constexpr (kPlanar<PREC>)
-        return (char*)(dst + (n * img_stride + y * pitch) * 32) + ((size_t)(i >> 3) * pitch + x) * 16 + ((i & 7) >> 1) * 4;
-    else
-        return (char*)(dst + (n * img_stride + y * pitch + x) * 32) + (i & ~1) * 2;
+    return (char*)(dst + (n * img_stride + y * pitch) * 32) + ((size_t)(i >> 3) * pitch + x) * 16 + ((i & 7) >> 1) * 4;
 }
-template <int PREC>
 __device__ __forceinline__ void store_belu_tile_split(char* base, const f32x16& accm, const f32x16& accx,
                                                       float beta, bool odd, int pitch, uint32_t& dom) {
-    store_belu_tile_split_t<false, kPlanar<PREC>>(base, accm, accx, beta, odd, 0, (long)pitch * 64, dom);
+    store_belu_tile_split_t<false>(base, accm, accx, beta, odd, 0, (long)pitch * 64, dom);
 }
-template <int PREC>
 __device__ __forceinline__ void store_belu_tile_split_masked(char* base, const f32x16& accm, const f32x16& accx,
                                                              float beta, bool odd, int limit, int pitch, uint32_t& dom) {
-    store_belu_tile_split_t<true, kPlanar<PREC>>(base, accm, accx, beta, odd, limit, (long)pitch * 64, dom);
+    store_belu_tile_split_t<true>(base, accm, accx, beta, odd, limit, (long)pitch * 64, dom);
 }
 
 // Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`
@@ -317,7 +304,7 @@ __device__ __forceinline__ const char* uniform_ptr(const void* p) {
 // kernel row the 5 taps x 3 channels are 15 CONSECUTIVE floats from pixel i on, so K is packed per kernel row:
 // 15 -> 16 slots = 8 MFMAs (K = 2 each) instead of 5 taps x (3 -> 4 channels) = 10.  40 MFMAs per tile row.
 // ---------------------------------------------------------------------------
-template <int TH, bool IMG_U8, int PREC>
+template <int TH, bool IMG_U8>
 __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     constexpr int T = TH / 4;
     constexpr int TWH = kTW + 4, THH = TH + 4, NPIX = THH * TWH;
@@ -341,7 +328,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     __shared__ float s_lut[256];
     if constexpr (IMG_U8) s_lut[tid] = __fdiv_rn((float)tid, 255.0f);
     const float bias = a.bias[i], beta = a.beta[i];
-    uint32_t dom = 0;  // split-half mode: the largest hi half this thread has produced (domain_track)
   for (int bid = blockIdx.x; bid < a.n_tiles; bid += gridDim.x) {
     const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
     const int ty = tile_div(t, a.div_tx), tx = t - ty * a.tiles_x;
@@ -379,7 +365,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
 #pragma unroll
     for (int m = 0; m < T; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = PREC == 1 ? bias : 0.f;  // (split-half map: the bias rides in the accumulator, see split_value)
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
     const float* xa = s_x + ((wave * T) * TWH + i) * 3 + h;   // slot k = 2 j + h of pixel i's kernel row
     const float* wb = s_w + (h * 32 + i) * 2;
@@ -405,37 +391,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
     for (int m = 0; m < T; ++m) {
         const int y = y0 + wave * T + m;
         if (y >= a.y_end) continue;
-        if constexpr (PREC == 0) {
-            float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
-            if (full_x) {
-                store_belu_tile(base, acc[m], bias, beta);
-            } else {
-                for_each_acc_row([&](int r, int row) {
-                    if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
-                });
-            }
+        float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
+        if (full_x) {
+            store_belu_tile(base, acc[m], bias, beta);
         } else {
-            // split-half map; the row pitch is a multiple of 32 px (+4), so the partial
-            // last tile column may be written in full: the overhang lands in the zero
-            // border's columns >= W... which must stay zero -> mask by zeroing instead
-            f32x16 zero, am = acc[m];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-            char* base = split_store_base<PREC>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
-            if (full_x) {
-                store_belu_tile_split<PREC>(base, am, zero, beta, i & 1, a.pitch, dom);
-            } else {
-                store_belu_tile_split_masked<PREC>(base, am, zero, beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
-            }
+            for_each_acc_row([&](int r, int row) {
+                if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias), beta);
+            });
         }
     }
   }
-    if constexpr (PREC == 1) domain_report(dom, a.domain);
 }
 
 // ---------------------------------------------------------------------------
-// Stage 0 of the split-half mode, on the f16 matrix cores.  conv0_kernel<.., PREC = 1> computes exact f32 products on the vector ALU's
-// MFMA (80 per tile and wave = 5 120 cycles) and then pays BeLU + the hi / lo split of 32 outputs per input pixel on the same pipe:
+// Stage 0 of the split-half mode, on the f16 matrix cores.  Until round 5 this mode ran conv0_kernel too: exact f32 products on the
+// vector ALU's MFMA (80 per tile and wave = 5 120 cycles), then BeLU + the hi / lo split of 32 outputs per input pixel on the same pipe:
 // 0.144 ms at 1080p, 9 % of the split-half frame (0.107 ms in the exact mode, whose epilogue is shorter).  Here the image tile is
 // split into halves once while it is staged ([pixel][R G B 0] as hi halves and as lo halves; a byte goes through a table of
 // split(byte / 255)), K runs over tap * 4 + channel (100 slots -> 7 K-blocks of 16; the 25 slots of the padding channel and the last
@@ -443,9 +413,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv0_kernel(Conv0Args a) {
 // cycles that run beside the epilogue's vector work instead of in front of it.  The weights (7 x (hi, lo) fragments, 14 KB) sit in LDS
 // for every tile the workgroup walks.  Same products as every other stage of this mode: hi.hi + (hi.lo + lo.hi) / 2048.
 // ---------------------------------------------------------------------------
-#ifndef SR_CONV0_SPLIT_MFMA
-#define SR_CONV0_SPLIT_MFMA 1
-#endif
 template <int TH, bool IMG_U8>
 __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
     constexpr int T = TH / 4;
@@ -539,9 +506,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
         for (int m = 0; m < T; ++m) {
             const int y = y0 + wave * T + m;
             if (y >= a.y_end) continue;
-            char* base = split_store_base<1>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
-            if (full_x) store_belu_tile_split<1>(base, accm[m], accx[m], beta, i & 1, a.pitch, dom);
-            else store_belu_tile_split_masked<1>(base, accm[m], accx[m], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
+            char* base = split_store_base(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
+            if (full_x) store_belu_tile_split(base, accm[m], accx[m], beta, i & 1, a.pitch, dom);
+            else store_belu_tile_split_masked(base, accm[m], accx[m], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
         }
     }
     domain_report(dom, a.domain);
@@ -704,12 +671,56 @@ __device__ __forceinline__ void ring_advance(int& gtap, int& slot, int ntaps_tot
 // of the next step right after the barrier, under the last group; split (12 MFMAs = ~400 cycles per step, one
 // LDS round trip) requests the whole next step's operands before this step's MFMAs.
 // ---------------------------------------------------------------------------
-template <int TWH, int PS, int KS, int T, int NTN, typename Stream>
-__device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[NTN * T], const char* hb, const char* ring, Stream& sm, int wave, int lane) {
+//
+// QUAD (round 6; the last stage of the exact mode, 8-row tiles): the same steps on v_mfma_f32_4x4x1_16B_f32.  The last stage has 27
+// output channels; on 32x32x2 its N is 32 and 5 columns of every instruction are padding.  The 4x4x1 instruction is sixteen 4x4 outer
+// products (2 passes, the same 64 FLOP per cycle and SIMD) and with CBSZ = 4 the A operand of block ABID is broadcast to all sixteen:
+//     D[lane 4 b + j][register i] += A[lane 4 ABID + i] * B[lane 4 b + j]
+// A = the weight fragment exactly as the 32x32x2 loop reads it (lane (h, j) = output slot j, four channels of k-quad h -- so ONE
+// register serves every slot group: ABID = 8 h + g picks slots 4 g .. 4 g + 3 of k-quad h), B = pixels (lane = pixel: lanes 0-31 the
+// wave's first tile row, 32-63 its second; one ds_read_b128 per k-quad), and a k-step of 64 pixels x 28 slots is 7 instructions instead
+// of the 8 instruction-equivalents of N = 32.  Same weight chunks, same LDS traffic (one weight read + two pixel reads per 8 k), and a
+// LANE ends up holding every channel of ITS pixel: depth-to-space and the RGBA packing are lane-local (stage_epilogue_quad).
+// The instruction chain per output is the very fmaf chain of the 32x32x2 form -- k-quad 0 then k-quad 1 of each e, as that
+// instruction sums its k = h pair -- so the two forms are bit-identical (scripts/experiments/ubench_mfma4x4.hip checks the chain
+// against the host's fmaf; every pipe == first form == band test checks the kernels): 4-row tiles and the first kernel form keep 32x32x2.
+// Measured in the step loop's structure (profiles/r6_ubench_mfma4x4.txt): 139.6 TFLOP/s issued against 144.8 for 32x32x2, on 7 / 8 of
+// the work.
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma_quad(float w, float p, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(w, p, c, 4, ABID, 0); }
+// slot groups of N-tile nt that carry expand channels (slot of a channel: sr_api.cpp expand_channel -- triples never straddle a 16-slot row)
+template <int FACTOR>
+constexpr int quad_groups(int nt) {
+    const int ntr = FACTOR * FACTOR - 10 * nt < 10 ? FACTOR * FACTOR - 10 * nt : 10, tl = ntr - 1;
+    return (16 * (tl / 5) + 3 * (tl % 5) + 2) / 4 + 1;
+}
+typedef f32x4 QuadAcc[8];  // one N-tile: register i of group g = slot 4 g + i of the lane's pixel
+// one k of k-quad H onto the first NG slot groups
+template <int H, int NG>
+__device__ __forceinline__ void quad_rank1(QuadAcc& acc, float w, float p) {
+    if constexpr (NG > 0) acc[0] = mfma_quad<8 * H + 0>(w, p, acc[0]);
+    if constexpr (NG > 1) acc[1] = mfma_quad<8 * H + 1>(w, p, acc[1]);
+    if constexpr (NG > 2) acc[2] = mfma_quad<8 * H + 2>(w, p, acc[2]);
+    if constexpr (NG > 3) acc[3] = mfma_quad<8 * H + 3>(w, p, acc[3]);
+    if constexpr (NG > 4) acc[4] = mfma_quad<8 * H + 4>(w, p, acc[4]);
+    if constexpr (NG > 5) acc[5] = mfma_quad<8 * H + 5>(w, p, acc[5]);
+    if constexpr (NG > 6) acc[6] = mfma_quad<8 * H + 6>(w, p, acc[6]);
+    if constexpr (NG > 7) acc[7] = mfma_quad<8 * H + 7>(w, p, acc[7]);
+}
+template <int FACTOR, int H>
+__device__ __forceinline__ void quad_rank1_tile(QuadAcc& acc, int nt, float w, float p) {  // nt: constant after unrolling
+    if (nt == 0) quad_rank1<H, quad_groups<FACTOR>(0)>(acc, w, p);
+    else quad_rank1<H, quad_groups<FACTOR>(1)>(acc, w, p);
+}
+
+template <int TWH, int PS, int KS, int T, int NTN, bool QUAD = false, int FACTOR = 3, typename Acc, typename Stream>
+__device__ __forceinline__ void half_steps_f32(Acc& acc, const char* hb, const char* ring, Stream& sm, int wave, int lane) {
     constexpr int NT = KS * KS, NP = (NT + 1) / 2;
+    static_assert(!QUAD || T == 2, "the quad form: 64 pixels = two tile rows per wave");
     const int i = lane & 31, h = lane >> 5;
     const int wlane = (h * 32 + i) * 16;
-    const char* abase = hb + h * PS + ((wave * T) * TWH + i) * 16;
+    // 32x32x2: lane (h, i) = pixel i of the wave's tile rows, k = h: plane h of the pair.  Quad: lane (h, i) = pixel i of tile row h, both planes.
+    const char* abase = QUAD ? hb + ((wave * T + h) * TWH + i) * 16 : hb + h * PS + ((wave * T) * TWH + i) * 16;
     struct Ops { f32x4 a[T]; f32x4 b; };
     // operand group q of pair p: q = 2 * tapslot + rr  (rr: which 8 of the half's 16 channels)
     auto load = [&](Ops& o, int p, int q, int sl) {
@@ -717,14 +728,22 @@ __device__ __forceinline__ void half_steps_f32(f32x16 (&acc)[NTN * T], const cha
         const char* ab = abase + (q & 1) * 2 * PS + (ky * TWH + kx) * 16;
         o.b = *(const f32x4*)(ring + sl * 4096 + wlane + q * 1024);
 #pragma unroll
-        for (int m = 0; m < T; ++m) o.a[m] = *(const f32x4*)(ab + m * TWH * 16);
+        for (int m = 0; m < T; ++m) o.a[m] = *(const f32x4*)(ab + (QUAD ? m * PS : m * TWH * 16));  // (quad: a[m] = k-quad m)
     };
     auto mfma = [&](const Ops& o, int nt) {
+        if constexpr (QUAD) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
+                quad_rank1_tile<FACTOR, 0>(acc[nt], nt, o.b[e], o.a[0][e]);
+                quad_rank1_tile<FACTOR, 1>(acc[nt], nt, o.b[e], o.a[1][e]);
+            }
+        } else {
 #pragma unroll
-            for (int m = 0; m < T; ++m)
-                acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[m][e], o.b[e], acc[nt * T + m], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < T; ++m)
+                    acc[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[m][e], o.b[e], acc[nt * T + m], 0, 0, 0);
+        }
     };
     Ops cur, nxt;
     load(cur, 0, 0, sm.slot());
@@ -1041,6 +1060,32 @@ __device__ __forceinline__ void lin_mfma(f32x16 (&acc)[NTN * T], const float* s_
     }
 }
 
+// ... and in the quad form (half_steps_f32 QUAD): the lane's own pixel [R G B 0] in one ds_read_b128, the weight pair as lin_mfma reads it
+// (lane (h, j): colours 2 h, 2 h + 1 of slot j).  lin_mfma's chain per output and tap is colour 0, 2 (its first instruction, k = h), 1, 3;
+// colour 3 is the zero channel under a zero weight -- fma(0, 0, acc) = acc for every acc but -0, which a chain that starts at +0 never
+// holds -- and is skipped here.
+template <int NTN, int FACTOR>
+__device__ __forceinline__ void lin_mfma_quad(QuadAcc (&acc)[NTN], const float* s_x, const float* s_w, int wave, int lane) {
+    constexpr int TWH = kTW + 2;
+    const int i = lane & 31, h = lane >> 5;
+    const float* xa = s_x + ((wave * 2 + h) * TWH + i) * 4;
+    const float* wb = s_w + lane * 2;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const f32x4 px = *(const f32x4*)(xa + (ky * TWH + kx) * 4);
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                const f32x2 b = *(const f32x2*)(wb + ((ky * 3 + kx) * NTN + nt) * 128);
+                quad_rank1_tile<FACTOR, 0>(acc[nt], nt, b.x, px.x);
+                quad_rank1_tile<FACTOR, 1>(acc[nt], nt, b.x, px.z);
+                quad_rank1_tile<FACTOR, 0>(acc[nt], nt, b.y, px.y);
+            }
+        }
+    }
+}
+
 // The same residual in the split-half mode, on the f16 matrix cores (round 5: on the f32 MFMA of the vector ALU the nine taps were
 // 9.7 % of this mode's last stage, profiles/r5_ab_nolin.txt).  The phase weights of LinearInterp x f are products of multiples of
 // 1 / (2 f), so (2 f)^2 times a weight is a small INTEGER, exact in a half: the staged pixels are divided by (2 f)^2 once (and split
@@ -1165,9 +1210,9 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
                     });
                 }
             } else {
-                    char* base = split_store_base<PREC>(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
-                if (full_x) store_belu_tile_split<PREC>(base, acc[m], accx[m], beta, i & 1, a.pitch, dom);  // (bias: in the accumulators' initial value)
-                else store_belu_tile_split_masked<PREC>(base, acc[m], accx[m], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
+                char* base = split_store_base(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
+                if (full_x) store_belu_tile_split(base, acc[m], accx[m], beta, i & 1, a.pitch, dom);  // (bias: in the accumulators' initial value)
+                else store_belu_tile_split_masked(base, acc[m], accx[m], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
             }
         }
     } else {
@@ -1253,6 +1298,67 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
                         }
                     }
                 }
+            }
+        }
+    }
+}
+
+// ... of a tile computed in the quad form: the lane holds every expand channel of ITS pixel (x0 + lane % 32, tile row 2 wave + lane / 32),
+// channel (triple tr = dy f + dx, colour c) in slot 16 (tl / 5) + 3 (tl % 5) + c of N-tile tr / 10, tl = tr % 10.  Same arithmetic per
+// value as stage_epilogue (so the same bits); the f sub-pixels of an output row are contiguous in the lane (RGBA: f dwords, f32: 3 f
+// floats) and consecutive lanes continue the row, every store inside one lane-masked region.
+template <int NTN, bool OUT_U8, int FACTOR>
+__device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc (&acc)[NTN], int n, int x0, int y0, int wave, int lane) {
+    const int x = x0 + (lane & 31), y = y0 + wave * 2 + (lane >> 5);
+    const int OW = a.W * FACTOR, h_band = a.y_end - a.y_begin;
+    const float* __restrict__ bias = a.bias;  // wave-uniform, constant indices: scalar loads
+    struct __attribute__((packed, aligned(4))) RowU8 { uint32_t px[FACTOR]; };
+    struct __attribute__((packed, aligned(4))) RowF32 { float v[3 * FACTOR]; };
+    if (x < a.W && y < a.y_end) {
+        const size_t orow = ((size_t)n * h_band + (size_t)(y - a.y_begin)) * FACTOR;
+#pragma unroll
+        for (int dy = 0; dy < FACTOR; ++dy) {
+            float v[3 * FACTOR + 1];
+#pragma unroll
+            for (int k = 0; k < 3 * FACTOR; ++k) {
+                const int tr = dy * FACTOR + k / 3, nt = tr / 10, tl = tr % 10, slot = 16 * (tl / 5) + 3 * (tl % 5) + k % 3;
+                v[k] = acc[nt][slot >> 2][slot & 3];
+            }
+            v[3 * FACTOR] = 0.f;
+            const size_t opx = (orow + dy) * OW + (size_t)x * FACTOR;
+            if constexpr (!OUT_U8) {
+                RowF32 o;
+#pragma unroll
+                for (int k = 0; k < 3 * FACTOR; k += 2) {
+                    const int tr0 = dy * FACTOR + k / 3, tr1 = dy * FACTOR + (k + 1) / 3;
+                    const int s0 = 16 * ((tr0 % 10) / 5) + 3 * ((tr0 % 10) % 5) + k % 3, s1 = 16 * ((tr1 % 10) / 5) + 3 * ((tr1 % 10) % 5) + (k + 1) % 3;
+                    const f32x2 b2 = {bias[(tr0 / 10) * 32 + s0], k + 1 < 3 * FACTOR ? bias[(tr1 / 10) * 32 + s1] : 0.f};
+                    const f32x2 s = f32x2{v[k], v[k + 1]} + b2;
+                    o.v[k] = s.x;
+                    if (k + 1 < 3 * FACTOR) o.v[k + 1] = s.y;
+                }
+                *(RowF32*)((float*)a.out + opx * 3) = o;
+            } else {
+                // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255 -- v_cvt_pk_u8_f32 of the floor (see stage_epilogue)
+                RowU8 o;
+                float q[3 * FACTOR + 1];
+#pragma unroll
+                for (int k = 0; k < 3 * FACTOR; k += 2) {
+                    const int tr0 = dy * FACTOR + k / 3, tr1 = dy * FACTOR + (k + 1) / 3;
+                    const int s0 = 16 * ((tr0 % 10) / 5) + 3 * ((tr0 % 10) % 5) + k % 3, s1 = 16 * ((tr1 % 10) / 5) + 3 * ((tr1 % 10) % 5) + (k + 1) % 3;
+                    const f32x2 b2 = {bias[(tr0 / 10) * 32 + s0], k + 1 < 3 * FACTOR ? bias[(tr1 / 10) * 32 + s1] : 0.f};
+                    const f32x2 s = (f32x2{v[k], v[k + 1]} + b2) * f32x2{255.0f, 255.0f} + f32x2{0.5f, 0.5f};
+                    q[k] = floorf(s.x); q[k + 1] = floorf(s.y);
+                }
+#pragma unroll
+                for (int dx = 0; dx < FACTOR; ++dx) {
+                    uint32_t w = 0xff000000u;
+                    w = __builtin_amdgcn_cvt_pk_u8_f32(q[3 * dx + 0], 0u, w);
+                    w = __builtin_amdgcn_cvt_pk_u8_f32(q[3 * dx + 1], 1u, w);
+                    w = __builtin_amdgcn_cvt_pk_u8_f32(q[3 * dx + 2], 2u, w);
+                    o.px[dx] = w;
+                }
+                *(RowU8*)((uint32_t*)a.out + opx) = o;
             }
         }
     }
@@ -1843,6 +1949,15 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { qm[m][k >> 1][k & 1] = f32x4{bias2[k & 1], bias2[k & 1], bias2[k & 1], bias2[k & 1]}; qx[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
+        // the exact mode's last stage, 8-row tiles: 4x4x1 MFMAs, the lane's own pixel in 4-slot groups (half_steps_f32 QUAD)
+        constexpr bool QUAD = FINAL && PREC == 0 && T == 2;
+        QuadAcc qa[QUAD ? NTN : 1];
+        if constexpr (QUAD) {
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+                for (int g = 0; g < 8; ++g) qa[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // (local to the tile ON PURPOSE: the registers the asynchronous atomic / load return into must not be live across the
         // tile loop's merge of the two tile bodies -- the compiler then copies them right after the asm statement, i.e. before
         // the data has arrived; it cannot know these asm outputs land later)
@@ -1883,7 +1998,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             constexpr int GS0 = H16 ? (src == 0 ? 0 : KS0 * KS0 + (src - 1) * 9) + (j & 1) * PAIRS_J
                                     : (j == 0 ? 0 : j == 1 ? H0::STEPS : 2 * H0::STEPS + (j - 2) * H3::STEPS) * NTN;
             PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring_lds, wbase, GS0, wave, lane, (j == 0 && !single) ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0};
-            if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN>(acc, hb, ring, sm, wave, lane);
+            if constexpr (QUAD) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN, true, FACTOR>(qa, hb, ring, sm, wave, lane);
+            else if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN>(acc, hb, ring, sm, wave, lane);
             else if constexpr (H16) half_steps_h16<GJ::TWH, GJ::PLANE, 2, KSJ, T, (j & 1) != 0, -HB>(qm, qx, hb, ring, sm, wave, lane);
             else half_steps_h<GJ::TWH, GJ::PLANE, 2, KSJ, T, NTN>(acc, accx, hb, ring, sm, wave, lane);
         };
@@ -1901,12 +2017,14 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if constexpr (PREC == 1) lin_mfma_h<TH, T, NTN>(acc, accx, (const char*)s_x, LIN_LO, (const f16x8*)s_wlin, wave, lane);
+            else if constexpr (QUAD) lin_mfma_quad<NTN, FACTOR>(qa, s_x, s_wlin, wave, lane);
             else lin_mfma<TH, T, NTN>(acc, s_x, s_wlin, wave, lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
             asm volatile("" ::: "memory");
         }
         if constexpr (H16) stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
+        else if constexpr (QUAD) stage_epilogue_quad<NTN, OUT_U8, FACTOR>(a, qa, n, x0, y0, wave, lane);
         else stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
     };
 
@@ -1968,9 +2086,6 @@ __global__ __launch_bounds__(256) void clear_borders_kernel(ClearArgs a) {
     for (long q = (base + kFeatPad + a.W) * 8 + threadIdx.x; q < end * 8; q += 256) m[q] = z;
 }
 
-bool sr_split_maps_planar() { return kPlanar<1>; }
-bool sr_split_stages_mfma16() { return kH16<1, false>; }
-
 hipError_t sr_launch_clear_borders(const ClearArgs& a, hipStream_t s) {
     const long rows = (a.total_px + a.pitch - 1) / a.pitch;
     hipLaunchKernelGGL(clear_borders_kernel, dim3((unsigned)rows, 4), dim3(256), 0, s, a);
@@ -1985,12 +2100,12 @@ static constexpr size_t stage_lds_bytes() {
     return 8 * (size_t)TileGeom<TH, KS0>::PLANE + kRingBytes;
 }
 
-template <int TH, int PREC>
+template <int TH>
 static hipError_t launch_conv0_t(const Conv0Args& a, int nblk, bool img_u8, hipStream_t s) {
     if (img_u8)
-        hipLaunchKernelGGL((conv0_kernel<TH, true, PREC>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((conv0_kernel<TH, true>), dim3(nblk), dim3(kThreads), 0, s, a);
     else
-        hipLaunchKernelGGL((conv0_kernel<TH, false, PREC>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((conv0_kernel<TH, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 
@@ -2004,9 +2119,8 @@ static hipError_t launch_conv0_split_t(const Conv0Args& a, int nblk, bool img_u8
 }
 
 hipError_t sr_launch_conv0(const Conv0Args& a, int th, int prec, int nblk, bool img_u8, hipStream_t s) {
-    if (prec == 0) return th == 8 ? launch_conv0_t<8, 0>(a, nblk, img_u8, s) : launch_conv0_t<4, 0>(a, nblk, img_u8, s);
-    if (SR_CONV0_SPLIT_MFMA && kPlanar<1>) return th == 8 ? launch_conv0_split_t<8>(a, nblk, img_u8, s) : launch_conv0_split_t<4>(a, nblk, img_u8, s);
-    return th == 8 ? launch_conv0_t<8, 1>(a, nblk, img_u8, s) : launch_conv0_t<4, 1>(a, nblk, img_u8, s);
+    if (prec == 0) return th == 8 ? launch_conv0_t<8>(a, nblk, img_u8, s) : launch_conv0_t<4>(a, nblk, img_u8, s);
+    return th == 8 ? launch_conv0_split_t<8>(a, nblk, img_u8, s) : launch_conv0_split_t<4>(a, nblk, img_u8, s);
 }
 
 // The > 64 KB dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is a property of a (kernel, device)
