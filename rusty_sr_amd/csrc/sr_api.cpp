@@ -674,7 +674,9 @@ int StackJob::prepare() {
             // profiles/r4_fork_tail.jsonl: the tail now also pays where round 3 excluded it, above 14 rounds with a nearly full last round
             // (1920x1080 undivided: 4.066 -> 4.052 ms); but NOT in the two bands of a forked call, whose launches run side by side and
             // end staggered anyway: 1920x1080 4.048 -> 4.018, 1600x900 2.853 -> 2.825, 1280x720 1.841 -> 1.834 ms without it)
-            if (tail < 0.0f) tail = (!split && rounds >= 3.0 && !forked) ? 1.0f : 0.0f;
+            // (round 6: not in the exact mode's last stage either -- its 8-row tiles run on 4x4x1 MFMAs with 28 output columns, its 4-row
+            // tiles still on 32x32x2 with 32, code the launch would otherwise never touch: 0.7775 -> 0.7695 ms at 1080p, profiles/r6_ab_quad.txt)
+            if (tail < 0.0f) tail = (!split && rounds >= 3.0 && !forked && st != 4) ? 1.0f : 0.0f;
             if (tail > 0.0f) {
                 const long per_row = (long)n * tiles_x;
                 const int want = (int)((tail * resident + per_row - 1) / per_row);  // tile rows of small tiles

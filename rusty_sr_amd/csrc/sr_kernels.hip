@@ -1308,16 +1308,20 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
 // value as stage_epilogue (so the same bits); the f sub-pixels of an output row are contiguous in the lane (RGBA: f dwords, f32: 3 f
 // floats) and consecutive lanes continue the row, every store inside one lane-masked region.
 template <int NTN, bool OUT_U8, int FACTOR>
-__device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc (&acc)[NTN], int n, int x0, int y0, int wave, int lane) {
+__device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc (&acc)[NTN], const float (&bias)[3 * FACTOR * FACTOR], int n, int x0, int y0,
+                                                    int wave, int lane) {
     const int x = x0 + (lane & 31), y = y0 + wave * 2 + (lane >> 5);
     const int OW = a.W * FACTOR, h_band = a.y_end - a.y_begin;
-    const float* __restrict__ bias = a.bias;  // wave-uniform, constant indices: scalar loads
     struct __attribute__((packed, aligned(4))) RowU8 { uint32_t px[FACTOR]; };
     struct __attribute__((packed, aligned(4))) RowF32 { float v[3 * FACTOR]; };
+    constexpr int OPX = OUT_U8 ? 4 : 12;  // bytes per output pixel
+    // output row of the wave's first tile row, sub-row 0, at the tile's first column: wave-uniform (scalar ALU); the lane adds its tile row and column
+    char* wbase = (char*)a.out + (((size_t)n * h_band + (size_t)(y0 + wave * 2 - a.y_begin)) * FACTOR * OW + (size_t)x0 * FACTOR) * OPX;
+    const uint32_t loff = ((uint32_t)(lane >> 5) * FACTOR * OW + (uint32_t)(lane & 31) * FACTOR) * OPX;
     if (x < a.W && y < a.y_end) {
-        const size_t orow = ((size_t)n * h_band + (size_t)(y - a.y_begin)) * FACTOR;
 #pragma unroll
         for (int dy = 0; dy < FACTOR; ++dy) {
+            char* obase = wbase + (size_t)dy * OW * OPX;
             float v[3 * FACTOR + 1];
 #pragma unroll
             for (int k = 0; k < 3 * FACTOR; ++k) {
@@ -1325,28 +1329,23 @@ __device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc 
                 v[k] = acc[nt][slot >> 2][slot & 3];
             }
             v[3 * FACTOR] = 0.f;
-            const size_t opx = (orow + dy) * OW + (size_t)x * FACTOR;
             if constexpr (!OUT_U8) {
                 RowF32 o;
 #pragma unroll
                 for (int k = 0; k < 3 * FACTOR; k += 2) {
-                    const int tr0 = dy * FACTOR + k / 3, tr1 = dy * FACTOR + (k + 1) / 3;
-                    const int s0 = 16 * ((tr0 % 10) / 5) + 3 * ((tr0 % 10) % 5) + k % 3, s1 = 16 * ((tr1 % 10) / 5) + 3 * ((tr1 % 10) % 5) + (k + 1) % 3;
-                    const f32x2 b2 = {bias[(tr0 / 10) * 32 + s0], k + 1 < 3 * FACTOR ? bias[(tr1 / 10) * 32 + s1] : 0.f};
+                    const f32x2 b2 = {bias[dy * 3 * FACTOR + k], k + 1 < 3 * FACTOR ? bias[dy * 3 * FACTOR + k + 1] : 0.f};
                     const f32x2 s = f32x2{v[k], v[k + 1]} + b2;
                     o.v[k] = s.x;
                     if (k + 1 < 3 * FACTOR) o.v[k + 1] = s.y;
                 }
-                *(RowF32*)((float*)a.out + opx * 3) = o;
+                *(RowF32*)(obase + loff) = o;
             } else {
                 // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255 -- v_cvt_pk_u8_f32 of the floor (see stage_epilogue)
                 RowU8 o;
                 float q[3 * FACTOR + 1];
 #pragma unroll
                 for (int k = 0; k < 3 * FACTOR; k += 2) {
-                    const int tr0 = dy * FACTOR + k / 3, tr1 = dy * FACTOR + (k + 1) / 3;
-                    const int s0 = 16 * ((tr0 % 10) / 5) + 3 * ((tr0 % 10) % 5) + k % 3, s1 = 16 * ((tr1 % 10) / 5) + 3 * ((tr1 % 10) % 5) + (k + 1) % 3;
-                    const f32x2 b2 = {bias[(tr0 / 10) * 32 + s0], k + 1 < 3 * FACTOR ? bias[(tr1 / 10) * 32 + s1] : 0.f};
+                    const f32x2 b2 = {bias[dy * 3 * FACTOR + k], k + 1 < 3 * FACTOR ? bias[dy * 3 * FACTOR + k + 1] : 0.f};
                     const f32x2 s = (f32x2{v[k], v[k + 1]} + b2) * f32x2{255.0f, 255.0f} + f32x2{0.5f, 0.5f};
                     q[k] = floorf(s.x); q[k + 1] = floorf(s.y);
                 }
@@ -1358,7 +1357,7 @@ __device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc 
                     w = __builtin_amdgcn_cvt_pk_u8_f32(q[3 * dx + 2], 2u, w);
                     o.px[dx] = w;
                 }
-                *(RowU8*)((uint32_t*)a.out + opx) = o;
+                *(RowU8*)(obase + loff) = o;
             }
         }
     }
@@ -1808,7 +1807,8 @@ __device__ __forceinline__ void queue_publish(const StageArgs& a, int xcd, int w
 
 // Stream of the pipe form: chunks through the ring with sequence-numbered waits, plus a piece of the next half
 // tile in each of the first steps; the first half of a tile also publishes the next tile's number.
-template <int PREC, int KSN>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int PREC, int KSN, typename Hook = NoHook>
 struct PipeStream {
     StepStream& st;
     const HalfRequest& rq;
@@ -1823,6 +1823,7 @@ struct PipeStream {
     QueueState& qs;
     int snap_step;          // half 0: the step at which the queue's answer is looked at
     int step_no;
+    Hook last_step_hook;    // runs in front of the barrier that ends the half's last step (final stage: the bilinear taps' image tile goes to LDS)
     __device__ __forceinline__ void begin_step() {
         step_request(st, gs0 + step_no, ring_lds, wbase, lane);
         if (mailbox && step_no == snap_step) queue_presolve(a, xcd, wave, lane, st, qs);
@@ -1837,6 +1838,7 @@ struct PipeStream {
     }
     __device__ __forceinline__ int slot() const { return st.slot; }
     template <int EXTRA> __device__ __forceinline__ void end_step(bool last) {
+        if (last) last_step_hook();
         if (last && mailbox) queue_publish(a, xcd, wave, lane, st, qs, mailbox);
         step_advance<EXTRA>(st, last);
     }
@@ -1856,8 +1858,14 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem + 2 * HB;
     volatile int* s_next = (volatile int*)(ring + kRingBytes);
-    float* s_wlin = (float*)(ring + kRingBytes + 16);  // final stage: the 9 x 128 fixed weights of the bilinear taps, loaded once
-    float* s_lut = s_wlin + 9 * 2 * 128;               // final stage, u8 input: byte / 255 (img_to_data, a true division) for every byte value
+    float* s_wlin = (float*)(ring + kRingBytes + 16);  // final stage: the 9 x 128 fixed weights of the bilinear taps per N-tile, loaded once
+    float* s_lut = s_wlin + 9 * NTN * 128;             // final stage, u8 input: byte / 255 (img_to_data, a true division) for every byte value
+    // final stage, one N-tile: the image tile of the bilinear taps has LDS of its own (round 6).  It used to go into the half-tile buffer the
+    // last half had just left -- a barrier in front of the taps (the buffer's last readers) and one behind them (the next tile's second
+    // half lands there).  With a region nothing else uses it is written in the tile's LAST step, in front of that step's own barrier, and
+    // read behind it: no barrier of its own, and the next tile's write is a whole tile of barriers away from this tile's reads.
+    constexpr bool kLinOwn = FINAL && NTN == 1;
+    float* s_xown = s_lut + 256;
     const uint32_t lds0 = lds_addr(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1874,6 +1882,18 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     // (kH16: lane l holds output channels (l & 15) and 16 + (l & 15))
     const float bias2[2] = {H16 ? a.bias[lane & 15] : 0.f, H16 ? a.bias[16 + (lane & 15)] : 0.f};
     const float beta2[2] = {H16 ? a.beta[lane & 15] : 0.f, H16 ? a.beta[16 + (lane & 15)] : 0.f};
+    // (quad form of the exact mode's last stage: a lane holds every channel of its pixel, so it needs every channel's bias -- wave-uniform
+    // values kept in vector registers for the whole launch; loaded per tile they came through the vector memory path, whose waits sat out
+    // the next tile's DMAs)
+    constexpr bool kQuad = FINAL && PREC == 0;
+    float qbias[kQuad ? 3 * FACTOR * FACTOR : 1];
+    if constexpr (kQuad) {
+#pragma unroll
+        for (int ch = 0; ch < 3 * FACTOR * FACTOR; ++ch) {
+            const int tr = ch / 3, tl = tr % 10;
+            qbias[ch] = a.bias[(tr / 10) * 32 + 16 * (tl / 5) + 3 * (tl % 5) + ch % 3];
+        }
+    }
     H0 h0;
     H3 h3;
     h0.template init<PREC>(a.pitch, lane);
@@ -1997,7 +2017,15 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
             constexpr int STEPS_J = H16 ? PAIRS_J + (j & 1) : HalfTile<KSJ>::STEPS * NTN;
             constexpr int GS0 = H16 ? (src == 0 ? 0 : KS0 * KS0 + (src - 1) * 9) + (j & 1) * PAIRS_J
                                     : (j == 0 ? 0 : j == 1 ? H0::STEPS : 2 * H0::STEPS + (j - 2) * H3::STEPS) * NTN;
-            PipeStream<PREC, KSN> sm{st, rq, *htn, a, ring_lds, wbase, GS0, wave, lane, (j == 0 && !single) ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0};
+            constexpr int LIN_LO_J = LinPrefetch<IMG_U8, TH>::NPIX * 8;  // split-half mode: bytes from the hi halves of the image tile to its lo halves
+            auto lin_store = [&]() {  // (kLinOwn: the pixels requested at this half's start are long in; see s_xown)
+                if constexpr (kLinOwn && j == NH - 1) {
+                    if constexpr (PREC == 1) linpx.store_split((char*)s_xown, LIN_LO_J, (const uint32_t*)s_lut, 4.0f * FACTOR * FACTOR, tid, st);
+                    else linpx.store(s_xown, s_lut, tid, st);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the writes are in LDS before this wave reaches the step's barrier
+                }
+            };
+            PipeStream<PREC, KSN, decltype(lin_store)> sm{st, rq, *htn, a, ring_lds, wbase, GS0, wave, lane, (j == 0 && !single) ? s_next : nullptr, xcd, qs, STEPS_J > 3 ? STEPS_J - 3 : 0, 0, lin_store};
             if constexpr (QUAD) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN, true, FACTOR>(qa, hb, ring, sm, wave, lane);
             else if constexpr (PREC == 0) half_steps_f32<GJ::TWH, GJ::PLANE, KSJ, T, NTN>(acc, hb, ring, sm, wave, lane);
             else if constexpr (H16) half_steps_h16<GJ::TWH, GJ::PLANE, 2, KSJ, T, (j & 1) != 0, -HB>(qm, qx, hb, ring, sm, wave, lane);
@@ -2008,23 +2036,27 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         if constexpr (NH > 2) { do_half(std::integral_constant<int, 2>{}); do_half(std::integral_constant<int, 3>{}); }
         if constexpr (NH > 4) { do_half(std::integral_constant<int, 4>{}); do_half(std::integral_constant<int, 5>{}); }
         if constexpr (FINAL) {
-            // bilinear residual: the image tile goes into the buffer the last half has just left (buffer 1)
-            float* s_x = (float*)(smem + HB);
             constexpr int LIN_LO = LinPrefetch<IMG_U8, TH>::NPIX * 8;  // split-half mode: bytes from the hi halves of the tile to its lo halves
-            if constexpr (PREC == 1) linpx.store_split((char*)s_x, LIN_LO, (const uint32_t*)s_lut, 4.0f * FACTOR * FACTOR, tid, st);
-            else linpx.store(s_x, s_lut, tid, st);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            float* s_x = kLinOwn ? s_xown : (float*)(smem + HB);
+            if constexpr (!kLinOwn) {
+                // two N-tiles (factor 4): no LDS to spare -- the image tile goes into the buffer the last half has just left (buffer 1)
+                if constexpr (PREC == 1) linpx.store_split((char*)s_x, LIN_LO, (const uint32_t*)s_lut, 4.0f * FACTOR * FACTOR, tid, st);
+                else linpx.store(s_x, s_lut, tid, st);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
             if constexpr (PREC == 1) lin_mfma_h<TH, T, NTN>(acc, accx, (const char*)s_x, LIN_LO, (const f16x8*)s_wlin, wave, lane);
             else if constexpr (QUAD) lin_mfma_quad<NTN, FACTOR>(qa, s_x, s_wlin, wave, lane);
             else lin_mfma<TH, T, NTN>(acc, s_x, s_wlin, wave, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
-            asm volatile("" ::: "memory");
+            if constexpr (!kLinOwn) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // everybody is done with buffer 1 before the next tile's second half lands there
+                asm volatile("" ::: "memory");
+            }
         }
         if constexpr (H16) stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
-        else if constexpr (QUAD) stage_epilogue_quad<NTN, OUT_U8, FACTOR>(a, qa, n, x0, y0, wave, lane);
+        else if constexpr (QUAD) stage_epilogue_quad<NTN, OUT_U8, FACTOR>(a, qa, qbias, n, x0, y0, wave, lane);
         else stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
     };
 
@@ -2172,8 +2204,11 @@ static hipError_t launch_stage_t(int stage, int factor, const StageArgs& a, int 
 template <int PREC>
 static hipError_t launch_stage_pipe_t(int stage, int factor, const StageArgs& a, int grid, bool img_u8, bool out_u8, hipStream_t s) {
     constexpr size_t lds5 = 2 * (size_t)HalfTile<5>::BYTES + kRingBytes + 16;
-    constexpr size_t lds3 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 2 * 128 * sizeof(float) + 256 * sizeof(float);  // + bilinear weights (<= 2 N-tiles), byte / 255 table
-    static_assert(lds3 <= 80 * 1024, "two workgroups per CU");
+    // + bilinear weights per N-tile, byte / 255 table, and (one N-tile: factor 2, 3) the bilinear taps' own image tile of (8 + 2) x (32 + 2) pixels
+    constexpr size_t lds3_1 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 128 * sizeof(float) + 256 * sizeof(float) + 10 * 34 * 16;
+    constexpr size_t lds3_2 = 2 * (size_t)HalfTile<3>::BYTES + kRingBytes + 16 + 9 * 2 * 128 * sizeof(float) + 256 * sizeof(float);
+    static_assert(lds3_1 <= 80 * 1024 && lds3_2 <= 80 * 1024, "two workgroups per CU");
+    const size_t lds3 = factor == 4 ? lds3_2 : lds3_1;
     switch (stage) {
         case 1: return launch_with_lds(conv_stage_pipe_kernel<1, 5, false, false, false, PREC>, a, grid, lds5, s);
         case 2: return launch_with_lds(conv_stage_pipe_kernel<2, 5, false, false, false, PREC>, a, grid, lds5, s);
