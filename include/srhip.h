@@ -161,7 +161,10 @@ void sr_host_free(void* p);
  * other's fill; bit-identical): the call is still asynchronous and ordered on `stream` alone.  What that costs:
  * a second set of feature maps (each band's are half the size; should they not fit, the call runs undivided), and -- on its first
  * use -- one stream creation and the allocations, inside the call (sr_reserve_* of the same shape does both ahead of time).
- * After such a call sr_read_feature refuses (each workspace holds one band), as it does after a pipelined host call. */
+ * After such a call sr_read_feature refuses (each workspace holds one band), as it does after a pipelined host call.
+ * u8 device images are READ as whole aligned 32-bit words by the parameter-free graphs' kernels: up to 3 bytes in front of the
+ * image's first byte and behind its last one -- bytes of the same aligned word, hence of the same allocation granule -- may be
+ * read (never written, never used). */
 int sr_upscale_f32_dev(sr_ctx* ctx, const float* d_in, int n, int h, int w, float* d_out,
                        void* stream);
 int sr_upscale_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels, int n, int h, int w,
@@ -238,7 +241,10 @@ int sr_upscale_sharded_rgba8_all(sr_ctx* const* ctxs, int n, const uint8_t* cons
 enum sr_precision { SR_PRECISION_F32 = 0, SR_PRECISION_SPLIT_F16 = 1 };
 int sr_set_precision(sr_ctx* ctx, int mode);
 /* After the stream(s) of earlier *_dev calls have been synchronised: SR_E_DOMAIN if any of them left the domain of
- * SR_PRECISION_SPLIT_F16 since the last check (the fault is cleared), else SR_OK.  Always SR_OK in SR_PRECISION_F32. */
+ * SR_PRECISION_SPLIT_F16 since the last check (the fault is cleared), else SR_OK.  No call made in SR_PRECISION_F32 raises a
+ * fault; one left by earlier split-mode calls is kept -- across sr_set_precision and across host-pointer calls, which neither
+ * report nor act on it -- until it is checked.  (A host-pointer call over several contexts recomputes per context: only the
+ * contexts whose rows left the domain return f32-mode rows; both modes meet the same 1e-4 bar.) */
 int sr_check_domain(sr_ctx* ctx);
 
 /* (A/B tuning switches that change no result bit, and their environment defaults, are NOT part of this interface:

@@ -613,6 +613,10 @@ struct StackJob {
     bool img_u8 = false, out_u8 = false;
     int img_ch = 3, n = 1, H = 0, W = 0, top = 0, bot = 0, tiles_x = 0;
     bool forked = false;  // one of the two bands of sr_run_stack_auto: no 4-row tail (see prepare)
+    // rows [0, late_top) and [H - late_bot, H) of the image arrive with gate->ready (sr_internal.h sr_halo_gate); mark: record gate->mark around the wait
+    const sr_halo_gate* gate = nullptr;
+    int late_top = 0, late_bot = 0;
+    bool mark = false;
     hipStream_t s = nullptr;
     struct Launch { int y0, y1, ty8, ty4, th, grid; bool pipe; } L[5];
     float* feat[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -710,21 +714,36 @@ int StackJob::launch(int st) const {
     const Launch& l = L[st];
     const int y0 = l.y0, y1 = l.y1;
     if (st == 0) {
-        const int tiles_y = (y1 - y0 + l.th - 1) / l.th;
-        Conv0Args a{};
-        a.img = d_img; a.wpack = P + c->off_w0; a.wpack_split = P + c->off_w0h; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
-        a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
-        a.pitch = ws->pitch; a.img_stride = ws->img_stride;
-        a.y_begin = y0; a.y_end = y1; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
-        a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
-        a.n_tiles = n * tiles_x * tiles_y;
-        a.queue_reset = ws->d_queue;
-        a.domain = c->d_domain;
-        for (int k = 1; k < 5; ++k) a.queue_grid[k] = L[k].grid;
-        // (grid: 8 workgroups per CU walking the tiles with a fixed stride; measured with 8 / 12 / 16 / 32 per CU, one per tile, and
-        // a grid that divides the tile count evenly: conv0's time does not depend on it)
-        HIPCHK(c, sr_launch_conv0(a, l.th, c->precision, std::min(a.n_tiles, 8 * cus), img_u8, s));
-        return SR_OK;
+        auto rows = [&](int ya, int yb) -> int {  // f rows [ya, yb)
+            if (ya >= yb) return SR_OK;
+            const int tiles_y = (yb - ya + l.th - 1) / l.th;
+            Conv0Args a{};
+            a.img = d_img; a.wpack = P + c->off_w0; a.wpack_split = P + c->off_w0h; a.bias = P + c->off_bias[0]; a.beta = P + c->off_beta[0];
+            a.dst = feat[0]; a.H = H; a.W = W; a.img_ch = img_ch;
+            a.pitch = ws->pitch; a.img_stride = ws->img_stride;
+            a.y_begin = ya; a.y_end = yb; a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+            a.div_tpi = make_tile_div((uint32_t)(tiles_x * tiles_y)); a.div_tx = make_tile_div((uint32_t)tiles_x);
+            a.n_tiles = n * tiles_x * tiles_y;
+            a.queue_reset = ws->d_queue;  // (every stage-0 launch of the call sets the same heads: the stage kernels follow them all)
+            a.domain = c->d_domain;
+            for (int k = 1; k < 5; ++k) a.queue_grid[k] = L[k].grid;
+            // (grid: 8 workgroups per CU walking the tiles with a fixed stride; measured with 8 / 12 / 16 / 32 per CU, one per tile, and
+            // a grid that divides the tile count evenly: conv0's time does not depend on it)
+            HIPCHK(c, sr_launch_conv0(a, l.th, c->precision, std::min(a.n_tiles, 8 * cus), img_u8, s));
+            return SR_OK;
+        };
+        if (!gate || !gate->ready) return rows(y0, y1);
+        // Interior first (sr_halo_gate): f row y reads image rows y - 2 .. y + 2; those that touch none of the rows still on their way
+        // are launched now, the rest -- at most 2 + the stage's margin rows either side -- behind the wait.
+        const int lo = late_top > 0 ? std::max(y0, late_top + 2) : y0, hi = late_bot > 0 ? std::min(y1, H - late_bot - 2) : y1;
+        int rc = lo < hi ? rows(lo, hi) : SR_OK;
+        if (rc != SR_OK) return rc;
+        if (mark && gate->mark[0]) HIPCHK(c, hipEventRecord(gate->mark[0], s));
+        HIPCHK(c, hipStreamWaitEvent(s, gate->ready, 0));
+        if (mark && gate->mark[1]) HIPCHK(c, hipEventRecord(gate->mark[1], s));
+        if (lo >= hi) return rows(y0, y1);
+        rc = rows(y0, lo);
+        return rc != SR_OK ? rc : rows(hi, y1);
     }
     StageArgs a{};
     float* f = feat[0]; float* l1 = feat[1]; float* l2 = feat[2]; float* l3 = feat[3];
@@ -753,13 +772,13 @@ int StackJob::launch(int st) const {
 // of the n images are produced; each earlier stage computes just the extra rows
 // the later ones read (f +-5, l1 +-3, l2 +-2, l3 +-1 around the band).
 int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top,
-                 int halo_bot, void* d_out, bool out_u8, hipStream_t s, int slot) {
+                 int halo_bot, void* d_out, bool out_u8, hipStream_t s, int slot, const sr_halo_gate* gate) {
     if (!c || !d_img || !d_out || slot < 0 || slot > 1) return SR_E_INVALID;
     sr_device_guard restore_device;
     if (n <= 0 || H <= 0 || W <= 0) return SR_E_INVALID;
     if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
     if (c->graph != SR_GRAPH_SR_NET) {  // bilinear_net / downsample_net: one elementwise kernel
-        if (halo_top || halo_bot) return SR_E_INVALID;
+        if (halo_top || halo_bot || gate) return SR_E_INVALID;
         if (c->graph == SR_GRAPH_DOWNSAMPLE && (H < 3 || W < 3)) return SR_E_INVALID;
         if (img_u8 != out_u8) return SR_E_INVALID;
         HIPCHK(c, hipSetDevice(c->device));
@@ -777,6 +796,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
     StackJob job;
     job.c = c; job.ws = &c->ws[slot]; job.d_img = d_img; job.d_out = d_out; job.img_u8 = img_u8; job.out_u8 = out_u8;
     job.img_ch = img_ch; job.n = n; job.H = H; job.W = W; job.top = halo_top; job.bot = H - halo_bot; job.s = s;
+    if (gate) { job.gate = gate; job.late_top = gate->top; job.late_bot = gate->bot; job.mark = true; }
     int rc = job.prepare();
     if (rc != SR_OK) return rc;
     const bool prof = c->profiling;
@@ -864,26 +884,25 @@ bool plan_fork(const sr_ctx* c, bool img_u8, int img_ch, int n, int H, int W, in
     return true;
 }
 
-int ensure_fork_resources(sr_ctx* c) {
+}  // namespace
+
+int sr_ensure_fork_resources(sr_ctx* c) {
     if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     for (auto& e : c->ev_fork) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return SR_OK;
 }
 
-}  // namespace
-
 int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
-                      void* d_out, bool out_u8, hipStream_t s) {
+                      void* d_out, bool out_u8, hipStream_t s, const sr_halo_gate* gate) {
     if (!c || !d_img || !d_out) return SR_E_INVALID;
     c->band_pending = false;  // (the event pairs of an earlier sharded call are not this call's: sr_comm.cpp sets the flag again behind its own)
-    const int own = H - halo_top - halo_bot;
     int rows_a = 0;
     if (!plan_fork(c, img_u8, img_ch, n, H, W, halo_top, halo_bot, &rows_a))
-        return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s);
+        return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s, 0, gate);
     sr_device_guard restore_device;
     HIPCHK(c, hipSetDevice(c->device));
     {
-        const int rc = ensure_fork_resources(c);
+        const int rc = sr_ensure_fork_resources(c);
         if (rc != SR_OK) return rc;
     }
     const int cut = halo_top + rows_a;  // first row of the second band, in the coordinates of the caller's buffer
@@ -898,17 +917,20 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
     b.d_img = (const char*)d_img + (size_t)(cut - SR_HALO) * W * in_px;
     b.d_out = (char*)d_out + (size_t)rows_a * f * W * f * out_px;
     b.H = H - (cut - SR_HALO); b.top = SR_HALO; b.bot = b.H - halo_bot;
+    if (gate) {  // the first band holds the late rows at the image's top, the second those at its bottom; the caller's stream is the one whose wait is timed
+        a.gate = b.gate = gate; a.late_top = gate->top; b.late_bot = gate->bot; a.mark = true;
+    }
     HIPCHK(c, hipEventRecord(c->ev_fork[0], s));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork[0], 0));
     // Both bands are planned (and their workspaces allocated) before anything is launched: should the second set of feature maps not fit,
     // the undivided pass on the first workspace still may -- the call must not fail for want of an optimisation's memory.
     int rc = a.prepare();
-    if (rc == SR_OK) rc = b.prepare();
-    if (rc == SR_E_NOMEM) {
+    if (rc != SR_OK) return rc;  // (the first band's maps do not fit: the undivided pass, which needs larger ones, cannot either)
+    rc = b.prepare();
+    if (rc == SR_E_NOMEM) {  // the second workspace is the optimisation's: give back what of it exists and run undivided on the first
         for (auto& p : c->ws[1].d_feat) { if (p) (void)hipFree(p); p = nullptr; }
         c->ws[1].feat_cap_px = 0; c->ws[1].geo_n = 0;
-        (void)hipStreamWaitEvent(s, c->ev_fork[0], 0);
-        return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s);
+        return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s, 0, gate);
     }
     for (int st = 0; st < 5 && rc == SR_OK; ++st) {
         rc = a.launch(st);
@@ -920,7 +942,6 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
     if (rc != SR_OK) return rc;
     HIPCHK(c, e1); HIPCHK(c, e2);
     c->last_h = c->last_w = 0;  // each workspace holds one band: sr_read_feature refuses
-    (void)own;
     return SR_OK;
 }
 
@@ -1082,6 +1103,10 @@ int run_host(sr_ctx* c, const void* in, bool img_u8, int img_ch, Deal deal, int 
     if ((y_lo > 0 || y_hi < h) && (n != 1 || c->graph != SR_GRAPH_SR_NET)) return SR_E_INVALID;
     if (y_lo > 0 && y_lo < SR_HALO) return SR_E_HALO;
     if (y_hi < h && h - y_hi < SR_HALO) return SR_E_HALO;
+    // A fault still standing in the context's domain word was raised by an EARLIER call -- an unchecked *_dev call (a context has one
+    // caller: nothing of it is still running once that caller is here) -- and is that call's to report (sr_check_domain); it must
+    // not make this call, whose values may all be in range, recompute in f32.  Set it aside.
+    if (c->h_domain && *(volatile int*)c->h_domain) { c->dev_fault = true; *(volatile int*)c->h_domain = 0; }
     bool in_order = false;
     const std::vector<Chunk> plan = plan_chunks(c, deal, h, w, in_px, out_px, y_lo, y_hi, &in_order);
     const int nch = (int)plan.size();
@@ -1264,7 +1289,7 @@ static int reserve_fork(sr_ctx* c, bool img_u8, int img_ch, int n, int h, int w)
     sr_device_guard restore_device;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = sr_ensure_streams(c, false);
-    if (rc == SR_OK) rc = ensure_fork_resources(c);
+    if (rc == SR_OK) rc = sr_ensure_fork_resources(c);
     if (rc != SR_OK) return rc;
     StackJob a, b;
     a.forked = b.forked = true;
@@ -1390,9 +1415,10 @@ int sr_read_feature(sr_ctx* c, int which, float* out_host, size_t cap_floats) {
 
 int sr_check_domain(sr_ctx* c) {
     if (!c) return SR_E_INVALID;
-    if (!c->h_domain || !*(volatile int*)c->h_domain) return SR_OK;
-    *(volatile int*)c->h_domain = 0;
-    return SR_E_DOMAIN;
+    const bool fault = c->dev_fault || (c->h_domain && *(volatile int*)c->h_domain);
+    c->dev_fault = false;
+    if (c->h_domain) *(volatile int*)c->h_domain = 0;
+    return fault ? SR_E_DOMAIN : SR_OK;
 }
 
 int sr_last_timing(sr_ctx* c, double* total_ms, double stage_ms[5], double* h2d_ms, double* d2h_ms) {

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, ALIGNED ? (CH == 3 ? 7 : 6) : 4) void bilinear
     typedef BlWindow<CH> Win;
     auto geometry = [&](int bb, int& cx, int& p0, int& ws) {
         cx = min(64 * bb + lane, chunks - 1);  // (lanes past the row's end redo its last chunk: same bytes to the same place, no branch)
-        const int o0 = 4 * cx, i0 = (int)(((uint32_t)o0 * 43691u) >> 17);  // o0 / 3 (exact below 2^17; o0 < 3 * 16384 + 256)
+        const int o0 = 4 * cx, i0 = (int)(__umulhi((uint32_t)o0, 0xAAAAAAABu) >> 1);  // o0 / 3, exact for every 32-bit o0 (round 5's 16-bit form was not beyond W = 32767)
         p0 = o0 - 3 * i0;
         ws = i0 - (p0 == 0 ? 1 : 0);
     };
@@ -595,7 +595,7 @@ hipError_t sr_launch_aux(int graph, const AuxArgs& a, bool img_u8, bool out_u8, 
         if (img_u8) {  // bilinear_u8_kernel: a wave per block of 64 chunks of one input row, every wave the same number of blocks (+-1)
             if (a.img_ch != 3 && a.img_ch != 4) return hipErrorInvalidValue;
             const long items = (long)a.n * a.H * (((3L * a.W + 3) / 4 + 63) / 64);
-            if (items >= (1L << 31)) return hipErrorInvalidValue;
+            if (items >= (1L << 31) - (1L << 20)) return hipErrorInvalidValue;  // (a wave's item counter runs up to items + 4 x grid before it stops)
             const void* fn = a.img_ch == 3 ? (aligned ? (const void*)bilinear_u8_kernel<3, true> : (const void*)bilinear_u8_kernel<3, false>)
                                            : (aligned ? (const void*)bilinear_u8_kernel<4, true> : (const void*)bilinear_u8_kernel<4, false>);
             int resident = 0;

@@ -5,8 +5,12 @@
 // the output: every output pixel depends on a 15x15 input window (SR_HALO = 7), so an image splits into
 // contiguous row bands; a band needs the 7 input rows either side of it from its neighbours, recomputes the
 // overlap and writes its own rows -- bit-identical to the undivided call.  The exchange is one grouped
-// ncclSend / ncclRecv pair per neighbour (<= 7 * W * 12 B each: latency-bound, one xGMI link per direction),
-// issued on the stream the band's kernels follow on, so no host synchronisation sits between them.
+// ncclSend / ncclRecv pair per neighbour (<= 7 * W * 12 B each: latency-bound, one xGMI link per direction).
+// Round 6, interior first: the exchange is queued on the context's SECOND stream (forked from the band's stream by an event, so
+// that it starts when the caller's band is complete) while the band's own stream copies the band and runs stage 0 on every row that
+// reads no halo row; that stream then waits for the exchange's event and runs stage 0's few edge rows and the other stages
+// (sr_internal.h sr_halo_gate).  No host synchronisation anywhere; what of the exchange was not hidden is timed by an event pair
+// around the wait (sr_last_comm_exposed_ms).
 //
 // A host that drives all its GPUs from ONE process has a second transport (sr_comm_init_local): the neighbour's rows
 // are the caller's own device buffers, so each context pulls its two halos with hipMemcpyPeerAsync on its own stream
@@ -141,11 +145,29 @@ int prepare_band(sr_ctx* c, const void* d_band, int h_band, int w, size_t px_byt
     // are not serialised the way per-stage profiling serialises them.
     for (auto& e : c->ev_comm) if (!e) HIPCHK(c, hipEventCreate(&e));
     for (auto& e : c->ev_band) if (!e) HIPCHK(c, hipEventCreate(&e));
-    c->comm_pending = c->band_pending = false;
+    for (auto& e : c->ev_wait) if (!e) HIPCHK(c, hipEventCreate(&e));
+    if (!c->ev_xfork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_xfork, hipEventDisableTiming));
+    c->comm_pending = c->band_pending = c->wait_pending = false;
     HIPCHK(c, hipEventRecord(c->ev_band[0], s));
+    if (c->comm_nranks > 1) {
+        // the exchange stream starts where the band's stream stands now: the caller's producers of d_band are done, and so is every
+        // earlier call's reader of d_ext (the receives land there)
+        const int rc2 = sr_ensure_fork_resources(c);
+        if (rc2 != SR_OK) return rc2;
+        HIPCHK(c, hipEventRecord(c->ev_xfork, s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_xfork, 0));
+    }
     HIPCHK(c, hipMemcpyAsync((char*)c->d_ext + (size_t)g.top * g.row_bytes, d_band, (size_t)h_band * g.row_bytes,
                              hipMemcpyDeviceToDevice, s));
     return SR_OK;
+}
+
+// the gate the band's conv stack waits behind: the exchange's end event, the halo rows either side, the wait's own event pair
+sr_halo_gate gate_of(sr_ctx* c, const BandGeom& g) {
+    sr_halo_gate gate;
+    gate.ready = c->ev_comm[1]; gate.top = g.top; gate.bot = g.bot;
+    gate.mark[0] = c->ev_wait[0]; gate.mark[1] = c->ev_wait[1];
+    return gate;
 }
 
 // one process per GPU: exchange + band pass of this rank, asynchronous on `s`
@@ -157,24 +179,28 @@ int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, 
     BandGeom g;
     int rc = prepare_band(c, d_band, h_band, w, u8 ? (size_t)img_ch : 3 * sizeof(float), g, s);
     if (rc != SR_OK) return rc;
+    sr_halo_gate gate;
     if (c->comm_nranks > 1) {
         Rccl* R = rccl();
         if (!R) return SR_E_COMM;
-        HIPCHK(c, hipEventRecord(c->ev_comm[0], s));
+        hipStream_t xs = c->stream2;
+        HIPCHK(c, hipEventRecord(c->ev_comm[0], xs));
         NCCLCHK(c, R->GroupStart());
-        rc = post_exchange(c, R, d_band, h_band, g, s);
+        rc = post_exchange(c, R, d_band, h_band, g, xs);
         const ncclResult_t ge = R->GroupEnd();
-        if (rc != SR_OK || ge != ncclSuccess) {  // possibly half-posted: nothing of it may stay queued on the caller's stream
+        if (rc != SR_OK || ge != ncclSuccess) {  // possibly half-posted: nothing of it may stay queued
             if (rc == SR_OK) c->last_nccl = (int)ge;
             abort_comm(c, R);
+            (void)hipStreamWaitEvent(s, c->ev_xfork, 0);
             return SR_E_COMM;
         }
-        HIPCHK(c, hipEventRecord(c->ev_comm[1], s));
+        HIPCHK(c, hipEventRecord(c->ev_comm[1], xs));
+        gate = gate_of(c, g);
     }
-    rc = sr_run_stack_auto(c, c->d_ext, u8, img_ch, 1, g.h_ext, w, g.top, g.bot, d_out, u8, s);
+    rc = sr_run_stack_auto(c, c->d_ext, u8, img_ch, 1, g.h_ext, w, g.top, g.bot, d_out, u8, s, c->comm_nranks > 1 ? &gate : nullptr);
     if (rc != SR_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev_band[1], s));
-    c->comm_pending = c->comm_nranks > 1;
+    c->comm_pending = c->wait_pending = c->comm_nranks > 1;
     c->band_pending = !c->profiling;  // (with per-stage profiling on, sr_last_timing reports the conv stack's own events)
     return SR_OK;
 }
@@ -219,26 +245,26 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
             const size_t halo = (size_t)SR_HALO * g[k].row_bytes;
             char* ext = (char*)c->d_ext;
             rc = hip(c, hipSetDevice(c->device));
-            if (rc == SR_OK) rc = hip(c, hipEventRecord(c->ev_comm[0], c->stream));
+            if (rc == SR_OK) rc = hip(c, hipEventRecord(c->ev_comm[0], c->stream2));
             if (rc == SR_OK && g[k].top)
                 rc = hip(c, hipMemcpyPeerAsync(ext, c->device, (const char*)d_bands[k - 1] + (size_t)(h_bands[k - 1] - SR_HALO) * g[k].row_bytes,
-                                               ctxs[k - 1]->device, halo, c->stream));
+                                               ctxs[k - 1]->device, halo, c->stream2));
             if (rc == SR_OK && g[k].bot)
                 rc = hip(c, hipMemcpyPeerAsync(ext + (size_t)(g[k].top + h_bands[k]) * g[k].row_bytes, c->device, d_bands[k + 1],
-                                               ctxs[k + 1]->device, halo, c->stream));
-            if (rc == SR_OK) rc = hip(c, hipEventRecord(c->ev_comm[1], c->stream));
+                                               ctxs[k + 1]->device, halo, c->stream2));
+            if (rc == SR_OK) rc = hip(c, hipEventRecord(c->ev_comm[1], c->stream2));
         }
     } else if (rc == SR_OK && n > 1) {
         for (int k = 0; k < n && rc == SR_OK; ++k) {
             rc = hip(ctxs[k], hipSetDevice(ctxs[k]->device));
-            if (rc == SR_OK) rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_comm[0], ctxs[k]->stream));
+            if (rc == SR_OK) rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_comm[0], ctxs[k]->stream2));
         }
         ncclResult_t gs = rc == SR_OK ? R->GroupStart() : ncclSuccess;
         if (gs != ncclSuccess) { ctxs[0]->last_nccl = (int)gs; rc = SR_E_COMM; }
         const bool grouped = rc == SR_OK;
         for (int k = 0; k < n && rc == SR_OK; ++k) {
             (void)hipSetDevice(ctxs[k]->device);
-            rc = post_exchange(ctxs[k], R, d_bands[k], h_bands[k], g[k], ctxs[k]->stream);
+            rc = post_exchange(ctxs[k], R, d_bands[k], h_bands[k], g[k], ctxs[k]->stream2);
         }
         if (grouped) {
             const ncclResult_t ge = R->GroupEnd();
@@ -246,7 +272,7 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
         }
         for (int k = 0; k < n && rc == SR_OK; ++k) {
             (void)hipSetDevice(ctxs[k]->device);
-            rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_comm[1], ctxs[k]->stream));
+            rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_comm[1], ctxs[k]->stream2));
         }
         // a failure inside the group may have left some ranks' operations queued without partners: abort every
         // communicator of the set, so that the drain below returns instead of waiting for them for ever
@@ -254,15 +280,18 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
             for (int k = 0; k < n; ++k) { (void)hipSetDevice(ctxs[k]->device); abort_comm(ctxs[k], R); }
     }
     for (int k = 0; k < n && rc == SR_OK; ++k) {
-        rc = sr_run_stack_auto(ctxs[k], ctxs[k]->d_ext, u8, img_ch, 1, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, ctxs[k]->stream);
+        const sr_halo_gate gate = gate_of(ctxs[k], g[k]);
+        rc = sr_run_stack_auto(ctxs[k], ctxs[k]->d_ext, u8, img_ch, 1, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, ctxs[k]->stream,
+                               n > 1 ? &gate : nullptr);
         if (rc == SR_OK) rc = hip(ctxs[k], hipSetDevice(ctxs[k]->device));
         if (rc == SR_OK) rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_band[1], ctxs[k]->stream));
-        if (rc == SR_OK) { ctxs[k]->comm_pending = n > 1; ctxs[k]->band_pending = !ctxs[k]->profiling; }
+        if (rc == SR_OK) { ctxs[k]->comm_pending = ctxs[k]->wait_pending = n > 1; ctxs[k]->band_pending = !ctxs[k]->profiling; }
     }
     int first = rc;
-    for (int k = 0; k < n; ++k) {  // drain every device, also on failure
+    for (int k = 0; k < n; ++k) {  // drain every device, also on failure (both streams: a failed call may have left the exchange unjoined)
         (void)hipSetDevice(ctxs[k]->device);
-        const hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
+        hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
+        if (e == hipSuccess && n > 1 && ctxs[k]->stream2) e = hipStreamSynchronize(ctxs[k]->stream2);
         if (e != hipSuccess && first == SR_OK) { ctxs[k]->last_hip = (int)e; first = SR_E_HIP; }
     }
     return first;
@@ -280,7 +309,9 @@ void sr_comm_release(sr_ctx* c) {
     if (c->d_ext) { (void)hipFree(c->d_ext); c->d_ext = nullptr; c->ext_cap = 0; }
     for (auto& e : c->ev_comm) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto& e : c->ev_band) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-    c->comm_pending = c->band_pending = false;
+    for (auto& e : c->ev_wait) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (c->ev_xfork) { (void)hipEventDestroy(c->ev_xfork); c->ev_xfork = nullptr; }
+    c->comm_pending = c->band_pending = c->wait_pending = false;
 }
 
 extern "C" {
@@ -413,6 +444,19 @@ int sr_last_comm_ms(sr_ctx* c, double* comm_ms) {
         c->comm_pending = false;
     }
     *comm_ms = c->comm_ms;
+    return SR_OK;
+}
+
+int sr_last_comm_exposed_ms(sr_ctx* c, double* exposed_ms) {
+    if (!c || !exposed_ms) return SR_E_INVALID;
+    if (c->wait_pending) {  // waits for the band's stream to get past its wait for the exchange (not for the kernels behind it)
+        float ms = 0;
+        HIPCHK(c, hipEventSynchronize(c->ev_wait[1]));
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_wait[0], c->ev_wait[1]));
+        c->comm_exposed_ms = ms;
+        c->wait_pending = false;
+    }
+    *exposed_ms = c->comm_exposed_ms;
     return SR_OK;
 }
 

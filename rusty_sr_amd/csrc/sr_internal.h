@@ -23,6 +23,7 @@ struct sr_ctx {
     int* h_domain = nullptr;   // host address of the flag
     int* d_domain = nullptr;   // the same word as the device sees it
     int domain_fallbacks = 0;  // host-pointer calls that were recomputed in exact f32 because of it
+    bool dev_fault = false;    // a fault an earlier *_dev call left in *h_domain, set aside at the start of a host-pointer call: sr_check_domain's
     int graph = SR_GRAPH_SR_NET;
     int factor = SR_FACTOR;
     // Device workspace of one pass of the conv stack.  Two of them: the host pipeline (run_host) alternates chunks between
@@ -72,7 +73,11 @@ struct sr_ctx {
     bool comm_local = false;          // sr_comm_init_local: neighbours are contexts of this process, halos go by peer copy
     int comm_rank = 0, comm_nranks = 1;
     void* d_ext = nullptr; size_t ext_cap = 0;  // band + halo rows, the exchange lands here
-    hipEvent_t ev_comm[2] = {nullptr, nullptr};  // around the halo exchange of a sharded call, on the band's stream
+    hipEvent_t ev_comm[2] = {nullptr, nullptr};  // around the halo exchange of a sharded call, on the stream it runs on (round 6: the context's stream2)
+    hipEvent_t ev_wait[2] = {nullptr, nullptr};  // on the band's stream, either side of its wait for the exchange: what of the exchange was NOT hidden
+    hipEvent_t ev_xfork = nullptr;               // band's stream -> exchange stream: the caller's band is complete
+    bool wait_pending = false;
+    double comm_exposed_ms = 0;
     hipEvent_t ev_band[2] = {nullptr, nullptr};  // around the whole sharded step of this context (band copy, exchange, conv stack)
     bool comm_pending = false, band_pending = false;  // the events of the last sharded call have not been read yet (sr_last_comm_ms / sr_last_timing)
     double comm_ms = 0;
@@ -102,12 +107,25 @@ struct sr_device_guard {
     } while (0)
 
 
+// Rows of the image that are still on their way when the call is made -- the halo rows of a sharded band, which a neighbour's GPU
+// sends while this one already works (sr_comm.cpp): the first `top` and the last `bot` rows of d_img are in place once `ready`
+// (recorded on another stream) has fired.  Only stage 0 reads the image's halo rows directly (f rows within 2 of them), so the stack
+// launches stage 0 for the rows that need none of them FIRST, waits for the event on its own stream, and then runs stage 0's few
+// edge rows and the other stages: the exchange hides under the band copy and the interior of stage 0.  mark[0..1] (optional) are
+// recorded on the waiting stream either side of the wait.
+struct sr_halo_gate {
+    hipEvent_t ready = nullptr;
+    int top = 0, bot = 0;
+    hipEvent_t mark[2] = {nullptr, nullptr};
+};
+
 // The whole conv stack on device buffers (sr_api.cpp): rows [halo_top, H - halo_bot) of each image are produced.
 int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
-                 void* d_out, bool out_u8, hipStream_t s, int slot = 0);
+                 void* d_out, bool out_u8, hipStream_t s, int slot = 0, const sr_halo_gate* gate = nullptr);
 // ... the same for one image as two row bands forked onto the context's second stream where that pays (the device entry points)
 int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
-                      void* d_out, bool out_u8, hipStream_t s);
+                      void* d_out, bool out_u8, hipStream_t s, const sr_halo_gate* gate = nullptr);
+int sr_ensure_fork_resources(sr_ctx* c);  // the second stream + the fork / join events
 int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes);
 int sr_ensure_streams(sr_ctx* c, bool pipelined);  // the context's own streams are created on first use
 void sr_comm_release(sr_ctx* c);  // sr_comm.cpp: destroy the communicator and its buffers (called by sr_destroy)

@@ -136,3 +136,33 @@ def test_device_entry_point_raises_a_fault_instead_of_clamping(params):
     f32.check_domain()  # the exact mode has no such domain
     f32.close()
     eng.close()
+
+
+def test_an_unchecked_device_fault_is_not_the_next_host_calls(params):
+    """A fault an earlier *_dev call left behind belongs to sr_check_domain: the next host-pointer call, whose values are all in
+    range, must run in the split-half mode (bit for bit what a fresh context returns), not recompute in f32 -- and the fault is
+    still reported afterwards, once, also across a switch of mode (include/srhip.h sr_check_domain)."""
+    import torch
+    import rusty_sr_amd as r
+    from rusty_sr_amd import _lib
+    rng = np.random.default_rng(15)
+    x = rng.random((1, 40, 72, 3), dtype=np.float32)
+    clean = r.Engine(params["imagenet"], device=0, precision="split_f16")
+    want_split = clean.upscale_f32(x)
+    clean.set_precision("f32")
+    want_f32 = clean.upscale_f32(x)
+    clean.close()
+    assert not np.array_equal(want_split, want_f32)  # (the two modes differ in the last bits: the comparison below means something)
+    eng = r.Engine(params["imagenet"], device=0, precision="split_f16")
+    y = x.copy()
+    y[0, 20, 30, 1] = 1e6
+    eng.upscale_f32_dev(torch.from_numpy(y).cuda())
+    torch.cuda.synchronize()
+    got = eng.upscale_f32(x)
+    assert np.array_equal(got, want_split)
+    eng.set_precision("f32")
+    with pytest.raises(r.SrError) as e:
+        eng.check_domain()
+    assert e.value.status == _lib.SR_E_DOMAIN
+    eng.check_domain()
+    eng.close()

@@ -453,6 +453,19 @@ def test_bilinear_and_downsample_graphs(params):
         ds.upscale_f32(np.zeros((2, 2, 3), np.float32))
 
 
+def test_u8_bilinear_graph_on_images_wider_than_32767_pixels():
+    """bilinear_u8_kernel divides output columns by 3 with a multiply-high; round 5's 16-bit form was exact below 98 304 output
+    columns only (advisor): 33 001- and 40 000-pixel rows, 3- and 4-channel, against the oracle."""
+    import rusty_sr_amd as r
+    bl = r.bilinear_net(r.FACTOR)
+    for k, (h, w, c) in enumerate(((2, 33001, 3), (3, 40000, 4))):
+        px = synth_u8(970 + k, 1, h, w)
+        want = oracle.bilinear(oracle.img_to_data(px))
+        if c == 4:
+            px = np.concatenate([px, synth_u8(980 + k, 1, h, w)[..., :1]], axis=-1)
+        _check_u8(bl.upscale_rgba8(px), want)
+
+
 def test_downsample_reads_any_channel_count_and_alignment():
     """downsample_net's threads read their 3x3 windows straight from global memory as the aligned words that hold them
     (sr_aux.hip): 3- and 4-channel u8 input, device pointers at every byte offset, widths with remainder columns, batches
