@@ -437,13 +437,17 @@ def main():
         def stage_ms(self, reps):
             """Per-stage kernel times (HIP events on the launch stream, inside libsrhip); median over reps."""
             eng.set_profiling(True)
-            acc, comm = [], []
+            acc, comm, expo = [], [], []
             for _ in range(reps):
                 self.step()
                 torch.cuda.synchronize()
                 acc.append(eng.last_timing()["stage_ms"])
                 comm.append(eng.last_comm_ms() if self.lib and world > 1 else 0.0)
+                expo.append(eng.last_comm_exposed_ms() if self.lib and world > 1 else 0.0)
             eng.set_profiling(False)
+            # (interior first: the exchange runs on its own stream beside the band copy and stage 0's interior rows; this is what the band's
+            # stream still had to wait for it)
+            self.comm_exposed_ms = float(np.median(expo))
             self.stage_mean = np.mean(np.array(acc), axis=0)   # beside the median: what `roofline.frac` is quoted on
             return np.median(np.array(acc), axis=0), float(np.median(comm))
 
@@ -623,6 +627,7 @@ def main():
                                  "frac_of_peak": round(stage_tflops(s, rows[s], W, stage_ms[s]) / peak, 4)} for s in range(5)]
             if world > 1:
                 result["comm_ms"] = round(comm_ms, 4)
+                result["comm_exposed_ms"] = round(main_band.comm_exposed_ms, 4)
                 if exchange_check is not None:
                     result["exchange_check"] = exchange_check
             io_bytes = H * W * (3 + 36 if u8 else 12 + 108)
@@ -725,7 +730,7 @@ def main():
             rows_c = band.rows() if world > 1 else [HC] * 5
             kc, ach_c, _ = roofline_of(st_c, rows_c, WC, args.precision)
             mine = {"rank": rank, "rows": b - a, "stage_ms": [round(float(v), 4) for v in st_c], "comm_ms": round(comm_c, 4),
-                    "roofline_frac": round(ach_c / peak_here, 4), "dominant_stage": kc}
+                    "comm_exposed_ms": round(band.comm_exposed_ms, 4), "roofline_frac": round(ach_c / peak_here, 4), "dominant_stage": kc}
             per_rank = [mine]
             if world > 1:
                 per_rank = [None] * world

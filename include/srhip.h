@@ -189,6 +189,9 @@ int sr_upscale_band_rgba8_dev(sr_ctx* ctx, const uint8_t* d_in, int in_channels,
  * (one grouped ncclSend / ncclRecv pair per neighbour over xGMI, queued on `stream`), then runs the band form
  * of the conv stack (sr_upscale_band_*_dev) and writes the band's 3*h_band output rows to d_out.  The rows of
  * all ranks together are bit-identical to the single-GPU call.
+ * Interior first: the exchange runs on a second stream of the context's own (forked from `stream` by an event and joined back
+ * to it by another, like the two-band form above) while `stream` copies the band and computes the first layer on every row that
+ * reads no halo row; only then does `stream` wait for the halos.  The call stays asynchronous and ordered on `stream` alone.
  *
  * One process per GPU (the normal form):  rank 0 calls sr_comm_unique_id and hands the 128 bytes to the other
  * ranks by whatever means the host has (a file, a socket, an environment variable, torch.distributed);
@@ -209,9 +212,12 @@ int sr_comm_init_local(sr_ctx* const* ctxs, int n);
 void sr_comm_destroy(sr_ctx* ctx);                      /* sr_destroy does this too */
 int sr_comm_rank(sr_ctx* ctx, int* rank, int* nranks);  /* 0 of 1 without a communicator */
 int sr_last_comm_error(sr_ctx* ctx);                    /* ncclResult_t of the last failed RCCL call */
-int sr_last_comm_ms(sr_ctx* ctx, double* comm_ms);      /* device time of the last sharded call's halo exchange (an event pair on the band's
-                                                         * stream, recorded on every call; waits for the exchange, not for the kernels).
+int sr_last_comm_ms(sr_ctx* ctx, double* comm_ms);      /* device time of the last sharded call's halo exchange (an event pair on the stream
+                                                         * it ran on, recorded on every call; waits for the exchange, not for the kernels).
                                                          * sr_last_timing after a sharded call: total_ms = this context's whole step */
+int sr_last_comm_exposed_ms(sr_ctx* ctx, double* exposed_ms);  /* ... and how long the band's stream stood waiting for it (an event pair
+                                                         * either side of its wait): the part of comm_ms that was NOT hidden under the
+                                                         * band copy and the first layer's interior rows */
 int sr_upscale_sharded_f32_dev(sr_ctx* ctx, const float* d_band, int h_band, int w, float* d_out, void* stream);
 int sr_upscale_sharded_rgba8_dev(sr_ctx* ctx, const uint8_t* d_band, int in_channels, int h_band, int w,
                                  uint8_t* d_out_rgba, void* stream);

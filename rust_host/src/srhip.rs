@@ -66,6 +66,7 @@ extern "C" {
     pub fn sr_comm_rank(ctx: *mut SrCtx, rank: *mut c_int, nranks: *mut c_int) -> c_int;
     pub fn sr_last_comm_error(ctx: *mut SrCtx) -> c_int;
     pub fn sr_last_comm_ms(ctx: *mut SrCtx, comm_ms: *mut f64) -> c_int;
+    pub fn sr_last_comm_exposed_ms(ctx: *mut SrCtx, exposed_ms: *mut f64) -> c_int;
     pub fn sr_upscale_sharded_f32_dev(ctx: *mut SrCtx, d_band: *const f32, h_band: c_int, w: c_int, d_out: *mut f32,
                                       stream: *mut c_void) -> c_int;
     pub fn sr_upscale_sharded_rgba8_dev(ctx: *mut SrCtx, d_band: *const u8, in_channels: c_int, h_band: c_int, w: c_int,

@@ -51,6 +51,7 @@ SYMBOLS = {
     "sr_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "sr_last_comm_error": (_i, [_vp]),
     "sr_last_comm_ms": (_i, [_vp, _dp]),
+    "sr_last_comm_exposed_ms": (_i, [_vp, _dp]),
     "sr_upscale_sharded_f32_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "sr_upscale_sharded_rgba8_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "sr_upscale_sharded_f32_all": (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_i), _i, C.POINTER(_vp)]),

@@ -217,6 +217,12 @@ class Engine:
         _lib.check(self._L.sr_last_comm_ms(self._ctx, C.byref(v)))
         return v.value
 
+    def last_comm_exposed_ms(self) -> float:
+        """What of the last sharded call's halo exchange the band's stream had to wait for (sr_last_comm_exposed_ms)."""
+        v = C.c_double()
+        _lib.check(self._L.sr_last_comm_exposed_ms(self._ctx, C.byref(v)))
+        return v.value
+
     def upscale_sharded_dev(self, band, out=None, stream=None):
         """This rank's band (rows, W, 3 f32 | 3-4 u8) of an image sharded in rank order: halo exchange over the
         context's RCCL communicator + band pass, asynchronous on the stream -> (3 rows, 3 W, 3 f32 | 4 u8)."""

@@ -251,8 +251,11 @@ def test_sharded_image_through_the_library_on_one_device(params, n, prec):
         # (sr_last_timing total_ms, no per-stage times) and the halo exchange inside it (sr_last_comm_ms)
         r.upscale_sharded_all(engs, bands)
         for e in engs:
-            t, c = e.last_timing(), e.last_comm_ms()
+            t, c, x = e.last_timing(), e.last_comm_ms(), e.last_comm_exposed_ms()
             assert t["total_ms"] > 0 and sum(t["stage_ms"]) == 0 and 0 < c < t["total_ms"]
+            # interior first: the band's stream waits for the exchange only behind the band copy and the first layer's interior rows
+            # (sr_last_comm_exposed_ms: an event pair either side of that wait)
+            assert 0 <= x < t["total_ms"]
         engs[0].set_profiling(True)
         r.upscale_sharded_all(engs, bands)
         assert engs[0].last_comm_ms() > 0 and sum(engs[0].last_timing()["stage_ms"]) > 0  # ... with it on, the conv stack's own per-stage events
