@@ -52,6 +52,7 @@ MAC_PER_PX = {  # stage -> MACs per input pixel
 FLOP_PER_PX = 2 * sum(MAC_PER_PX.values())  # 260352
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA (not the 2:1-sparse headline)
+MEASURED_F16_MFMA16_RANDOM_TFLOPS = 1967.0  # bare v_mfma_f32_16x16x32_f16 stream on random operands, 20 s: profiles/r6_power_clock_probe.txt
 PEAK_HBM_GBPS = 8000.0
 MARGIN = (5, 3, 2, 1, 0)  # extra rows stage s computes either side of a band (what later stages read)
 
@@ -664,6 +665,20 @@ def main():
                                      "stage_ms": [round(float(v), 4) for v in ost],
                                      "stage3_tflops": round(ach_o, 2), "stage3_frac_of_peak": round(ach_o / peak_o, 4),
                                      "peak": peak_o}
+        if other == "split_f16":
+            # The split-half mode issues THREE f16 products per algorithmic one (hi.hi, hi.lo, lo.hi), and the f16 matrix pipe does not hold
+            # its nominal clock on real operands: a bare stream of random-operand v_mfma_f32_16x16x32_f16 -- what stages 1-3 issue -- runs at
+            # 1.96 GHz = 1 967 TFLOP/s on this part while the mode's own frames run at 1.72 GHz (profiles/r6_power_clock_probe.txt: clock from
+            # a one-wave probe kernel beside 20 s of the real frames).  Both denominators, so that neither has to be taken on trust.
+            issued = 3.0 * ach_o
+            result["other_precision"]["roofline"] = {
+                "bound": "mfma", "kernel": "stage 3 (conv_stage_pipe_kernel<3, 5, ..., 1, 3>, v_mfma_f32_16x16x32_f16)", "unit": "TFLOP/s",
+                "algorithmic": round(ach_o, 2), "issued": round(issued, 2),
+                "peak_nominal": PEAK_F16_MFMA_TFLOPS, "frac_of_nominal_issued": round(issued / PEAK_F16_MFMA_TFLOPS, 4),
+                "peak_measured_random_operands": MEASURED_F16_MFMA16_RANDOM_TFLOPS,
+                "frac_of_measured_issued": round(issued / MEASURED_F16_MFMA16_RANDOM_TFLOPS, 4),
+                "source": "profiles/r6_power_clock_probe.txt (scripts/experiments/power_clock_probe.hip, third leg; round 5's boxes: 2 090, "
+                          "profiles/r5_ubench_split_floor.txt)"}
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # BASELINE.json labels its configs "4x".  The reference cannot do 4x (FACTOR = 3, no 4x weights);

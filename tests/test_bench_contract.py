@@ -54,6 +54,11 @@ def test_bench_single_gpu_contract():
         e = prev[f"{ways}_way"]
         assert e["rows"] == 2160 // ways and e["ms_per_band"] > 0 and 0 < e["useful_roofline_frac"] < 1
     assert 0 < d["config_A"]["whole_call_frac"] < 1
+    # the split-half mode beside the headline: its dominant kernel against BOTH denominators (the nominal f16 peak and the rate a bare
+    # random-operand stream of its instruction sustains on this part), on issued FLOPs (three f16 products per algorithmic one)
+    orf = d["other_precision"]["roofline"]
+    assert orf["peak_nominal"] == 2500.0 and 0 < orf["peak_measured_random_operands"] < orf["peak_nominal"] and "profiles/" in orf["source"]
+    assert abs(orf["issued"] - 3 * orf["algorithmic"]) < 0.05 and 0 < orf["frac_of_nominal_issued"] < orf["frac_of_measured_issued"] < 1
     assert d["config_D"]["images_per_rank"] == 64 and d["config_D"]["data_path_collectives"] == 0 and "host_pipelined" in d["config_D"]
 
 
