@@ -777,12 +777,30 @@ def main():
                             fnb(ext, topb, botb, out=ob)
                         torch.cuda.synchronize()
                         best = min(best, (time.perf_counter() - t0) / ksteps * 1e3)
+                    # ... and with per-layer feature halos (sr_set_experiment "halo" = "layers"): every stage computes the
+                    # band's own rows only -- the kernel work of a whole image of that many rows, which is what is timed here (the four
+                    # feature-row exchanges per frame, <= 1 MB each, need the neighbours and are not in it)
+                    own = ext[topb:topb + rows_b].contiguous()[None]
+                    fno = eng.upscale_rgba8_dev if u8 else eng.upscale_f32_dev
+                    for _ in range(3):
+                        fno(own, out=ob[None])
+                    torch.cuda.synchronize()
+                    best_l = 1e9
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        for _ in range(ksteps):
+                            fno(own, out=ob[None])
+                        torch.cuda.synchronize()
+                        best_l = min(best_l, (time.perf_counter() - t0) / ksteps * 1e3)
                     preview[f"{ways}_way"] = {
                         "rows": rows_b, "halo_rows": topb + botb, "ms_per_band": round(best, 4),
                         "ideal_ms": round(ms_c / ways, 4), "over_ideal": round(best / (ms_c / ways), 4),
                         "useful_roofline_frac": round(rows_b * WC * FLOP_PER_PX / (best / 1e3) / 1e12 / peak_here, 4),
-                        "n_bands_in_parallel_would_be": round(9 * HC * WC / 1e6 / (best / 1e3), 1)}
-                    del ext, ob
+                        "n_bands_in_parallel_would_be": round(9 * HC * WC / 1e6 / (best / 1e3), 1),
+                        "layer_halos": {"kernel_ms_per_band": round(best_l, 4),
+                                        "useful_roofline_frac": round(rows_b * WC * FLOP_PER_PX / (best_l / 1e3) / 1e12 / peak_here, 4),
+                                        "exchanged_bytes_per_neighbour": int((2 + 3) * (32 * ((WC + 31) // 32) + 4) * 128)}}
+                    del ext, ob, own
                 preview["rows"], preview["halo_rows"] = 270, 14  # (the 8-way entry under its round-2 keys)
                 preview["ms_per_band"] = preview["8_way"]["ms_per_band"]
                 preview["eight_bands_in_parallel_would_be"] = preview["8_way"]["n_bands_in_parallel_would_be"]

@@ -23,8 +23,10 @@ extern "C" {
  * ("" automatic, "0" plain row-major); "bands": the host pipeline cuts one large image into that many equal row bands
  * ("" / "0": its own plan); "rows": the bands' heights themselves, "r0,r1,..." top to bottom, computed in order on one stream, or with a
  * leading '=' on alternating streams (used when they add up to the rows of the call); "geo": "0" keeps equal bands where the plan would
- * shrink them geometrically.
- * Defaults come from SRHIP_TH / SRHIP_TAIL / SRHIP_PIPE / SRHIP_BW / SRHIP_BANDS / SRHIP_ROWS / SRHIP_GEO, read once in sr_create.
+ * shrink them geometrically; "halo": what a sharded call (sr_upscale_sharded_*) exchanges -- "" / "input": 7 input rows per
+ * neighbour, the overlap recomputed; "layers": additionally the edge rows of every layer's output after its stage
+ * (f 2 rows, l1 / l2 / l3 one each), nothing recomputed (8(e)(ii)); every context of a call must say the same.
+ * Defaults come from SRHIP_TH / SRHIP_TAIL / SRHIP_PIPE / SRHIP_BW / SRHIP_BANDS / SRHIP_ROWS / SRHIP_GEO / SRHIP_HALO, read once in sr_create.
  * Unknown key: SR_E_INVALID. */
 int sr_set_experiment(sr_ctx* ctx, const char* key, const char* value);
 

@@ -305,9 +305,9 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[10][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
+    static const char* const kSwitch[11][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
                                                {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}, {"rows", "SRHIP_ROWS"}, {"fork", "SRHIP_FORK"},
-                                               {"forkshare", "SRHIP_FORKSHARE"}, {"forkmin", "SRHIP_FORKMIN"}};
+                                               {"forkshare", "SRHIP_FORKSHARE"}, {"forkmin", "SRHIP_FORKMIN"}, {"halo", "SRHIP_HALO"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
     {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
@@ -497,6 +497,8 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
         c->fork_share = *v ? std::min(0.9, std::max(0.1, atof(v))) : 0.5;
     } else if (!strcmp(key, "forkmin")) {  // ... automatic rule: fork from this many rounds of tiles on
         c->fork_min_rounds = *v ? atof(v) : 3.5;
+    } else if (!strcmp(key, "halo")) {  // sharded calls: "" / "input": 7 input rows per neighbour, the overlap recomputed; "layers": feature rows after every stage
+        c->layer_halos = !strcmp(v, "layers");
     } else if (!strcmp(key, "bw")) {   // tile-order column-block width in tiles; "" / negative: automatic, 0: plain row-major
         c->env_bw = *v ? atoi(v) : -1;
     } else {
@@ -613,6 +615,7 @@ struct StackJob {
     bool img_u8 = false, out_u8 = false;
     int img_ch = 3, n = 1, H = 0, W = 0, top = 0, bot = 0, tiles_x = 0;
     bool forked = false;  // one of the two bands of sr_run_stack_auto: no 4-row tail (see prepare)
+    bool layers = false;  // every stage computes rows [top, bot) only: the rows beyond come from the neighbours' maps (sr_band_pass)
     // rows [0, late_top) and [H - late_bot, H) of the image arrive with gate->ready (sr_internal.h sr_halo_gate); mark: record gate->mark around the wait
     const sr_halo_gate* gate = nullptr;
     int late_top = 0, late_bot = 0;
@@ -638,8 +641,8 @@ int StackJob::prepare() {
     // ---- plan every launch first: conv0 (the call's first launch) sets the tile-queue heads of the four stage kernels
     for (int st = 0; st < 5; ++st) {
         Launch& l = L[st];
-        l.y0 = std::max(0, top - margin[st]);
-        l.y1 = std::min(H, bot + margin[st]);
+        l.y0 = layers ? top : std::max(0, top - margin[st]);
+        l.y1 = layers ? bot : std::min(H, bot + margin[st]);
         const int rows = l.y1 - l.y0;
         // Tile classes of the launch (sr_kernels.h TileGrid): `ty8` rows of 8-row tiles, then `ty4` rows of 4-row tiles.
         // Measured on MI355X (profiles/r3_tileplans_*, r3_queuefix_*; `rounds` = 8-row tiles per resident workgroup):
@@ -827,6 +830,49 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
     }
     return SR_OK;
 }
+
+struct sr_band_pass {
+    StackJob job;
+};
+
+int sr_band_pass_begin(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int H, int W, int halo_top, int halo_bot, void* d_out, bool out_u8,
+                       hipStream_t s, bool layers, const sr_halo_gate* gate, sr_band_pass** out) {
+    if (!c || !d_img || !d_out || !out || c->graph != SR_GRAPH_SR_NET || H <= 0 || W <= 0) return SR_E_INVALID;
+    *out = nullptr;
+    if (img_u8 && img_ch != 3 && img_ch != 4) return SR_E_INVALID;
+    if ((halo_top != 0 && halo_top < SR_HALO) || (halo_bot != 0 && halo_bot < SR_HALO)) return SR_E_HALO;
+    if (halo_top < 0 || halo_bot < 0 || halo_top + halo_bot >= H) return SR_E_INVALID;
+    sr_device_guard restore_device;
+    HIPCHK(c, hipSetDevice(c->device));
+    sr_band_pass* p = new (std::nothrow) sr_band_pass();
+    if (!p) return SR_E_NOMEM;
+    StackJob& job = p->job;
+    job.c = c; job.ws = &c->ws[0]; job.d_img = d_img; job.d_out = d_out; job.img_u8 = img_u8; job.out_u8 = out_u8;
+    job.img_ch = img_ch; job.n = 1; job.H = H; job.W = W; job.top = halo_top; job.bot = H - halo_bot; job.s = s; job.layers = layers;
+    if (gate) { job.gate = gate; job.late_top = gate->top; job.late_bot = gate->bot; job.mark = true; }
+    const int rc = job.prepare();
+    if (rc != SR_OK) { delete p; return rc; }
+    c->band_pending = false;
+    c->last_h = c->last_w = 0;  // (with `layers` the maps hold this band's own rows and its neighbours' edge rows: not an image sr_read_feature could return)
+    *out = p;
+    return SR_OK;
+}
+
+int sr_band_pass_stage(sr_band_pass* p, int st) {
+    if (!p || st < 0 || st > 4) return SR_E_INVALID;
+    sr_device_guard restore_device;
+    HIPCHK(p->job.c, hipSetDevice(p->job.c->device));
+    return p->job.launch(st);
+}
+
+float* sr_band_pass_row(const sr_band_pass* p, int map, int y) {
+    // pixel (y, -kFeatPad) of the map: in both layouts row y of the padded buffer begins (kFeatPad + y) x pitch pixels of 32 floats in
+    return p->job.ws->d_feat[map] + (size_t)(kFeatPad + y) * p->job.ws->pitch * 32;
+}
+
+size_t sr_band_pass_row_floats(const sr_band_pass* p) { return (size_t)p->job.ws->pitch * 32; }
+
+void sr_band_pass_end(sr_band_pass* p) { delete p; }
 
 // One image as TWO row bands on two streams.  Each band carries the SR_HALO rows of the other it needs and is
 // bit-identical to the undivided pass like every band; the second runs on the context's own second stream and workspace, forked

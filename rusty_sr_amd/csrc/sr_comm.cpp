@@ -170,6 +170,58 @@ sr_halo_gate gate_of(sr_ctx* c, const BandGeom& g) {
     return gate;
 }
 
+// ---- per-layer feature halos (sr_set_experiment "halo" = "layers") -------------------------------------------
+// Instead of recomputing 14 input rows' worth of every stage per interior band, every stage computes the band's own rows and the
+// neighbours' edge rows of its OUTPUT are exchanged before the next stage: f 2 rows (the 5x5 layers read them), l1 / l2 / l3 one row
+// each.  Whole padded map rows travel (pitch x 128 B: 984 KB for f, 492 KB for the others at 3840 px), so the receiver's border columns
+// get the sender's zeros.  The input exchange stays as it is (stage 0 reads 2 of its 7 rows, the residual of the last stage 1).  Same
+// values computed once each instead of twice: bit-identical to the recompute form and to the undivided call.
+constexpr int layer_rows(int st) { return st == 0 ? 2 : 1; }
+
+struct LayerRows {  // what stage st's exchange moves for one context: null where there is no neighbour
+    float *top_send, *top_recv, *bot_send, *bot_recv;
+    size_t count;  // floats per direction
+};
+LayerRows layer_rows_of(const sr_band_pass* bp, const BandGeom& g, int h_band, int st) {
+    const int k = layer_rows(st);
+    LayerRows r{nullptr, nullptr, nullptr, nullptr, (size_t)k * sr_band_pass_row_floats(bp)};
+    if (g.top) { r.top_send = sr_band_pass_row(bp, st, g.top); r.top_recv = sr_band_pass_row(bp, st, g.top - k); }
+    if (g.bot) { r.bot_send = sr_band_pass_row(bp, st, g.top + h_band - k); r.bot_recv = sr_band_pass_row(bp, st, g.top + h_band); }
+    return r;
+}
+
+int post_layer_exchange(sr_ctx* c, Rccl* R, const LayerRows& r, hipStream_t s) {
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    if (r.top_send) {
+        NCCLCHK(c, R->Send(r.top_send, r.count, ncclFloat, c->comm_rank - 1, comm, s));
+        NCCLCHK(c, R->Recv(r.top_recv, r.count, ncclFloat, c->comm_rank - 1, comm, s));
+    }
+    if (r.bot_send) {
+        NCCLCHK(c, R->Send(r.bot_send, r.count, ncclFloat, c->comm_rank + 1, comm, s));
+        NCCLCHK(c, R->Recv(r.bot_recv, r.count, ncclFloat, c->comm_rank + 1, comm, s));
+    }
+    return SR_OK;
+}
+
+// one rank's band pass in that mode: stage, exchange, stage, ... all on `s`
+int run_layers_rank(sr_ctx* c, Rccl* R, bool u8, int img_ch, int h_band, int w, const BandGeom& g, void* d_out, const sr_halo_gate* gate, hipStream_t s) {
+    sr_band_pass* bp = nullptr;
+    int rc = sr_band_pass_begin(c, c->d_ext, u8, img_ch, g.h_ext, w, g.top, g.bot, d_out, u8, s, true, gate, &bp);
+    for (int st = 0; st < 5 && rc == SR_OK; ++st) {
+        rc = sr_band_pass_stage(bp, st);
+        if (rc != SR_OK || st == 4) break;
+        const LayerRows r = layer_rows_of(bp, g, h_band, st);
+        ncclResult_t gs = R->GroupStart();
+        if (gs != ncclSuccess) { c->last_nccl = (int)gs; rc = SR_E_COMM; break; }
+        rc = post_layer_exchange(c, R, r, s);
+        const ncclResult_t ge = R->GroupEnd();
+        if (rc == SR_OK && ge != ncclSuccess) { c->last_nccl = (int)ge; rc = SR_E_COMM; }
+        if (rc != SR_OK) abort_comm(c, R);
+    }
+    if (bp) sr_band_pass_end(bp);
+    return rc;
+}
+
 // one process per GPU: exchange + band pass of this rank, asynchronous on `s`
 int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, int w, void* d_out, hipStream_t s) {
     if (!d_out) return SR_E_INVALID;
@@ -197,7 +249,8 @@ int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, 
         HIPCHK(c, hipEventRecord(c->ev_comm[1], xs));
         gate = gate_of(c, g);
     }
-    rc = sr_run_stack_auto(c, c->d_ext, u8, img_ch, 1, g.h_ext, w, g.top, g.bot, d_out, u8, s, c->comm_nranks > 1 ? &gate : nullptr);
+    if (c->layer_halos && c->comm_nranks > 1) rc = run_layers_rank(c, rccl(), u8, img_ch, h_band, w, g, d_out, &gate, s);
+    else rc = sr_run_stack_auto(c, c->d_ext, u8, img_ch, 1, g.h_ext, w, g.top, g.bot, d_out, u8, s, c->comm_nranks > 1 ? &gate : nullptr);
     if (rc != SR_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev_band[1], s));
     c->comm_pending = c->wait_pending = c->comm_nranks > 1;
@@ -216,7 +269,7 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
         if (ctxs[k]->comm_nranks != n || ctxs[k]->comm_rank != k || !d_outs[k]) return SR_E_INVALID;
     const bool local = ctxs[0]->comm_local;
     for (int k = 1; k < n; ++k)
-        if (ctxs[k]->comm_local != local) return SR_E_INVALID;
+        if (ctxs[k]->comm_local != local || ctxs[k]->layer_halos != ctxs[0]->layer_halos) return SR_E_INVALID;
     sr_device_guard restore_device;
     Rccl* R = n > 1 && !local ? rccl() : nullptr;
     if (n > 1 && !local && !R) return SR_E_COMM;
@@ -279,7 +332,63 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
         if (rc != SR_OK)
             for (int k = 0; k < n; ++k) { (void)hipSetDevice(ctxs[k]->device); abort_comm(ctxs[k], R); }
     }
-    for (int k = 0; k < n && rc == SR_OK; ++k) {
+    const bool layers = n > 1 && ctxs[0]->layer_halos;
+    if (rc == SR_OK && layers) {
+        // Feature halos, all ranks from this thread: the stages go out stage by stage over all contexts, and between two stages every
+        // context gets its neighbours' edge rows -- by peer copy on its own stream behind the neighbours' "stage done" events (local
+        // transport), or by one grouped send / receive round (RCCL).
+        std::vector<sr_band_pass*> bp(n, nullptr);
+        std::vector<sr_halo_gate> gates(n);
+        for (int k = 0; k < n && rc == SR_OK; ++k) {
+            sr_ctx* c = ctxs[k];
+            rc = hip(c, hipSetDevice(c->device));
+            for (auto& e : c->ev_layer) if (rc == SR_OK && !e) rc = hip(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            gates[k] = gate_of(c, g[k]);
+            if (rc == SR_OK) rc = sr_band_pass_begin(c, c->d_ext, u8, img_ch, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, c->stream, true, &gates[k], &bp[k]);
+        }
+        for (int st = 0; st < 5 && rc == SR_OK; ++st) {
+            for (int k = 0; k < n && rc == SR_OK; ++k) {
+                rc = sr_band_pass_stage(bp[k], st);
+                if (rc == SR_OK && st < 4) { rc = hip(ctxs[k], hipSetDevice(ctxs[k]->device)); if (rc == SR_OK) rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_layer[st], ctxs[k]->stream)); }
+            }
+            if (st == 4 || rc != SR_OK) break;
+            if (local) {
+                for (int k = 0; k < n && rc == SR_OK; ++k) {
+                    sr_ctx* c = ctxs[k];
+                    const LayerRows mine = layer_rows_of(bp[k], g[k], h_bands[k], st);
+                    rc = hip(c, hipSetDevice(c->device));
+                    if (rc == SR_OK && mine.top_recv) {  // the upper neighbour's last own rows
+                        const LayerRows theirs = layer_rows_of(bp[k - 1], g[k - 1], h_bands[k - 1], st);
+                        rc = hip(c, hipStreamWaitEvent(c->stream, ctxs[k - 1]->ev_layer[st], 0));
+                        if (rc == SR_OK) rc = hip(c, hipMemcpyPeerAsync(mine.top_recv, c->device, theirs.bot_send, ctxs[k - 1]->device, mine.count * sizeof(float), c->stream));
+                    }
+                    if (rc == SR_OK && mine.bot_recv) {  // the lower neighbour's first own rows
+                        const LayerRows theirs = layer_rows_of(bp[k + 1], g[k + 1], h_bands[k + 1], st);
+                        rc = hip(c, hipStreamWaitEvent(c->stream, ctxs[k + 1]->ev_layer[st], 0));
+                        if (rc == SR_OK) rc = hip(c, hipMemcpyPeerAsync(mine.bot_recv, c->device, theirs.top_send, ctxs[k + 1]->device, mine.count * sizeof(float), c->stream));
+                    }
+                }
+            } else {
+                ncclResult_t gs = R->GroupStart();
+                if (gs != ncclSuccess) { ctxs[0]->last_nccl = (int)gs; rc = SR_E_COMM; break; }
+                for (int k = 0; k < n && rc == SR_OK; ++k) {
+                    (void)hipSetDevice(ctxs[k]->device);
+                    rc = post_layer_exchange(ctxs[k], R, layer_rows_of(bp[k], g[k], h_bands[k], st), ctxs[k]->stream);
+                }
+                const ncclResult_t ge = R->GroupEnd();
+                if (rc == SR_OK && ge != ncclSuccess) { ctxs[0]->last_nccl = (int)ge; rc = SR_E_COMM; }
+                if (rc != SR_OK)
+                    for (int k = 0; k < n; ++k) { (void)hipSetDevice(ctxs[k]->device); abort_comm(ctxs[k], R); }
+            }
+        }
+        for (int k = 0; k < n; ++k) {
+            if (bp[k]) sr_band_pass_end(bp[k]);
+            if (rc == SR_OK) rc = hip(ctxs[k], hipSetDevice(ctxs[k]->device));
+            if (rc == SR_OK) rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_band[1], ctxs[k]->stream));
+            if (rc == SR_OK) { ctxs[k]->comm_pending = ctxs[k]->wait_pending = true; ctxs[k]->band_pending = !ctxs[k]->profiling; }
+        }
+    }
+    for (int k = 0; k < n && rc == SR_OK && !layers; ++k) {
         const sr_halo_gate gate = gate_of(ctxs[k], g[k]);
         rc = sr_run_stack_auto(ctxs[k], ctxs[k]->d_ext, u8, img_ch, 1, g[k].h_ext, w, g[k].top, g[k].bot, d_outs[k], u8, ctxs[k]->stream,
                                n > 1 ? &gate : nullptr);
@@ -311,6 +420,7 @@ void sr_comm_release(sr_ctx* c) {
     for (auto& e : c->ev_band) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto& e : c->ev_wait) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (c->ev_xfork) { (void)hipEventDestroy(c->ev_xfork); c->ev_xfork = nullptr; }
+    for (auto& e : c->ev_layer) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     c->comm_pending = c->band_pending = c->wait_pending = false;
 }
 

@@ -83,6 +83,8 @@ struct sr_ctx {
     double comm_ms = 0;
     int last_nccl = 0;
     bool comm_broken = false;         // an exchange failed half-posted: the communicator was aborted, sharded calls return SR_E_COMM
+    bool layer_halos = false;         // sharded calls exchange FEATURE rows after every stage instead of recomputing the overlap (sr_set_experiment "halo")
+    hipEvent_t ev_layer[4] = {nullptr, nullptr, nullptr, nullptr};  // one-process sharded call in that mode: "stage st of this context is done"
 };
 
 // The library never leaves the calling thread on another device than it found it on: torch (and any HIP host) takes
@@ -126,6 +128,18 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
 int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
                       void* d_out, bool out_u8, hipStream_t s, const sr_halo_gate* gate = nullptr);
 int sr_ensure_fork_resources(sr_ctx* c);  // the second stream + the fork / join events
+
+// One pass of the conv stack over a band, stage by stage -- for a caller that has something to do BETWEEN the stages (sr_comm.cpp:
+// the per-layer feature-halo exchange).  `layers`: every stage computes the band's OWN rows only (no recompute
+// margin); the rows of f / l1 / l2 / l3 that the next stage reads beyond them (2 / 1 / 1 / 1 either side) are the caller's to put
+// into this context's maps before it launches that stage.
+struct sr_band_pass;
+int sr_band_pass_begin(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int H, int W, int halo_top, int halo_bot, void* d_out, bool out_u8,
+                       hipStream_t s, bool layers, const sr_halo_gate* gate, sr_band_pass** out);
+int sr_band_pass_stage(sr_band_pass* p, int st);                 // launch stage st (0..4) on the pass's stream
+float* sr_band_pass_row(const sr_band_pass* p, int map, int y);  // row y (the pass's image coordinates) of map 0..3 = f, l1, l2, l3, border columns included
+size_t sr_band_pass_row_floats(const sr_band_pass* p);           // ... its length: pitch x 32 floats, contiguous in both map layouts
+void sr_band_pass_end(sr_band_pass* p);
 int sr_ensure_buf(sr_ctx* c, void** p, size_t* cap, size_t bytes);
 int sr_ensure_streams(sr_ctx* c, bool pipelined);  // the context's own streams are created on first use
 void sr_comm_release(sr_ctx* c);  // sr_comm.cpp: destroy the communicator and its buffers (called by sr_destroy)

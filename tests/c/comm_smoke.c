@@ -26,6 +26,7 @@
 #include <time.h>
 
 #include "srhip.h"
+#include "srhip_experimental.h" /* the "halo" switch: per-layer feature halos */
 
 #define MAXDEV 16
 #define CHECK(expr) do { int rc_ = (expr); if (rc_ != SR_OK) { fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #expr, rc_, sr_strerror(rc_)); return 1; } } while (0)
@@ -206,7 +207,14 @@ int main(int argc, char** argv) {
         CHECK(sr_comm_init_all(ctxs, ndev));                              /* and back: a set may change transport */
         if (sharded_equals(ctxs, dev, ndev, px, want, "RCCL again")) return 1;
         if (timed_config_c(ctxs, dev, ndev, "RCCL")) return 1;
+        /* feature rows after every stage instead of the recomputed overlap -- same bits, both transports */
+        for (k = 0; k < ndev; ++k) CHECK(sr_set_experiment(ctxs[k], "halo", "layers"));
+        if (sharded_equals(ctxs, dev, ndev, px, want, "RCCL, per-layer feature halos")) return 1;
+        if (timed_config_c(ctxs, dev, ndev, "RCCL, per-layer feature halos")) return 1;
         CHECK(sr_comm_init_local(ctxs, ndev));
+        if (sharded_equals(ctxs, dev, ndev, px, want, "peer copy, per-layer feature halos")) return 1;
+        if (timed_config_c(ctxs, dev, ndev, "peer copy, per-layer feature halos")) return 1;
+        for (k = 0; k < ndev; ++k) CHECK(sr_set_experiment(ctxs[k], "halo", "input"));
         if (timed_config_c(ctxs, dev, ndev, "peer copy")) return 1;
     } else {
         printf("  RCCL over several devices: skipped: 1 device\n");
@@ -217,6 +225,11 @@ int main(int argc, char** argv) {
         CHECK(sr_comm_init_local(two, 2));
         if (sharded_equals(two, dev0, 2, px, want, "peer copy, two contexts of device 0")) return 1;
         if (timed_config_c(two, dev0, 2, "peer copy, both contexts on device 0 (a rehearsal, not a measurement of two GPUs)")) return 1;
+        CHECK(sr_set_experiment(two[0], "halo", "layers"));
+        CHECK(sr_set_experiment(two[1], "halo", "layers"));
+        if (sharded_equals(two, dev0, 2, px, want, "peer copy, per-layer feature halos, two contexts of device 0")) return 1;
+        if (timed_config_c(two, dev0, 2, "peer copy, per-layer feature halos, both contexts on device 0 (a rehearsal)")) return 1;
+        CHECK(sr_set_experiment(two[0], "halo", "input"));
         sr_destroy(two[1]);
         CHECK(sr_comm_init_rank(ctxs[0], NULL, 0, 0, 1));
     }

@@ -53,6 +53,8 @@ def test_bench_single_gpu_contract():
     for ways in (2, 4, 8):
         e = prev[f"{ways}_way"]
         assert e["rows"] == 2160 // ways and e["ms_per_band"] > 0 and 0 < e["useful_roofline_frac"] < 1
+        # ... and projected with per-layer feature halos (nothing recomputed): the kernel work of the band's own rows
+        assert 0 < e["layer_halos"]["kernel_ms_per_band"] <= e["ms_per_band"] * 1.02 and e["useful_roofline_frac"] * 0.98 <= e["layer_halos"]["useful_roofline_frac"] < 1
     assert 0 < d["config_A"]["whole_call_frac"] < 1
     # the split-half mode beside the headline: its dominant kernel against BOTH denominators (the nominal f16 peak and the rate a bare
     # random-operand stream of its instruction sustains on this part), on issued FLOPs (three f16 products per algorithmic one)

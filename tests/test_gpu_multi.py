@@ -243,6 +243,21 @@ def test_sharded_image_through_the_library_on_one_device(params, n, prec):
         edges = np.cumsum([0] + hs)
         outs = r.upscale_sharded_all(engs, [torch.from_numpy(px[a:b]).cuda() for a, b in zip(edges[:-1], edges[1:])])
         np.testing.assert_array_equal(np.concatenate([o.cpu().numpy() for o in outs]), want)
+        # SURVEY 8(e)(ii), per-layer feature halos: every stage computes the band's own rows, the neighbours' edge rows of its output
+        # (f 2, l1 / l2 / l3 one each) are exchanged before the next stage -- nothing recomputed, the same bits
+        for e in engs:
+            e.set_experiment("halo", "layers")
+        for bs, ref in ((bands, want), (bands32, want32), ([torch.from_numpy(px[a:b]).cuda() for a, b in zip(edges[:-1], edges[1:])], want)):
+            for _ in range(2):
+                outs = r.upscale_sharded_all(engs, bs)
+                np.testing.assert_array_equal(np.concatenate([o.cpu().numpy() for o in outs]), ref)
+        engs[-1].set_experiment("halo", "input")
+        with pytest.raises(r.SrError):   # every context of a call must exchange the same way
+            r.upscale_sharded_all(engs, bands)
+        for e in engs:
+            e.set_experiment("halo", "input")
+        outs = r.upscale_sharded_all(engs, bands)  # ... and back: the recompute form on maps that held neighbours' rows
+        np.testing.assert_array_equal(np.concatenate([o.cpu().numpy() for o in outs]), want)
         with pytest.raises(r.SrError):   # a band shorter than the halo its neighbour needs
             r.upscale_sharded_all(engs, [torch.from_numpy(px[:6]).cuda()] + bands[1:])
         with pytest.raises(r.SrError):   # a lone rank of a local communicator cannot see its neighbours
