@@ -55,6 +55,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 MFMA (not t
 MEASURED_F16_MFMA16_RANDOM_TFLOPS = 1967.0  # bare v_mfma_f32_16x16x32_f16 stream on random operands, 20 s: profiles/r6_power_clock_probe.txt
 PEAK_HBM_GBPS = 8000.0
 MARGIN = (5, 3, 2, 1, 0)  # extra rows stage s computes either side of a band (what later stages read)
+# SRHIP_HALO=layers (include/srhip_experimental.h "halo"): the library's sharded calls exchange feature rows after every stage instead
+# of recomputing that overlap -- a band's stages then compute its own rows only
+LAYER_HALOS = os.environ.get("SRHIP_HALO", "") == "layers"
 
 
 def synth_u8(seed, h, w, n=None):
@@ -453,6 +456,8 @@ def main():
             return np.median(np.array(acc), axis=0), float(np.median(comm))
 
         def rows(self):
+            if LAYER_HALOS and self.lib:
+                return [self.hb] * 5
             return [min(self.hb + self.top + self.bot, self.hb + (min(m, self.top) + min(m, self.bot))) for m in MARGIN]
 
     # ------------------------------------------------------------------ the `value` workload (weak scaling)
@@ -810,7 +815,8 @@ def main():
                     "workload": f"3840x2160 RGB x3, {args.io}, resident in HBM" + (f", {world} row bands of {HC // world} rows + 7-row halos "
                                 f"(strong scaling; exchange: {exchange})" if world > 1 else ", one GPU"),
                     "value": round(9 * HC * WC / 1e6 / (ms_c / 1e3), 2), "unit": "output MP/s", "ms_per_step": round(ms_c, 4),
-                    "scaling": "strong", "steps": ksteps, "recompute_overhead": round(sum(p["rows"] + 14 for p in per_rank) / HC - 1, 4) if world > 1 else 0.0,
+                    "scaling": "strong", "steps": ksteps, "recompute_overhead": round(sum(p["rows"] + 14 for p in per_rank) / HC - 1, 4) if world > 1 and not (LAYER_HALOS and use_lib) else 0.0,
+                    **({"halo": "per-layer feature rows (f 2, l1 / l2 / l3 one each way per neighbour), nothing recomputed"} if world > 1 and LAYER_HALOS and use_lib else {}),
                     **n1_reference(ms_c, world, args.precision, args.io),
                     "roofline_frac_per_rank": [p["roofline_frac"] for p in per_rank], "per_rank": per_rank}
             del band

@@ -8,8 +8,9 @@
 #   2. the two tests that skip on one device: contexts on every device (the > 64 KB LDS attribute is per device), and the RCCL-sharded
 #      call + the host-memory multi-device forms over all devices;
 #   3. bench.py --gpus 2 / 4 / 8 (whichever the node has), launched exactly as the driver does: the weak-scaling `value`, config C
-#      (3840x2160 in N row bands: per-rank roofline fraction and halo-exchange time) and config D (64 x 512x512 dealt round-robin).
-# Results: OUTDIR/comm_smoke.txt, OUTDIR/pytest_multi.txt, profiles/r5_scale_N.json (the bench line) and profiles/r5_scale_summary.json
+#      (3840x2160 in N row bands: per-rank roofline fraction, halo-exchange time and how much of it the band's stream waited for) and
+#      config D (64 x 512x512 dealt round-robin); for N > 1 a second line with SRHIP_HALO=layers (per-layer feature halos, nothing recomputed).
+# Results: OUTDIR/comm_smoke.txt, OUTDIR/pytest_multi.txt, profiles/r6_scale_N.json (the bench line) and profiles/r6_scale_summary.json
 # (N -> MP/s, ms per step, config C's ms, per-rank roofline_frac and comm_ms) -- commit the profiles/ files.
 set -u
 cd "$(dirname "$0")/.."
@@ -43,26 +44,32 @@ for N in 1 2 4 8; do
             bench.py --gpus "$N" --steps 20 --warmup 5 > "$OUT/scale_$N.json" 2> "$OUT/scale_$N.err"
     fi
     echo "bench --gpus $N rc=$?"
-    tail -1 "$OUT/scale_$N.json" > "profiles/r5_scale_$N.json"
+    tail -1 "$OUT/scale_$N.json" > "profiles/r6_scale_$N.json"
+    if [ "$N" -gt 1 ]; then  # the same line with feature rows exchanged after every stage instead of the recomputed overlap
+        SRHIP_HALO=layers timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((29600 + N)) \
+            bench.py --gpus "$N" --steps 20 --warmup 5 > "$OUT/scale_layers_$N.json" 2> "$OUT/scale_layers_$N.err"
+        echo "bench --gpus $N (layer halos) rc=$?"
+        tail -1 "$OUT/scale_layers_$N.json" > "profiles/r6_scale_layers_$N.json"
+    fi
 done
 python - "$OUT" <<'PY'
 import glob, json, os, sys
 out = {}
-for f in sorted(glob.glob("profiles/r5_scale_[0-9]*.json")):
+for f in sorted(glob.glob("profiles/r6_scale_[0-9]*.json")) + sorted(glob.glob("profiles/r6_scale_layers_[0-9]*.json")):
     try:
         d = json.loads(open(f).read())
     except Exception as e:  # noqa: BLE001
         out[os.path.basename(f)] = {"error": str(e)}
         continue
     c = d.get("config_C") or {}
-    out[str(d.get("n_gpus"))] = {
+    out[str(d.get("n_gpus")) + ("_layer_halos" if "layers" in f else "")] = {
         "value_mp_s": d.get("value"), "ms_per_step": d.get("ms_per_step"), "scaling": d.get("scaling"), "exchange": (d.get("config") or {}).get("exchange"),
-        "exchange_check": d.get("exchange_check"), "comm_ms": d.get("comm_ms"),
+        "exchange_check": d.get("exchange_check"), "comm_ms": d.get("comm_ms"), "comm_exposed_ms": d.get("comm_exposed_ms"),
         "config_C": {k: c.get(k) for k in ("ms_per_step", "value", "speedup_vs_n1", "efficiency_vs_n1", "roofline_frac_per_rank", "recompute_overhead")},
-        "config_C_per_rank": [{k: p.get(k) for k in ("rank", "rows", "roofline_frac", "comm_ms")} for p in (c.get("per_rank") or []) if p],
+        "config_C_per_rank": [{k: p.get(k) for k in ("rank", "rows", "roofline_frac", "comm_ms", "comm_exposed_ms")} for p in (c.get("per_rank") or []) if p],
         "config_D": {k: (d.get("config_D") or {}).get(k) for k in ("ms_per_step", "value", "images_per_rank")},
     }
-json.dump(out, open("profiles/r5_scale_summary.json", "w"), indent=1)
+json.dump(out, open("profiles/r6_scale_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
 echo "first_multigpu: $([ $rc_all = 0 ] && echo ok || echo FAILURES -- see $OUT)"
