@@ -75,9 +75,12 @@ def soak(budget, seed=None):
                 cuts = np.sort(rng.choice(np.arange(1, h // 7), size=k - 1, replace=False)) * 7
                 edges = [0] + [int(c) for c in cuts] + [h]
                 if min(e1 - e0 for e0, e1 in zip(edges[:-1], edges[1:])) >= 7:
+                    halo = str(rng.choice(["input", "layers"]))  # the recomputed overlap, or feature rows after every stage
+                    for e in group[:k]:
+                        e.set_experiment("halo", halo)
                     outs = r.upscale_sharded_all(group[:k], [px[0, e0:e1].contiguous() for e0, e1 in zip(edges[:-1], edges[1:])])
                     if not torch.equal(torch.cat(outs), ga[0]):
-                        bad.append((prec, "sharded", h, w, edges))
+                        bad.append((prec, "sharded", halo, h, w, edges))
                     stats["sharded"] += 1
             for _ in range(3):
                 if not torch.equal(a.upscale_rgba8_dev(big), first):
