@@ -177,6 +177,29 @@ def test_async_asm_results_are_not_read_before_their_wait():
     assert re.search(r"[1-9]\d* wait tables and [1-9]\d* LDS-DMA m0 writes checked, 0 with an unexpected layout", res.stdout), res.stdout
 
 
+def test_last_stage_of_the_exact_mode_is_on_4x4x1_mfmas():
+    """DESIGN.md 4a': the exact mode's last stage runs its 8-row tiles on v_mfma_f32_4x4x1_16B_f32 with CBSZ = 4 (27 channels in 28 slots:
+    seven 4-slot groups per k-quad, ABID 0-6 and 8-14), its 4-row tiles on 32x32x2; no other kernel uses the instruction; nothing of it
+    spills; and one tile's unrolled body still fits a 64 KB instruction cache with the rest of the loop."""
+    from rusty_sr_amd.build import DEVICE_ASM as asm, build_lib
+    build_lib()
+    text = open(asm).read()
+    kernels = dict(re.findall(r"^(_Z22conv_stage_pipe_kernel\w+):.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M))
+    finals = {k: v for k, v in kernels.items() if re.search(r"ILi3ELi3ELb1ELb[01]ELb[01]ELi0ELi3E", k)}   # <3, 3, FINAL, *, *, PREC 0, FACTOR 3>
+    assert len(finals) == 2, sorted(kernels)
+    for name, body in finals.items():
+        quad = re.findall(r"v_mfma_f32_4x4x1_16b_f32 .*", body)
+        assert len(quad) == (864 + 27) * 7, (name, len(quad))            # 27 taps x 32 channels + the residual's 27 k-steps, seven groups each
+        assert all("cbsz:4" in q for q in quad)
+        abids = {int(m) for q in quad for m in re.findall(r"abid:(\d+)", q)} | ({0} if any("abid" not in q for q in quad) else set())
+        assert abids == set(range(0, 7)) | set(range(8, 15)), abids
+        assert len(re.findall(r"v_mfma_f32_32x32x2_f32", body)) == 27 * 16 + 9 * 2   # the 4-row tile body: 27 taps x 16 + the residual's 18
+        assert "scratch_" not in body and re.search(r"\.amdhsa_private_segment_fixed_size 0", body)
+        assert len(quad) * 8 < 56 * 1024
+    others = [k for k, v in kernels.items() if k not in finals and "v_mfma_f32_4x4x1" in v and not re.search(r"Lb1ELb[01]ELb[01]ELi0ELi[24]E", k)]
+    assert not others, others   # (factor 2 / 4 instances of the same stage use it too: 3 and 8 + 5 groups)
+
+
 def test_parameter_free_kernels_keep_their_loads_global():
     """What made the round-5 kernels of sr_aux.hip fast is visible in their assembly, and easy to lose in an edit: the pixel
     windows must be read with global_load (an integer cast back to a pointer turns them into flat_load, and then every wait the
