@@ -2008,7 +2008,9 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
                 rq = HalfRequest{!st.have_next ? 0 : nsmall_tile ? HalfTile<KSN>::NG_SMALL : HalfTile<KSN>::G::NG,
                                  HalfTile<KSN>::template origin_of<PREC>(a.src[0], 0, a.img_stride, a.pitch, nn, ny0, nx0, wave),
                                  HalfTile<KSN>::plane_of(other, wave)};
-            if constexpr (FINAL && j == NH - 1) linpx.issue(a, n, y0, x0, tid, st);
+            // (kLinOwn: requested and written one half EARLIER than they are read, so that the tile's last half carries only the next
+            // tile's first requests -- profiles/r6_tile_timeline.txt: the last half was the longest of the six)
+            if constexpr (FINAL && j == (kLinOwn ? NH - 2 : NH - 1)) linpx.issue(a, n, y0, x0, tid, st);
             const HalfTile<KSN>* htn;
             if constexpr (KSN == KS0) htn = (const HalfTile<KSN>*)&h0; else htn = (const HalfTile<KSN>*)&h3;
             using GJ = TileGeom<8, KSJ>;
@@ -2019,7 +2021,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
                                     : (j == 0 ? 0 : j == 1 ? H0::STEPS : 2 * H0::STEPS + (j - 2) * H3::STEPS) * NTN;
             constexpr int LIN_LO_J = LinPrefetch<IMG_U8, TH>::NPIX * 8;  // split-half mode: bytes from the hi halves of the image tile to its lo halves
             auto lin_store = [&]() {  // (kLinOwn: the pixels requested at this half's start are long in; see s_xown)
-                if constexpr (kLinOwn && j == NH - 1) {
+                if constexpr (kLinOwn && j == NH - 2) {
                     if constexpr (PREC == 1) linpx.store_split((char*)s_xown, LIN_LO_J, (const uint32_t*)s_lut, 4.0f * FACTOR * FACTOR, tid, st);
                     else linpx.store(s_xown, s_lut, tid, st);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the writes are in LDS before this wave reaches the step's barrier
