@@ -48,3 +48,27 @@ class TorchNet:
         d2s = e.reshape(n, 3, 3, 3, H, W).permute(0, 4, 1, 5, 2, 3).reshape(n, 3 * H, 3 * W, 3)
         lin = F.interpolate(x, scale_factor=3, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)  # LinearInterp, :27
         return (lin + d2s).contiguous().numpy()
+
+    @torch.no_grad()
+    def band_stages(self):
+        """The five stages as callables on ROW-EXTENDED (rows, W, C) maps that return a band's own rows (rusty_sr_amd.shard
+        upscale_sharded_layers: the per-layer feature-halo protocol, tests/test_shard_gloo.py): horizontal zero padding as ever, NO vertical
+        padding -- the extension rows are the neighbours' rows, or the zeros of a true image edge."""
+        w, b, a = self.w, self.b, self.beta
+        nchw = lambda t: t.permute(2, 0, 1)[None].contiguous()
+        nhwc = lambda t: t[0].permute(1, 2, 0).contiguous()
+        conv = lambda t, key, bias, k: F.conv2d(nchw(t), w[key], None if bias is None else b[bias], padding=(0, k // 2))
+        crop = lambda t, d: t[d:t.shape[0] - d]  # an extension of 2 rows seen by a 3x3 conv
+        s0 = lambda x2: nhwc(self._belu(conv(x2, "conv0", "f_bias", 5), a["f_activ"]))
+        s1 = lambda f2: nhwc(self._belu(conv(f2, "conv1", "l1_bias", 5), a["l1_activ"]))
+        s2 = lambda f2, l1: nhwc(self._belu(conv(f2, "conv2", "l2_bias", 5) + conv(l1, "conv5", None, 3), a["l2_activ"]))
+        s3 = lambda f2, l1, l2: nhwc(self._belu(conv(f2, "conv3", "l3_bias", 5) + conv(l1, "conv6", None, 3) + conv(l2, "conv8", None, 3), a["l3_activ"]))
+
+        def s4(l1, l2, l3, x1, top_edge, bot_edge):
+            e = conv(l1, "conv7", "expand_bias", 3) + conv(l2, "conv9", None, 3) + conv(l3, "conv10", None, 3)
+            n, _, H, W = e.shape
+            d2s = e.reshape(n, 3, 3, 3, H, W).permute(0, 4, 1, 5, 2, 3).reshape(3 * H, 3 * W, 3)
+            lin = F.interpolate(nchw(x1), scale_factor=3, mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+            lin = lin[(0 if top_edge else 3):lin.shape[0] - (0 if bot_edge else 3)]  # the neighbours' rows were only there to interpolate towards
+            return (lin + d2s).contiguous()
+        return [s0, s1, s2, s3, s4]

@@ -103,6 +103,54 @@ def upscale_sharded(band: torch.Tensor, rank: int, world: int,
     return compute(ext, xchg.top, xchg.bot)
 
 
+def exchange_rows(t: torch.Tensor, k: int, rank: int, world: int, group=None) -> torch.Tensor:
+    """Per-layer feature halos (libsrhip: sr_set_experiment "halo" = "layers"): `t` is this rank's own rows of one
+    map, (rows, W, C).  Sends its first / last k rows to ranks r-1 / r+1, receives theirs, and returns (k + rows + k, W, C) with the
+    received rows in place -- ZEROS where there is no neighbour (a true image edge: the reference's per-layer zero padding)."""
+    rows = t.shape[0]
+    if world > 1 and rows < k:
+        raise ValueError(f"band of {rows} rows is narrower than the {k} rows its neighbour needs")
+    ext = torch.zeros((rows + 2 * k,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    ext[k:k + rows] = t
+    if world == 1:
+        return ext
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, t[:k].contiguous(), peer(rank - 1), group))
+        ops.append(dist.P2POp(dist.irecv, ext[:k], peer(rank - 1), group))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.isend, t[rows - k:].contiguous(), peer(rank + 1), group))
+        ops.append(dist.P2POp(dist.irecv, ext[k + rows:], peer(rank + 1), group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    return ext
+
+
+LAYER_ROWS = (2, 1, 1, 1)  # rows of f, l1, l2, l3 the next stages read beyond a band (5x5 convs read f; 3x3 convs the others)
+
+
+def upscale_sharded_layers(band: torch.Tensor, rank: int, world: int, stages, group=None) -> torch.Tensor:
+    """One sharded upscale with per-layer feature halos instead of the recomputed overlap.  `band`: this rank's (rows, W, 3) slice.
+    `stages`: five callables working on ROW-EXTENDED maps and returning the band's OWN rows only (no vertical padding of their own: the
+    extension rows are the neighbours' rows, or zeros at a true edge):
+        f  = stages[0](x2)                  x2 = input + 2 rows either side
+        l1 = stages[1](f2)                  f2 = f + 2 rows
+        l2 = stages[2](f2, l1_1)            l1_1 = l1 + 1 row
+        l3 = stages[3](f2, l1_1, l2_1)
+        out = stages[4](l1_1, l2_1, l3_1, x1, top_edge, bottom_edge)    x1 = input + 1 row where a neighbour exists (the bilinear residual
+                                                                        clamps at true edges, it does not zero-pad)
+    Exactly the rows libsrhip moves in that mode (csrc/sr_comm.cpp layer_rows); the same values computed once each."""
+    x2 = exchange_rows(band, 2, rank, world, group)
+    f2 = exchange_rows(stages[0](x2), LAYER_ROWS[0], rank, world, group)
+    l1 = exchange_rows(stages[1](f2), LAYER_ROWS[1], rank, world, group)
+    l2 = exchange_rows(stages[2](f2, l1), LAYER_ROWS[2], rank, world, group)
+    l3 = exchange_rows(stages[3](f2, l1, l2), LAYER_ROWS[3], rank, world, group)
+    top_edge, bot_edge = rank == 0, rank == world - 1
+    x1 = x2[(2 if top_edge else 1):x2.shape[0] - (2 if bot_edge else 1)]
+    return stages[4](l1, l2, l3, x1, top_edge, bot_edge)
+
+
 def init_band_comm(engine, rank: int, world: int, group=None) -> None:
     """Give `engine` (this rank's Engine) its RCCL band communicator INSIDE libsrhip (sr_comm_init_rank): rank 0
     draws the 128-byte id (ncclGetUniqueId), torch.distributed only carries those bytes to the other ranks.  After

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from conftest import ROOT, synth_u8
-from rusty_sr_amd.shard import BandExchange, round_robin, split_rows, upscale_batch_round_robin, upscale_sharded
+from rusty_sr_amd.shard import BandExchange, round_robin, split_rows, upscale_batch_round_robin, upscale_sharded, upscale_sharded_layers
 
 
 def test_split_rows_and_round_robin():
@@ -188,3 +188,33 @@ def test_band_comm_id_travels_and_a_failure_on_rank_0_reaches_every_rank(tmp_pat
     mp.spawn(_id_worker, args=(world, _free_port(), fail_id, str(tmp_path)), nprocs=world, join=True)
     got = [open(tmp_path / f"id_{r}.txt").read() for r in range(world)]
     assert got == (["OSError", "RuntimeError", "RuntimeError"] if fail_id else ["joined"] * world), got
+
+
+def _worker_layers(rank, world, port, h, w, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.torch_ref import TorchNet
+        with open(os.path.join(ROOT, "rusty_sr_amd", "res", "imagenet.rsr"), "rb") as f:
+            params = oracle.rsr_decode(f.read())
+        x = torch.from_numpy(oracle.img_to_data(synth_u8(22, 1, h, w)[0]))
+        a, b = split_rows(h, world)[rank]
+        out = upscale_sharded_layers(x[a:b], rank, world, TorchNet(params).band_stages())
+        assert out.shape == (3 * (b - a), 3 * w, 3)
+        torch.save(out, os.path.join(tmp, f"lay{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 23), (3, 16)])
+def test_per_layer_feature_halos_equal_unsharded_gloo(tmp_path, params, world, h):
+    """SURVEY.md 8(e)(ii), the protocol libsrhip runs with sr_set_experiment("halo", "layers"): every stage computes a band's own rows,
+    the neighbours' edge rows of its output (f 2, l1 / l2 / l3 one each) travel before the next stage -- here over gloo with the
+    torch-CPU restatement as the per-stage compute.  Nothing is recomputed; the ranks' rows together are the unsharded image."""
+    w = 20
+    mp.spawn(_worker_layers, args=(world, _free_port(), h, w, str(tmp_path)), nprocs=world, join=True)
+    got = torch.cat([torch.load(os.path.join(str(tmp_path), f"lay{r}.pt")) for r in range(world)]).numpy()
+    x = oracle.img_to_data(synth_u8(22, 1, h, w)[0])
+    want = oracle.forward(params["imagenet"], x[None])[0]
+    assert got.shape == want.shape and np.abs(got - want).max() < 2e-5  # (oneDNN sums in another order than the C oracle)
