@@ -254,7 +254,8 @@ int run_sharded(sr_ctx* c, const void* d_band, bool u8, int img_ch, int h_band, 
     if (rc != SR_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev_band[1], s));
     c->comm_pending = c->wait_pending = c->comm_nranks > 1;
-    c->band_pending = !c->profiling;  // (with per-stage profiling on, sr_last_timing reports the conv stack's own events)
+    // (with per-stage profiling on, sr_last_timing reports the conv stack's own events -- which the stage-by-stage pass of the layer-halo form does not record)
+    c->band_pending = !c->profiling || (c->layer_halos && c->comm_nranks > 1);
     return SR_OK;
 }
 
@@ -385,7 +386,7 @@ int run_sharded_all(sr_ctx* const* ctxs, int n, const void* const* d_bands, cons
             if (bp[k]) sr_band_pass_end(bp[k]);
             if (rc == SR_OK) rc = hip(ctxs[k], hipSetDevice(ctxs[k]->device));
             if (rc == SR_OK) rc = hip(ctxs[k], hipEventRecord(ctxs[k]->ev_band[1], ctxs[k]->stream));
-            if (rc == SR_OK) { ctxs[k]->comm_pending = ctxs[k]->wait_pending = true; ctxs[k]->band_pending = !ctxs[k]->profiling; }
+            if (rc == SR_OK) { ctxs[k]->comm_pending = ctxs[k]->wait_pending = true; ctxs[k]->band_pending = true; }  // (no per-stage events in this form)
         }
     }
     for (int k = 0; k < n && rc == SR_OK && !layers; ++k) {

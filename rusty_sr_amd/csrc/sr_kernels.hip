@@ -244,29 +244,6 @@ __device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16
         }
     }
 }
-// The same for the 16x16 accumulators of half_steps_h16: one f32x4 = output channel (lane & 15) of its channel half for the four pixels
-// 4 (lane >> 4) + r of its pixel half.  `base`: the lane's first pixel (even lanes) or second (odd lanes) in the row of the channel
-// group, dword ((lane & 7) >> 1) of the 16-byte cell; row-planar maps only.  limit: image columns from that pixel on (MASKED).
-template <bool MASKED>
-__device__ __forceinline__ void store_belu_quad_split(char* base, const f32x4& accm, const f32x4& accx, float beta, bool odd,
-                                                      int limit, long lo_off, uint32_t& dom) {
-    const uint32_t sel = odd ? 0x03020706u : 0x05040100u;  // (see store_belu_tile_split_t)
-    char* base_lo = base + lo_off;
-#pragma unroll
-    for (int r = 0; r < 4; r += 2) {
-        const f32x2 v = belu2_fused(split_value(f32x2{accm[r], accm[r + 1]}, f32x2{accx[r], accx[r + 1]}), beta);  // (the bias is in accm)
-        uint32_t mh, ml;
-        split_half2(v, mh, ml);
-        domain_track(dom, mh);
-        const uint32_t ph = swap_lane_pair(mh), pl = swap_lane_pair(ml);
-        const uint32_t oh = __builtin_amdgcn_perm(ph, mh, sel), ol = __builtin_amdgcn_perm(pl, ml, sel);
-        if (!MASKED || r < limit) {
-            *(uint32_t*)(base + r * 16) = oh;
-            *(uint32_t*)(base_lo + r * 16) = ol;
-        }
-    }
-}
-
 // Where lane i (channel pair (i & ~1, i | 1)) of pixel-row group h writes: the address of pixel x = x0 + 4 h + (i & 1) of map row y.
 __device__ __forceinline__ char* split_store_base(float* dst, size_t n, long img_stride, long y, int pitch, int x, int i) {
     return (char*)(dst + (n * img_stride + y * pitch) * 32) + ((size_t)(i >> 3) * pitch + x) * 16 + ((i & 7) >> 1) * 4;
@@ -554,8 +531,12 @@ __device__ __forceinline__ void lds_dma16(const void* base, uint32_t voff, uint3
 // stream, each worth ~10 cycles of f32-MFMA time.  A constant offset is rematerialised instead (one s_mov).
 __device__ __forceinline__ void lds_dma16_at(const void* base, uint32_t byte_off, uint32_t voff, uint32_t lds) {
     const uint64_t b = (uint64_t)(uintptr_t)base;
+    // (byte_off and lds are wave-uniform at every call site, but under register pressure the compiler may carry such a value -- the ring slot,
+    // say -- in a vector register, and an "s" operand it cannot satisfy is an assembler error: readfirstlane folds away wherever the value
+    // already sits in a scalar register)
     asm volatile("s_add_u32 vcc_lo, %0, %2\n\ts_addc_u32 vcc_hi, %1, 0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, vcc offset:0"
-                 :: "s"((uint32_t)b), "s"((uint32_t)(b >> 32)), "s"(byte_off), "s"(lds), "v"(voff) : "vcc", "scc", "memory");
+                 :: "s"((uint32_t)b), "s"((uint32_t)(b >> 32)), "s"(__builtin_amdgcn_readfirstlane(byte_off)), "s"(__builtin_amdgcn_readfirstlane(lds)), "v"(voff)
+                 : "vcc", "scc", "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
@@ -914,6 +895,11 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
 // lanes 32-63 its second tap -- the per-lane LDS base carries the distance between the two taps' pixels, every read is still one
 // ds_read_b128 at an immediate offset.  A wave's 32 x 32 output tile row is 2 pixel halves x 2 channel halves, each product 3 MFMAs of
 // 16 cycles: 24 per step and tile row pair, the matrix cycles of the 12 it replaces; 12 operand reads per step as before.
+// Round 6: the WEIGHT fragment is passed as the instruction's A operand and the pixel fragment as its B (the two fragments have the same
+// register shape, so this costs nothing): the result is the transposed tile -- lane l holds, for pixel (l & 15) of its pixel half, the four
+// CONSECUTIVE output channels 4 (l >> 4) .. + 3 of its channel half.  Two channels of one pixel pack into a dword without a lane exchange,
+// four into the 8 bytes that are contiguous in the row-planar map: the epilogue loses its two DPP moves and two v_perm per value pair and
+// stores 8 bytes per lane in 256-byte runs instead of 4-byte pieces (stage_epilogue_h16).
 // A half has an ODD number of taps (25, 9).  Leaving one K half of the last MFMA group empty would waste 4-10 % of the matrix work,
 // so the lone last tap of BOTH halves of a source shares one step: the second half BEGINS with it, lanes 0-31 reading the first half's
 // buffer (XD bytes from its own), lanes 32-63 its own.  The first half is pairs only.  Steps per source: 12 + 13 (5x5), 4 + 5 (3x3)
@@ -979,19 +965,19 @@ __device__ __forceinline__ void half_steps_h16(f32x4 (&accm)[T][2][2], f32x4 (&a
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) { accm[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.ah[m][ph], cur.bh[ch], accm[m][ph][ch], 0, 0, 0); after_mfma(); }
+                for (int ch = 0; ch < 2; ++ch) { accm[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.bh[ch], cur.ah[m][ph], accm[m][ph][ch], 0, 0, 0); after_mfma(); }
 #pragma unroll
         for (int m = 0; m < T; ++m)
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) { accx[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.ah[m][ph], cur.bl[ch], accx[m][ph][ch], 0, 0, 0); after_mfma(); }
+                for (int ch = 0; ch < 2; ++ch) { accx[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.bl[ch], cur.ah[m][ph], accx[m][ph][ch], 0, 0, 0); after_mfma(); }
 #pragma unroll
         for (int m = 0; m < T; ++m)
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) { accx[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.al[m][ph], cur.bh[ch], accx[m][ph][ch], 0, 0, 0); after_mfma(); }
+                for (int ch = 0; ch < 2; ++ch) { accx[m][ph][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur.bh[ch], cur.al[m][ph], accx[m][ph][ch], 0, 0, 0); after_mfma(); }
         sm.template end_step<1>(last);
         cur = nxt;
     }
@@ -1363,12 +1349,19 @@ __device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc 
     }
 }
 
-// ... of a tile computed on 16x16 accumulators (kH16; row-planar split-half map): lane l holds output channel 16 ch + (l & 15) for the
-// pixels 16 ph + 4 (l >> 4) + (0..3) of tile row m.
+// ... of a tile computed on 16x16 accumulators (kH16; row-planar split-half map; channels in registers, see half_steps_h16): lane l holds
+// output channels 16 ch + 4 (l >> 4) + (0..3) of pixel 16 ph + (l & 15) of tile row m.  BeLU, the hi / lo split, then one 8-byte store of the
+// four hi halves and one of the four lo halves: half a 16-byte cell of channel group 2 ch + (l >> 5) each (lanes l and l ^ 16 complete it).
+__device__ __forceinline__ f32x2 belu2_fused2(f32x2 v, f32x2 beta) {
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 t = __builtin_elementwise_fma(v, v, one);
+    const f32x2 s = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+    return __builtin_elementwise_fma(beta, v, s) - one;
+}
 template <int T>
 __device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&accm)[T][2][2], f32x4 (&accx)[T][2][2],
-                                                   const float (&beta)[2], int n, int x0, int y0, int wave, int lane, uint32_t& dom) {
-    const int c16 = lane & 15, g = lane >> 4;
+                                                   const f32x4 (&beta)[2], int n, int x0, int y0, int wave, int lane, uint32_t& dom) {
+    const int p16 = lane & 15, g = lane >> 4;
     const bool full_x = x0 + kTW <= a.W;
     const long lo_off = (long)a.pitch * 64;  // the lo group's row: four channel groups further on
 #pragma unroll
@@ -1377,13 +1370,23 @@ __device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&a
         if (y >= a.y_end) continue;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            // channel group 2 ch + (c16 >> 3), dword (c16 & 7) >> 1 of its 16-byte cell; even lanes store the pair's first pixel, odd lanes its second
-            char* row = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch) * 32) + (size_t)(2 * ch + (c16 >> 3)) * a.pitch * 16 + ((c16 & 7) >> 1) * 4;
+            // channel group 2 ch + (g >> 1), bytes 8 (g & 1) .. + 7 of the pixel's 16-byte cell
+            char* row = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch) * 32) + (size_t)(2 * ch + (g >> 1)) * a.pitch * 16 + (g & 1) * 8;
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
-                const int x = x0 + 16 * ph + 4 * g + (c16 & 1);
-                if (full_x) store_belu_quad_split<false>(row + (long)x * 16, accm[m][ph][ch], accx[m][ph][ch], beta[ch], c16 & 1, 0, lo_off, dom);
-                else store_belu_quad_split<true>(row + (long)x * 16, accm[m][ph][ch], accx[m][ph][ch], beta[ch], c16 & 1, a.W - x, lo_off, dom);
+                const int x = x0 + 16 * ph + p16;
+                const f32x4 vm = accm[m][ph][ch], vx = accx[m][ph][ch];  // (the bias is in accm: see split_value)
+                const f32x2 v01 = belu2_fused2(split_value(f32x2{vm[0], vm[1]}, f32x2{vx[0], vx[1]}), f32x2{beta[ch][0], beta[ch][1]});
+                const f32x2 v23 = belu2_fused2(split_value(f32x2{vm[2], vm[3]}, f32x2{vx[2], vx[3]}), f32x2{beta[ch][2], beta[ch][3]});
+                uint32_t h01, l01, h23, l23;
+                split_half2(v01, h01, l01);
+                split_half2(v23, h23, l23);
+                domain_track(dom, h01);
+                domain_track(dom, h23);
+                if (full_x || x < a.W) {
+                    *(uint2*)(row + (long)x * 16) = make_uint2(h01, h23);
+                    *(uint2*)(row + (long)x * 16 + lo_off) = make_uint2(l01, l23);
+                }
             }
         }
     }
@@ -1470,12 +1473,18 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
             if constexpr (PREC == 1) accx[m][r] = 0.f;
         }
     f32x4 qm[H16 ? T : 1][2][2], qx[H16 ? T : 1][2][2];  // ... or, kH16, the same tile as 16x16 accumulators
-    const float bias2[2] = {H16 ? a.bias[lane & 15] : 0.f, H16 ? a.bias[16 + (lane & 15)] : 0.f};
+    // (kH16: lane l holds output channels 16 ch + 4 (l >> 4) + (0..3) of its pixels)
+    f32x4 bias2[2], beta2[2];
     if constexpr (H16) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            bias2[ch] = *(const f32x4*)(a.bias + 16 * ch + 4 * (lane >> 4));
+            beta2[ch] = *(const f32x4*)(a.beta + 16 * ch + 4 * (lane >> 4));
+        }
 #pragma unroll
         for (int m = 0; m < T; ++m)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { qm[m][k >> 1][k & 1] = f32x4{bias2[k & 1], bias2[k & 1], bias2[k & 1], bias2[k & 1]}; qx[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int k = 0; k < 4; ++k) { qm[m][k >> 1][k & 1] = bias2[k & 1]; qx[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
     int gtap = 0, slot = 0;
     auto taps = [&](auto ks_tag) {
@@ -1505,7 +1514,6 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
         lin_taps<TH, T, IMG_U8, NW * 64, NTN, PREC, FACTOR>(acc, accx, tile, ring, a, a.wpack + (size_t)NTAPS * kChunkFloats, n, y0, x0, wave, lane, tid);
     uint32_t dom = 0;
     if constexpr (H16) {
-        const float beta2[2] = {a.beta[lane & 15], a.beta[16 + (lane & 15)]};
         stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
     } else {
         stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
@@ -1879,9 +1887,13 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NTN; ++nt) bias[nt] = a.bias[nt * 32 + i];
     const float beta = FINAL ? 0.f : a.beta[i];
-    // (kH16: lane l holds output channels (l & 15) and 16 + (l & 15))
-    const float bias2[2] = {H16 ? a.bias[lane & 15] : 0.f, H16 ? a.bias[16 + (lane & 15)] : 0.f};
-    const float beta2[2] = {H16 ? a.beta[lane & 15] : 0.f, H16 ? a.beta[16 + (lane & 15)] : 0.f};
+    // (kH16: lane l holds output channels 16 ch + 4 (l >> 4) + (0..3) of its pixels)
+    f32x4 bias2[2], beta2[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        bias2[ch] = H16 ? *(const f32x4*)(a.bias + 16 * ch + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        beta2[ch] = H16 ? *(const f32x4*)(a.beta + 16 * ch + 4 * (lane >> 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // (quad form of the exact mode's last stage: a lane holds every channel of its pixel, so it needs every channel's bias -- wave-uniform
     // values kept in vector registers for the whole launch; loaded per tile they came through the vector memory path, whose waits sat out
     // the next tile's DMAs)
@@ -1967,7 +1979,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
 #pragma unroll
             for (int m = 0; m < T; ++m)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { qm[m][k >> 1][k & 1] = f32x4{bias2[k & 1], bias2[k & 1], bias2[k & 1], bias2[k & 1]}; qx[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int k = 0; k < 4; ++k) { qm[m][k >> 1][k & 1] = bias2[k & 1]; qx[m][k >> 1][k & 1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
         // the exact mode's last stage, 8-row tiles: 4x4x1 MFMAs, the lane's own pixel in 4-slot groups (half_steps_f32 QUAD)
         constexpr bool QUAD = FINAL && PREC == 0 && T == 2;
