@@ -121,6 +121,13 @@ __device__ __forceinline__ f32x2 belu2_fused(f32x2 v, float beta) {
     const f32x2 s = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
     return __builtin_elementwise_fma(f32x2{beta, beta}, v, s) - one;
 }
+// ... with a slope per value (the two values are two CHANNELS of one pixel: accumulators computed with the weights as the MFMA's A operand)
+__device__ __forceinline__ f32x2 belu2_fused2(f32x2 v, f32x2 beta) {
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 t = __builtin_elementwise_fma(v, v, one);
+    const f32x2 s = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+    return __builtin_elementwise_fma(beta, v, s) - one;
+}
 
 // BeLU(acc + bias) of one 32x32 accumulator tile -> NHWC rows at base + row*32 floats
 // (row pairs r, r+1 are adjacent pixels); immediate-offset stores only.
@@ -260,6 +267,30 @@ __device__ __forceinline__ void store_belu_tile_split_masked(char* base, const f
 // Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`
 // (row = (r&3) + 8*(r>>2); the lane's +4*h is already in `base`): compile-time
 // offsets, so each store is one instruction with an immediate.
+// The same tile computed with the WEIGHT fragment as the MFMA's A operand (the transposed product: the two fragments have the same register
+// shape): lane (i, h) holds, of pixel i of the tile row, output channels 8 j + 4 h + (0..3) in registers 4 j + (0..3).  Two channels of a
+// pixel pack into a dword with no lane exchange, four are the 8 bytes 8 h .. 8 h + 7 of the pixel's 16-byte cell in channel group j: one
+// 8-byte store of hi halves and one of lo halves per group, lanes i and i + 32 completing the cell, a wave writing 512 contiguous bytes.
+// `base`: the lane's pixel in the row of channel group 0, + 8 h; groups are `group_stride` bytes apart, the lo groups `lo_off` further on.
+__device__ __forceinline__ void store_belu_tile_split_cr(char* base, const f32x16& accm, const f32x16& accx, const f32x4 (&beta)[4], bool write,
+                                                         long group_stride, long lo_off, uint32_t& dom) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * j;
+        const f32x2 v01 = belu2_fused2(split_value(f32x2{accm[r], accm[r + 1]}, f32x2{accx[r], accx[r + 1]}), f32x2{beta[j][0], beta[j][1]});  // (the bias is in accm)
+        const f32x2 v23 = belu2_fused2(split_value(f32x2{accm[r + 2], accm[r + 3]}, f32x2{accx[r + 2], accx[r + 3]}), f32x2{beta[j][2], beta[j][3]});
+        uint32_t h01, l01, h23, l23;
+        split_half2(v01, h01, l01);
+        split_half2(v23, h23, l23);
+        domain_track(dom, h01);
+        domain_track(dom, h23);
+        if (write) {
+            *(uint2*)(base + j * group_stride) = make_uint2(h01, h23);
+            *(uint2*)(base + j * group_stride + lo_off) = make_uint2(l01, l23);
+        }
+    }
+}
+
 template <typename F>
 __device__ __forceinline__ void for_each_acc_row(F&& f) {
 #pragma unroll
@@ -424,7 +455,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
     }
     const char* abase = (const char*)&s_px[0][0] + ((wave * T) * TWH + i) * 8;
     constexpr uint32_t LO = NPIX * 2 * 4;  // bytes from the hi array to the lo array
-    const float bias = a.bias[i], beta = a.beta[i];
+    // The weights are the MFMA's A operand, the pixels its B: lane (i, h) holds output channels 8 j + 4 h + (0..3) of pixel i (store_belu_tile_split_cr)
+    f32x4 bias4[4], beta4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bias4[j] = *(const f32x4*)(a.bias + 8 * j + 4 * h);
+        beta4[j] = *(const f32x4*)(a.beta + 8 * j + 4 * h);
+    }
     uint32_t dom = 0;  // the largest hi half this thread has produced, inputs included (domain_track)
     for (int bid = blockIdx.x; bid < a.n_tiles; bid += gridDim.x) {
         const int n = tile_div(bid, a.div_tpi), t = bid - n * tiles_per_img;
@@ -460,7 +497,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
 #pragma unroll
         for (int m = 0; m < T; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accm[m][r] = bias; accx[m][r] = 0.f; }  // (the bias rides in the accumulator, see split_value)
+            for (int r = 0; r < 16; ++r) { accm[m][r] = bias4[r >> 2][r & 3]; accx[m][r] = 0.f; }  // (the bias rides in the accumulator, see split_value)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const f16x8 bh = wl[(b * 2 + 0) * 64], bl = wl[(b * 2 + 1) * 64];
@@ -472,9 +509,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
                 const uint2 la = *(const uint2*)(ra + LO), lb2 = *(const uint2*)(rb + LO);
                 const uint32_t ahw[4] = {ha.x, ha.y, hb2.x, hb2.y}, alw[4] = {la.x, la.y, lb2.x, lb2.y};
                 const f16x8 ah = __builtin_bit_cast(f16x8, ahw), al = __builtin_bit_cast(f16x8, alw);
-                accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[m], 0, 0, 0);
-                accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[m], 0, 0, 0);
-                accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[m], 0, 0, 0);
+                accm[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, accm[m], 0, 0, 0);
+                accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, accx[m], 0, 0, 0);
+                accx[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, accx[m], 0, 0, 0);
             }
         }
 
@@ -483,9 +520,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
         for (int m = 0; m < T; ++m) {
             const int y = y0 + wave * T + m;
             if (y >= a.y_end) continue;
-            char* base = split_store_base(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
-            if (full_x) store_belu_tile_split(base, accm[m], accx[m], beta, i & 1, a.pitch, dom);
-            else store_belu_tile_split_masked(base, accm[m], accx[m], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
+            char* base = (char*)(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch) * 32) + (size_t)(x0 + i) * 16 + 8 * h;
+            store_belu_tile_split_cr(base, accm[m], accx[m], beta4, full_x || x0 + i < a.W, (long)a.pitch * 16, (long)a.pitch * 64, dom);
         }
     }
     domain_report(dom, a.domain);
@@ -1352,12 +1388,6 @@ __device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc 
 // ... of a tile computed on 16x16 accumulators (kH16; row-planar split-half map; channels in registers, see half_steps_h16): lane l holds
 // output channels 16 ch + 4 (l >> 4) + (0..3) of pixel 16 ph + (l & 15) of tile row m.  BeLU, the hi / lo split, then one 8-byte store of the
 // four hi halves and one of the four lo halves: half a 16-byte cell of channel group 2 ch + (l >> 5) each (lanes l and l ^ 16 complete it).
-__device__ __forceinline__ f32x2 belu2_fused2(f32x2 v, f32x2 beta) {
-    const f32x2 one = {1.0f, 1.0f};
-    const f32x2 t = __builtin_elementwise_fma(v, v, one);
-    const f32x2 s = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
-    return __builtin_elementwise_fma(beta, v, s) - one;
-}
 template <int T>
 __device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&accm)[T][2][2], f32x4 (&accx)[T][2][2],
                                                    const f32x4 (&beta)[2], int n, int x0, int y0, int wave, int lane, uint32_t& dom) {
