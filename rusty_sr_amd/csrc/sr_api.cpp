@@ -67,6 +67,10 @@ int expand_channel(int f, int nt, int j) {
     return (jj < 15 && tr < f * f) ? tr * 3 + jj % 3 : -1;
 }
 int expand_tiles(int f) { return (f * f + 9) / 10; }
+// The split-half mode's last stage computes the transposed tile (weights as the MFMA's A operand, sr_kernels.hip half_steps_h): lane
+// (pixel, h) then holds output slots 8 a + 4 h + b (a, b = 0..3) in register 4 a + b.  Slot j of that form carries the channel that sits in
+// column 16 h + 4 a + b of the layout above, so a lane's sixteen registers are the five whole triples of "row" h (stage_epilogue_final_t).
+int expand_channel_t(int f, int nt, int j) { return expand_channel(f, nt, 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3)); }
 
 // Weight chunks of the stage kernels (both forms): one 4 KB chunk per STEP = two taps of one 16-channel half
 // (and, for a node with more than 32 output channels, per N-tile).  Steps run half 0 (channels 0-15) over the
@@ -220,7 +224,7 @@ void pack_lin_split(std::vector<float>& dst, int f) {
             for (int h = 0; h < 2; ++h)
                 for (int j = 0; j < 32; ++j)
                     for (int e = 0; e < 8; ++e) {
-                        const int s = 16 * b + 8 * h + e, tap = s / 4, c = s % 4, ch = expand_channel(f, nt, j);
+                        const int s = 16 * b + 8 * h + e, tap = s / 4, c = s % 4, ch = expand_channel_t(f, nt, j);
                         if (tap >= 9 || c >= 3 || ch < 0 || ch % 3 != c) continue;
                         const int tr = ch / 3, dy = tr / f, dx = tr % f;
                         hp[(((size_t)(b * ntn + nt) * 2 + h) * 32 + j) * 8 + e] = (_Float16)std::nearbyint(w1[dy][tap / 3] * w1[dx][tap % 3] * scale);
@@ -368,7 +372,7 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
         c->off_w0h = push(w);
         for (int split = 0; split < 2; ++split) {  // exact-f32 chunks, then the same stages in split-half form
             auto ident = [](int, int j) { return j; };
-            auto expand = [&](int nt, int j) { return expand_channel(factor, nt, j); };
+            auto expand = [&](int nt, int j) { return split ? expand_channel_t(factor, nt, j) : expand_channel(factor, nt, j); };
             const bool h16 = split != 0;  // stages 1-3 of the split-half mode on 16x16x32 MFMAs: their own step order
             auto conv = [&](const float* wp, int ks) { if (h16) pack_steps_h16(w, wp, ks); else pack_steps(w, wp, ks, 1, split != 0, ident); };
             auto exp3 = [&](const float* wp) { pack_steps(w, wp, 3, expand_tiles(factor), split != 0, expand); };

@@ -793,6 +793,9 @@ __device__ __forceinline__ void half_steps_f32(Acc& acc, const char* hb, const c
     }
 }
 
+// (Round 6, as in half_steps_h16: the WEIGHT fragment is the instruction's A operand and the pixel fragment its B -- same register shapes -- so
+// the accumulators hold the transposed tile: lane (i, h) has, of pixel i of the tile row, output slots 8 j + 4 h + (0..3) in registers
+// 4 j + (0..3).  This loop only serves the split-half mode's LAST stage, whose epilogue is then lane-local: stage_epilogue_final_t.)
 template <int TWH, int PS, int LO, int KS, int T, int NTN, typename Stream>
 __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&accx)[NTN * T], const char* hb, const char* ring,
                                              Stream& sm, int wave, int lane) {
@@ -910,11 +913,11 @@ __device__ __forceinline__ void half_steps_h(f32x16 (&accm)[NTN * T], f32x16 (&a
         for (int ts = 0; ts < 2; ++ts) {
             if (2 * p + ts < NT) {
 #pragma unroll
-                for (int m = 0; m < T; ++m) { accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bh[ts], accm[nt * T + m], 0, 0, 0); after_mfma(); }
+                for (int m = 0; m < T; ++m) { accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.bh[ts], cur.ah[ts][m], accm[nt * T + m], 0, 0, 0); after_mfma(); }
 #pragma unroll
-                for (int m = 0; m < T; ++m) { accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.ah[ts][m], cur.bl[ts], accx[nt * T + m], 0, 0, 0); after_mfma(); }
+                for (int m = 0; m < T; ++m) { accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.bl[ts], cur.ah[ts][m], accx[nt * T + m], 0, 0, 0); after_mfma(); }
 #pragma unroll
-                for (int m = 0; m < T; ++m) { accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.al[ts][m], cur.bh[ts], accx[nt * T + m], 0, 0, 0); after_mfma(); }
+                for (int m = 0; m < T; ++m) { accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.bh[ts], cur.al[ts][m], accx[nt * T + m], 0, 0, 0); after_mfma(); }
             } else {  // the lone last tap of an odd kernel: the second tap slot is empty, its items still have to be issued
 #pragma unroll
                 for (int m = 0; m < 3 * T; ++m) after_mfma();
@@ -1137,8 +1140,8 @@ __device__ __forceinline__ void lin_mfma_h(f32x16 (&accm)[NTN * T], f32x16 (&acc
             const f16x8 bw = s_w[((b * NTN + nt) * 2 + h) * 32 + i];
 #pragma unroll
             for (int m = 0; m < T; ++m) {
-                accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bw, accm[nt * T + m], 0, 0, 0);
-                accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bw, accx[nt * T + m], 0, 0, 0);
+                accm[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, ah[m], accm[nt * T + m], 0, 0, 0);  // (weights as A: see half_steps_h)
+                accx[nt * T + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw, al[m], accx[nt * T + m], 0, 0, 0);
             }
         }
     }
@@ -1323,6 +1326,104 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
             }
         }
     }
+}
+
+// n consecutive dwords (n a constant after unrolling) at a 4-byte-aligned address, as the widest stores there are
+template <int N>
+struct __attribute__((packed, aligned(4))) DwordRun { uint32_t w[N]; };
+template <int N>
+__device__ __forceinline__ void store_run_n(char* o, const uint32_t* w) {
+    DwordRun<N> r;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.w[k] = w[k];
+    *(DwordRun<N>*)o = r;
+}
+__device__ __forceinline__ void store_run_dwords(char* o, const uint32_t* w, int n) {
+    if (n == 1) store_run_n<1>(o, w);
+    else if (n == 2) store_run_n<2>(o, w);
+    else if (n == 3) store_run_n<3>(o, w);
+    else if (n == 4) store_run_n<4>(o, w);
+    else if (n == 6) store_run_n<6>(o, w);
+    else if (n == 9) store_run_n<9>(o, w);
+    else if (n == 12) store_run_n<12>(o, w);
+}
+// ... of the split-half mode's last stage (transposed accumulators, see half_steps_h): lane (i, h) holds, of pixel x0 + i of tile row m, the
+// sixteen output slots 8 (r >> 2) + 4 h + (r & 3), r = 0..15, of every N-tile -- and the host packs the expand channels so that those are
+// the five WHOLE RGB triples tl = 5 h + r / 3, colour r % 3, of sub-pixel tr = 10 nt + tl (sr_api.cpp expand_channel_t; r = 15 idle): the
+// triples of "16-lane row" h of the exact mode's layout, whose biases a.bias[32 nt + 16 h + r] are therefore sixteen consecutive floats.
+// Depth-to-space and the RGBA packing are lane-local (no DPP), a lane's sub-pixels of one output row are contiguous and stored together,
+// consecutive lanes continue the row.  Same arithmetic per value as stage_epilogue.
+template <int T, int NTN, bool OUT_U8, int FACTOR>
+__device__ __forceinline__ void stage_epilogue_final_t(const StageArgs& a, f32x16 (&accm)[NTN * T], f32x16 (&accx)[NTN * T], const f32x4 (&fbias)[NTN][4],
+                                                       int n, int x0, int y0, int wave, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    const int OW = a.W * FACTOR, h_band = a.y_end - a.y_begin;
+    constexpr int OPX = OUT_U8 ? 4 : 12;  // bytes per output pixel
+    if (x0 + i >= a.W) return;
+    // output row of the wave's first tile row, sub-row 0, at the lane's pixel
+    char* lbase = (char*)a.out + (((size_t)n * h_band + (size_t)(y0 + wave * T - a.y_begin)) * FACTOR * OW + (size_t)(x0 + i) * FACTOR) * OPX;
+    auto body = [&](auto hc) {
+        constexpr int H = decltype(hc)::value;
+#pragma unroll
+        for (int m = 0; m < T; ++m) {
+            if (y0 + wave * T + m >= a.y_end) continue;
+            char* mbase = lbase + (size_t)m * FACTOR * OW * OPX;
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                const f32x16& am = accm[nt * T + m];
+                const f32x16& ax = accx[nt * T + m];
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 s = (f32x2{am[r], am[r + 1]} + f32x2{ax[r], ax[r + 1]} * f32x2{1.0f / kLoScale, 1.0f / kLoScale}) +
+                                    f32x2{fbias[nt][r >> 2][r & 3], fbias[nt][(r + 1) >> 2][(r + 1) & 3]};
+                    if constexpr (OUT_U8) {
+                        // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255 -- v_cvt_pk_u8_f32 of the floor (see stage_epilogue)
+                        const f32x2 q = s * f32x2{255.0f, 255.0f} + f32x2{0.5f, 0.5f};
+                        v[r] = floorf(q.x); v[r + 1] = floorf(q.y);
+                    } else {
+                        v[r] = s.x; v[r + 1] = s.y;
+                    }
+                }
+                // the lane's triples tl = 0..4 are sub-pixels tr = 10 nt + 5 H + tl (below f^2): a run of consecutive dx within one output row dy
+                // starts at the lane's first triple and wherever dx = 0 (everything here is a constant after unrolling)
+#pragma unroll
+                for (int tl = 0; tl < 5; ++tl) {
+                    constexpr int F2 = FACTOR * FACTOR;
+                    const int tr = 10 * nt + 5 * H + tl;
+                    if (tr >= F2) continue;
+                    const int dy = tr / FACTOR, dx = tr % FACTOR;
+                    if (tl != 0 && dx != 0) continue;
+                    int run = FACTOR - dx;                    // to the end of the output row ...
+                    if (run > 5 - tl) run = 5 - tl;           // ... of the lane's triples ...
+                    if (run > F2 - tr) run = F2 - tr;         // ... of the sub-pixels
+                    char* o = mbase + ((size_t)dy * OW + dx) * OPX;
+                    uint32_t w[12];
+                    int ndw;
+                    if constexpr (OUT_U8) {
+                        ndw = run;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (k >= run) continue;
+                            uint32_t px = 0xff000000u;
+                            px = __builtin_amdgcn_cvt_pk_u8_f32(v[3 * (tl + k) + 0], 0u, px);
+                            px = __builtin_amdgcn_cvt_pk_u8_f32(v[3 * (tl + k) + 1], 1u, px);
+                            px = __builtin_amdgcn_cvt_pk_u8_f32(v[3 * (tl + k) + 2], 2u, px);
+                            w[k] = px;
+                        }
+                    } else {
+                        ndw = 3 * run;
+#pragma unroll
+                        for (int k = 0; k < 12; ++k)
+                            if (k < 3 * run) w[k] = __float_as_uint(v[3 * tl + k]);
+                    }
+                    store_run_dwords(o, w, ndw);
+                }
+            }
+        }
+    };
+    if (h == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
 }
 
 // ... of a tile computed in the quad form: the lane holds every expand channel of ITS pixel (x0 + lane % 32, tile row 2 wave + lane / 32),
@@ -1545,6 +1646,13 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
     uint32_t dom = 0;
     if constexpr (H16) {
         stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
+    } else if constexpr (FINAL && PREC == 1) {
+        f32x4 fbias[NTN][4];  // (transposed accumulators: lane (i, h) holds the slots whose biases are a.bias[32 nt + 16 h + (0..15)])
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fbias[nt][k] = *(const f32x4*)(a.bias + 32 * nt + 16 * (lane >> 5) + 4 * k);
+        stage_epilogue_final_t<T, NTN, OUT_U8, FACTOR>(a, acc, accx, fbias, n, x0, y0, wave, lane);
     } else {
         stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
     }
@@ -1927,6 +2035,15 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
     // (quad form of the exact mode's last stage: a lane holds every channel of its pixel, so it needs every channel's bias -- wave-uniform
     // values kept in vector registers for the whole launch; loaded per tile they came through the vector memory path, whose waits sat out
     // the next tile's DMAs)
+    // (split-half mode's last stage, transposed accumulators: lane (i, h) holds the slots whose biases are a.bias[32 nt + 16 h + (0..15)], stage_epilogue_final_t)
+    constexpr bool kFinalT = FINAL && PREC == 1;
+    f32x4 fbias[kFinalT ? NTN : 1][4];
+    if constexpr (kFinalT) {
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fbias[nt][k] = *(const f32x4*)(a.bias + 32 * nt + 16 * (lane >> 5) + 4 * k);
+    }
     constexpr bool kQuad = FINAL && PREC == 0;
     float qbias[kQuad ? 3 * FACTOR * FACTOR : 1];
     if constexpr (kQuad) {
@@ -2101,6 +2218,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         }
         if constexpr (H16) stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
         else if constexpr (QUAD) stage_epilogue_quad<NTN, OUT_U8, FACTOR>(a, qa, qbias, n, x0, y0, wave, lane);
+        else if constexpr (kFinalT) stage_epilogue_final_t<T, NTN, OUT_U8, FACTOR>(a, acc, accx, fbias, n, x0, y0, wave, lane);
         else stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
     };
 
