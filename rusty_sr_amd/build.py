@@ -12,6 +12,9 @@ HEADERS = ["sr_kernels.h", "sr_internal.h", os.path.join("..", "..", "include", 
 
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread"]
+# the stage kernels only: the split-half epilogues spell their pair arithmetic as scalar instructions on purpose (sr_kernels.hip f32p) and
+# must not be packed again; the exact mode's packed instructions are explicit vector types and stay
+KERNEL_FLAGS = ["-fno-slp-vectorize"]
 
 
 def _newer(target, deps):
@@ -44,7 +47,7 @@ def build_lib(force=False, verbose=False):
                 temps = os.path.join(objdir, f"temps.{os.getpid()}")
                 os.makedirs(temps, exist_ok=True)
                 tmp = os.path.join(temps, f + ".o")
-                cmd = [hipcc, "-save-temps=obj", *FLAGS, "-x", "hip", "-c", src, "-o", tmp]
+                cmd = [hipcc, "-save-temps=obj", *FLAGS, *KERNEL_FLAGS, "-x", "hip", "-c", src, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             try:

@@ -56,6 +56,15 @@
 #pragma clang fp contract(off)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// A pair of values worked on with TWO scalar instructions per operation.  The split-half mode's epilogues run beside the partner wave's f16
+// MFMAs, where a packed f32 instruction (v_pk_fma_f32 ...) costs more than the two scalar ones it replaces (MI355X_MICROARCH.md "price of
+// one filler beside MFMAs"; profiles/r6_ab_epilogue_scalar.txt: -1.2 % at 1080p).  The file is built with -fno-slp-vectorize so that the
+// compiler does not pack them again.  (The exact mode keeps f32x2: there every vector instruction is paid in f32-MFMA time, so fewer is better.)
+struct f32p { float x, y; };
+__device__ __forceinline__ f32p operator+(f32p a, f32p b) { return f32p{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f32p operator-(f32p a, f32p b) { return f32p{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f32p operator*(f32p a, f32p b) { return f32p{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f32p p_fma(f32p a, f32p b, f32p c) { return f32p{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -109,24 +118,18 @@ __device__ __forceinline__ f32x2 belu2(f32x2 v, float beta) {
 }
 
 // The split-half mode's epilogues: the node's bias is folded into the main accumulators' initial value, and the arithmetic uses explicit
-// packed FMAs -- v = accm + accx / 2048 and BeLU are 4 packed instructions + 2 v_sqrt_f32 per value pair instead of 8 + 2.  (This mode is
+// FMAs -- v = accm + accx / 2048 and BeLU are 4 operations + 1 v_sqrt_f32 per value instead of 8 + 1.  (This mode is
 // held to the 1e-4 bar against the oracle, not to bit-identity with the exact mode, whose belu2 keeps the reference's unfused order; every
 // form and band of THIS mode runs the same code and stays bit-identical to the others.)
-__device__ __forceinline__ f32x2 split_value(f32x2 accm, f32x2 accx) {
-    return __builtin_elementwise_fma(accx, f32x2{1.0f / 2048.0f, 1.0f / 2048.0f}, accm);
+__device__ __forceinline__ f32p split_value(f32p accm, f32p accx) {
+    return p_fma(accx, f32p{1.0f / 2048.0f, 1.0f / 2048.0f}, accm);
 }
-__device__ __forceinline__ f32x2 belu2_fused(f32x2 v, float beta) {
-    const f32x2 one = {1.0f, 1.0f};
-    const f32x2 t = __builtin_elementwise_fma(v, v, one);
-    const f32x2 s = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
-    return __builtin_elementwise_fma(f32x2{beta, beta}, v, s) - one;
-}
-// ... with a slope per value (the two values are two CHANNELS of one pixel: accumulators computed with the weights as the MFMA's A operand)
-__device__ __forceinline__ f32x2 belu2_fused2(f32x2 v, f32x2 beta) {
-    const f32x2 one = {1.0f, 1.0f};
-    const f32x2 t = __builtin_elementwise_fma(v, v, one);
-    const f32x2 s = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
-    return __builtin_elementwise_fma(beta, v, s) - one;
+// (a slope per value: the two values are two CHANNELS of one pixel -- accumulators computed with the weights as the MFMA's A operand)
+__device__ __forceinline__ f32p belu2_fused2(f32p v, f32p beta) {
+    const f32p one = {1.0f, 1.0f};
+    const f32p t = p_fma(v, v, one);
+    const f32p s = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+    return p_fma(beta, v, s) - one;
 }
 
 // BeLU(acc + bias) of one 32x32 accumulator tile -> NHWC rows at base + row*32 floats
@@ -191,19 +194,12 @@ __device__ __forceinline__ float load_img(const void* img, int img_ch, bool u8, 
 constexpr float kLoScale = 2048.0f;
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));  // what v_cvt_pkrtz_f16_f32 returns
 
-// Exchange a dword with the neighbouring lane (lane ^ 1): one v_mov_b32_dpp quad_perm:[1,0,3,2]
-// -- pure VALU.  (__shfl_xor lowers to ds_bpermute_b32: an LDS-crossbar op whose lgkmcnt wait
-// also stalls on every operand ds_read in flight.)
-__device__ __forceinline__ uint32_t swap_lane_pair(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
-}
-
 // Split two f32 values: packed hi halves / packed lo halves (2 x v_cvt_pkrtz, 2 x v_cvt_f32_f16,
-// one packed subtract, one packed multiply).
-__device__ __forceinline__ void split_half2(f32x2 v, uint32_t& hi2, uint32_t& lo2) {
+// two subtractions, two multiplications).
+__device__ __forceinline__ void split_half2(f32p v, uint32_t& hi2, uint32_t& lo2) {
     const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
-    const f32x2 hf = {(float)h.x, (float)h.y};
-    const f32x2 r = (v - hf) * f32x2{kLoScale, kLoScale};
+    const f32p hf = {(float)h.x, (float)h.y};
+    const f32p r = (v - hf) * f32p{kLoScale, kLoScale};
     hi2 = __builtin_bit_cast(uint32_t, h);
     lo2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r.x, r.y));
 }
@@ -221,54 +217,8 @@ __device__ __forceinline__ void domain_report(uint32_t dom, int* flag) {
     if (((dom & 0xffffu) >= 0x7bffu) | ((dom >> 16) >= 0x7bffu)) *(volatile int*)flag = 1;
 }
 
-// BeLU(acc) of one 32x32 tile -> split-half NHWC rows.  A feature pixel is 128 B:
-// 32 hi halves then 32 lo halves.  Lane = channel j, register pair (r, r+1) = two
-// adjacent pixels: even lanes collect channels (j, j+1) of pixel `row` from their
-// odd neighbour, odd lanes channels (j-1, j) of pixel `row+1` (one DPP swap + one
-// v_perm_b32 each), so every store is a full dword.  `base` points at this lane's pixel (x0 + 4h + (j&1)) in the row of its hi
-// channel group (row-planar map, see kPlanar), dword (j % 8) / 2 of the 16-byte group; consecutive pixels are 16 bytes apart and the
-// lo group's row lies `lo_off` = 4 x pitch x 16 bytes further on; `limit` = image columns left of the lane's pixel.
-template <bool MASKED>
-__device__ __forceinline__ void store_belu_tile_split_t(char* base, const f32x16& accm, const f32x16& accx,
-                                                        float beta, bool odd, int limit, long lo_off, uint32_t& dom) {
-    // v_perm_b32(src0 = partner, src1 = mine): bytes 0-3 = mine, 4-7 = partner
-    const uint32_t sel = odd ? 0x03020706u   // (partner.hi16, mine.hi16)  = channels (j-1, j) of pixel row+1
-                             : 0x05040100u;  // (mine.lo16, partner.lo16)  = channels (j, j+1) of pixel row
-    constexpr int PX = 16;
-    char* base_lo = base + lo_off;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        const f32x2 v = belu2_fused(split_value(f32x2{accm[r], accm[r + 1]}, f32x2{accx[r], accx[r + 1]}), beta);  // (the bias is in accm: see split_value)
-        uint32_t mh, ml;
-        split_half2(v, mh, ml);
-        domain_track(dom, mh);
-        const uint32_t ph = swap_lane_pair(mh), pl = swap_lane_pair(ml);
-        const uint32_t oh = __builtin_amdgcn_perm(ph, mh, sel), ol = __builtin_amdgcn_perm(pl, ml, sel);
-        const int row = (r & 3) + 8 * (r >> 2);
-        if (!MASKED || row < limit) {
-            *(uint32_t*)(base + row * PX) = oh;
-            *(uint32_t*)(base_lo + row * PX) = ol;
-        }
-    }
-}
-// Where lane i (channel pair (i & ~1, i | 1)) of pixel-row group h writes: the address of pixel x = x0 + 4 h + (i & 1) of map row y.
-__device__ __forceinline__ char* split_store_base(float* dst, size_t n, long img_stride, long y, int pitch, int x, int i) {
-    return (char*)(dst + (n * img_stride + y * pitch) * 32) + ((size_t)(i >> 3) * pitch + x) * 16 + ((i & 7) >> 1) * 4;
-}
-__device__ __forceinline__ void store_belu_tile_split(char* base, const f32x16& accm, const f32x16& accx,
-                                                      float beta, bool odd, int pitch, uint32_t& dom) {
-    store_belu_tile_split_t<false>(base, accm, accx, beta, odd, 0, (long)pitch * 64, dom);
-}
-__device__ __forceinline__ void store_belu_tile_split_masked(char* base, const f32x16& accm, const f32x16& accx,
-                                                             float beta, bool odd, int limit, int pitch, uint32_t& dom) {
-    store_belu_tile_split_t<true>(base, accm, accx, beta, odd, limit, (long)pitch * 64, dom);
-}
-
-// Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`
-// (row = (r&3) + 8*(r>>2); the lane's +4*h is already in `base`): compile-time
-// offsets, so each store is one instruction with an immediate.
-// The same tile computed with the WEIGHT fragment as the MFMA's A operand (the transposed product: the two fragments have the same register
-// shape): lane (i, h) holds, of pixel i of the tile row, output channels 8 j + 4 h + (0..3) in registers 4 j + (0..3).  Two channels of a
+// BeLU(acc) of one 32x32 tile -> split-half pairs in the row-planar map (kPlanar).  The tile is computed with the WEIGHT fragment as the
+// MFMA's A operand (the transposed product: the two fragments have the same register shape): lane (i, h) holds, of pixel i of the tile row, output channels 8 j + 4 h + (0..3) in registers 4 j + (0..3).  Two channels of a
 // pixel pack into a dword with no lane exchange, four are the 8 bytes 8 h .. 8 h + 7 of the pixel's 16-byte cell in channel group j: one
 // 8-byte store of hi halves and one of lo halves per group, lanes i and i + 32 completing the cell, a wave writing 512 contiguous bytes.
 // `base`: the lane's pixel in the row of channel group 0, + 8 h; groups are `group_stride` bytes apart, the lo groups `lo_off` further on.
@@ -277,8 +227,8 @@ __device__ __forceinline__ void store_belu_tile_split_cr(char* base, const f32x1
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 4 * j;
-        const f32x2 v01 = belu2_fused2(split_value(f32x2{accm[r], accm[r + 1]}, f32x2{accx[r], accx[r + 1]}), f32x2{beta[j][0], beta[j][1]});  // (the bias is in accm)
-        const f32x2 v23 = belu2_fused2(split_value(f32x2{accm[r + 2], accm[r + 3]}, f32x2{accx[r + 2], accx[r + 3]}), f32x2{beta[j][2], beta[j][3]});
+        const f32p v01 = belu2_fused2(split_value(f32p{accm[r], accm[r + 1]}, f32p{accx[r], accx[r + 1]}), f32p{beta[j][0], beta[j][1]});  // (the bias is in accm)
+        const f32p v23 = belu2_fused2(split_value(f32p{accm[r + 2], accm[r + 3]}, f32p{accx[r + 2], accx[r + 3]}), f32p{beta[j][2], beta[j][3]});
         uint32_t h01, l01, h23, l23;
         split_half2(v01, h01, l01);
         split_half2(v23, h23, l23);
@@ -436,7 +386,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
     if (blockIdx.x == 0 && tid < 40) a.queue_reset[tid] = (a.queue_grid[tid >> 3] - (tid & 7) + 7) >> 3;
     if constexpr (IMG_U8) {
         uint32_t hi2, lo2;
-        split_half2(f32x2{__fdiv_rn((float)tid, 255.0f), 0.0f}, hi2, lo2);
+        split_half2(f32p{__fdiv_rn((float)tid, 255.0f), 0.0f}, hi2, lo2);
         s_lut[tid] = (hi2 & 0xffffu) | (lo2 << 16);
     }
     // B fragments: lane (output channel i, K half h) of block b holds slots 16 b + 8 h + (0..7), hi halves and lo halves (sr_api.cpp
@@ -482,8 +432,8 @@ __global__ __launch_bounds__(kThreads, 3) void conv0_split_kernel(Conv0Args a) {
                     h1 = wb & 0xffffu; l1 = wb >> 16;
                 } else {
                     const float* q = (const float*)a.img + gp * 3;
-                    split_half2(f32x2{q[0], q[1]}, h0, l0);
-                    split_half2(f32x2{q[2], 0.0f}, h1, l1);
+                    split_half2(f32p{q[0], q[1]}, h0, l0);
+                    split_half2(f32p{q[2], 0.0f}, h1, l1);
                     domain_track(dom, h0);
                     domain_track(dom, h1);
                 }
@@ -1149,7 +1099,7 @@ __device__ __forceinline__ void lin_mfma_h(f32x16 (&accm)[NTN * T], f32x16 (&acc
 // one staged pixel of that tile: (R, G, B) / (2 f)^2 as hi halves and lo halves.  u8: through the table lin_split_table_entry fills.
 __device__ __forceinline__ uint32_t lin_split_table_entry(int byte, float scale) {
     uint32_t hi2, lo2;
-    split_half2(f32x2{__fdiv_rn(__fdiv_rn((float)byte, 255.0f), scale), 0.0f}, hi2, lo2);
+    split_half2(f32p{__fdiv_rn(__fdiv_rn((float)byte, 255.0f), scale), 0.0f}, hi2, lo2);
     return (hi2 & 0xffffu) | (lo2 << 16);
 }
 __device__ __forceinline__ void lin_split_store_u8(char* s_hi, int lo_off, int p, uint32_t wr, uint32_t wg, uint32_t wb) {
@@ -1158,8 +1108,8 @@ __device__ __forceinline__ void lin_split_store_u8(char* s_hi, int lo_off, int p
 }
 __device__ __forceinline__ void lin_split_store_f32(char* s_hi, int lo_off, int p, float r, float g, float b, float scale) {
     uint32_t h0, l0, h1, l1;
-    split_half2(f32x2{__fdiv_rn(r, scale), __fdiv_rn(g, scale)}, h0, l0);
-    split_half2(f32x2{__fdiv_rn(b, scale), 0.0f}, h1, l1);
+    split_half2(f32p{__fdiv_rn(r, scale), __fdiv_rn(g, scale)}, h0, l0);
+    split_half2(f32p{__fdiv_rn(b, scale), 0.0f}, h1, l1);
     *(uint2*)(s_hi + p * 8) = make_uint2(h0, h1);
     *(uint2*)(s_hi + lo_off + p * 8) = make_uint2(l0, l1);
 }
@@ -1213,11 +1163,12 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], f32x16 (&accx)[
     lin_mfma<TH, T, NTN>(acc, s_x, s_w, wave, lane);
 }
 
-// What happens to a finished tile: bias + BeLU -> the node's feature map (exact f32 or split-half pairs), or,
-// for the final stage, + expand_bias, depth-to-space (Expand, network.rs:39) and optionally the u8 quantiser.
-template <int TH, int T, int NTN, bool FINAL, bool OUT_U8, int PREC, int FACTOR>
-__device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)[NTN * T], f32x16 (&accx)[PREC == 1 ? NTN * T : 1],
-                                               const float (&bias)[NTN], float beta, int n, int x0, int y0, int wave, int lane, uint32_t& dom) {
+// What happens to a finished tile of the EXACT mode (32x32 accumulators: lane = output channel, registers = pixels): bias + BeLU -> the
+// node's feature map, or, for the final stage, + expand_bias, depth-to-space (Expand, network.rs:39) and optionally the u8 quantiser.
+// (The split-half mode's tiles: stage_epilogue_h16, stage_epilogue_final_t; the exact mode's last stage on 8-row tiles: stage_epilogue_quad.)
+template <int TH, int T, int NTN, bool FINAL, bool OUT_U8, int FACTOR>
+__device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)[NTN * T], const float (&bias)[NTN], float beta, int n, int x0, int y0,
+                                               int wave, int lane) {
     const int i = lane & 31, h = lane >> 5;
     const bool full_x = x0 + kTW <= a.W;
     if constexpr (!FINAL) {
@@ -1225,28 +1176,16 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
         for (int m = 0; m < T; ++m) {
             const int y = y0 + wave * T + m;
             if (y >= a.y_end) continue;
-            if constexpr (PREC == 0) {
-                float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
-                if (full_x) {
-                    store_belu_tile(base, acc[m], bias[0], beta);
-                } else {
-                    for_each_acc_row([&](int r, int row) {
-                        if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias[0]), beta);
-                    });
-                }
+            float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
+            if (full_x) {
+                store_belu_tile(base, acc[m], bias[0], beta);
             } else {
-                char* base = split_store_base(a.dst, (size_t)n, a.img_stride, y, a.pitch, x0 + 4 * h + (i & 1), i);
-                if (full_x) store_belu_tile_split(base, acc[m], accx[m], beta, i & 1, a.pitch, dom);  // (bias: in the accumulators' initial value)
-                else store_belu_tile_split_masked(base, acc[m], accx[m], beta, i & 1, a.W - (x0 + 4 * h + (i & 1)), a.pitch, dom);
+                for_each_acc_row([&](int r, int row) {
+                    if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias[0]), beta);
+                });
             }
         }
     } else {
-        if constexpr (PREC == 1) {
-#pragma unroll
-            for (int m = 0; m < NTN * T; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][r] = acc[m][r] + accx[m][r] * (1.0f / kLoScale);
-        }
         // Expand (network.rs:39): out[f y+dy][f x+dx][c] = (bilinear + convs, all in acc) + expand_bias.
         // Lane i of N-tile nt (15 of every 16 lanes) owns colour c = (i % 16) % 3 of sub-pixel triple
         // tr = 10 nt + 5 (i / 16) + (i % 16) / 3 (dy = tr / f, dx = tr % f); the host packs the weights in that order
@@ -1375,11 +1314,11 @@ __device__ __forceinline__ void stage_epilogue_final_t(const StageArgs& a, f32x1
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const f32x2 s = (f32x2{am[r], am[r + 1]} + f32x2{ax[r], ax[r + 1]} * f32x2{1.0f / kLoScale, 1.0f / kLoScale}) +
-                                    f32x2{fbias[nt][r >> 2][r & 3], fbias[nt][(r + 1) >> 2][(r + 1) & 3]};
+                    const f32p s = (f32p{am[r], am[r + 1]} + f32p{ax[r], ax[r + 1]} * f32p{1.0f / kLoScale, 1.0f / kLoScale}) +
+                                   f32p{fbias[nt][r >> 2][r & 3], fbias[nt][(r + 1) >> 2][(r + 1) & 3]};
                     if constexpr (OUT_U8) {
                         // data_to_img (main.rs:175): clamp(floor(255 v + 0.5), 0, 255), alpha 255 -- v_cvt_pk_u8_f32 of the floor (see stage_epilogue)
-                        const f32x2 q = s * f32x2{255.0f, 255.0f} + f32x2{0.5f, 0.5f};
+                        const f32p q = s * f32p{255.0f, 255.0f} + f32p{0.5f, 0.5f};
                         v[r] = floorf(q.x); v[r + 1] = floorf(q.y);
                     } else {
                         v[r] = s.x; v[r + 1] = s.y;
@@ -1507,8 +1446,8 @@ __device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&a
             for (int ph = 0; ph < 2; ++ph) {
                 const int x = x0 + 16 * ph + p16;
                 const f32x4 vm = accm[m][ph][ch], vx = accx[m][ph][ch];  // (the bias is in accm: see split_value)
-                const f32x2 v01 = belu2_fused2(split_value(f32x2{vm[0], vm[1]}, f32x2{vx[0], vx[1]}), f32x2{beta[ch][0], beta[ch][1]});
-                const f32x2 v23 = belu2_fused2(split_value(f32x2{vm[2], vm[3]}, f32x2{vx[2], vx[3]}), f32x2{beta[ch][2], beta[ch][3]});
+                const f32p v01 = belu2_fused2(split_value(f32p{vm[0], vm[1]}, f32p{vx[0], vx[1]}), f32p{beta[ch][0], beta[ch][1]});
+                const f32p v23 = belu2_fused2(split_value(f32p{vm[2], vm[3]}, f32p{vx[2], vx[3]}), f32p{beta[ch][2], beta[ch][3]});
                 uint32_t h01, l01, h23, l23;
                 split_half2(v01, h01, l01);
                 split_half2(v23, h23, l23);
@@ -1654,7 +1593,8 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
             for (int k = 0; k < 4; ++k) fbias[nt][k] = *(const f32x4*)(a.bias + 32 * nt + 16 * (lane >> 5) + 4 * k);
         stage_epilogue_final_t<T, NTN, OUT_U8, FACTOR>(a, acc, accx, fbias, n, x0, y0, wave, lane);
     } else {
-        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
+        static_assert(PREC == 0, "the split-half mode's tiles have epilogues of their own");
+        stage_epilogue<TH, T, NTN, FINAL, OUT_U8, FACTOR>(a, acc, bias, beta, n, x0, y0, wave, lane);
     }
     if constexpr (PREC == 1 && !FINAL) domain_report(dom, a.domain);
 }
@@ -2219,7 +2159,7 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         if constexpr (H16) stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
         else if constexpr (QUAD) stage_epilogue_quad<NTN, OUT_U8, FACTOR>(a, qa, qbias, n, x0, y0, wave, lane);
         else if constexpr (kFinalT) stage_epilogue_final_t<T, NTN, OUT_U8, FACTOR>(a, acc, accx, fbias, n, x0, y0, wave, lane);
-        else stage_epilogue<TH, T, NTN, FINAL, OUT_U8, PREC, FACTOR>(a, acc, accx, bias, beta, n, x0, y0, wave, lane, dom);
+        else stage_epilogue<TH, T, NTN, FINAL, OUT_U8, FACTOR>(a, acc, bias, beta, n, x0, y0, wave, lane);
     };
 
     // The 48 expand channels of factor 4 are two N-tiles: in the split-half mode an 8-row tile body would hold 128 accumulator registers

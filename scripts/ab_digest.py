@@ -35,6 +35,7 @@ def main():
                 rng = np.random.default_rng(factor)
                 eng = r.Engine((rng.standard_normal(_lib.lib().sr_num_params_factor(factor)) * 0.05).astype(np.float32), device=0, precision=prec,
                                factor=factor)
+            eng.set_experiment("fork", "0")  # (a forked call keeps its bands' maps in two workspaces: sr_read_feature refuses)
             for n, h, w in shapes[: 4 if factor == 3 else 2]:
                 px = synth_u8(5, h, w, n=n) if n > 1 else synth_u8(5, h, w)[None]
                 dpx = torch.from_numpy(px).cuda()

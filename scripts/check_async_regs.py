@@ -47,7 +47,7 @@ def main():
         path = sys.argv[1]
     else:
         path = os.path.join(tempfile.gettempdir(), "sr_kernels_lint.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-x", "hip", "-S",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-x", "hip", "-S",
                                "--cuda-device-only", os.path.join(ROOT, "rusty_sr_amd", "csrc", "sr_kernels.hip"), "-o", path],
                               stderr=subprocess.DEVNULL)
     lines = open(path).read().split("\n")

@@ -14,7 +14,7 @@ def main():
         text = open(sys.argv[1]).read()
     else:
         src = os.path.join(ROOT, "rusty_sr_amd", "csrc", "sr_kernels.hip")
-        text = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-x", "hip", "-c",
+        text = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-x", "hip", "-c",
                                src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
     keys = [("VGPRs", "vgpr"), ("AGPRs", "agpr"), ("SGPRs", "sgpr"), (r"ScratchSize \[bytes/lane\]", "scratch"),
             (r"Occupancy \[waves/SIMD\]", "occ"), (r"LDS Size \[bytes/block\]", "lds")]
