@@ -65,6 +65,9 @@ __device__ __forceinline__ f32p operator+(f32p a, f32p b) { return f32p{a.x + b.
 __device__ __forceinline__ f32p operator-(f32p a, f32p b) { return f32p{a.x - b.x, a.y - b.y}; }
 __device__ __forceinline__ f32p operator*(f32p a, f32p b) { return f32p{a.x * b.x, a.y * b.y}; }
 __device__ __forceinline__ f32p p_fma(f32p a, f32p b, f32p c) { return f32p{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+// 8 bytes of a split-half map: four hi (or lo) halves of one pixel.  (Plain stores: non-temporal and write-through ones were measured again after
+// the stores became whole 16-byte cells per lane pair -- 1.478 -> 1.506 / 1.496 ms, profiles/r6_ab_split_transposed.txt.)
+__device__ __forceinline__ void store_map8(char* p, uint32_t a, uint32_t b) { *(uint2*)p = make_uint2(a, b); }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -235,8 +238,8 @@ __device__ __forceinline__ void store_belu_tile_split_cr(char* base, const f32x1
         domain_track(dom, h01);
         domain_track(dom, h23);
         if (write) {
-            *(uint2*)(base + j * group_stride) = make_uint2(h01, h23);
-            *(uint2*)(base + j * group_stride + lo_off) = make_uint2(l01, l23);
+            store_map8(base + j * group_stride, h01, h23);
+            store_map8(base + j * group_stride + lo_off, l01, l23);
         }
     }
 }
@@ -1454,8 +1457,8 @@ __device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&a
                 domain_track(dom, h01);
                 domain_track(dom, h23);
                 if (full_x || x < a.W) {
-                    *(uint2*)(row + (long)x * 16) = make_uint2(h01, h23);
-                    *(uint2*)(row + (long)x * 16 + lo_off) = make_uint2(l01, l23);
+                    store_map8(row + (long)x * 16, h01, h23);
+                    store_map8(row + (long)x * 16 + lo_off, l01, l23);
                 }
             }
         }

@@ -200,6 +200,28 @@ def test_last_stage_of_the_exact_mode_is_on_4x4x1_mfmas():
     assert not others, others   # (factor 2 / 4 instances of the same stage use it too: 3 and 8 + 5 groups)
 
 
+def test_split_half_epilogues_are_lane_local_and_scalar():
+    """DESIGN.md 4b (round 6): every split-half kernel computes the transposed tile (weights as the MFMA's A operand), so its epilogue packs
+    channel pairs of ONE pixel -- no DPP lane exchange, no v_perm_b32 in the stage kernels' epilogues -- and spells its pair arithmetic as
+    scalar instructions (packed f32 instructions beside the partner wave's MFMAs cost more than two scalar ones; the file is built with
+    -fno-slp-vectorize so that they stay scalar).  The exact mode keeps its packed epilogue.  Nothing spills."""
+    from rusty_sr_amd.build import DEVICE_ASM as asm, build_lib
+    build_lib()
+    text = open(asm).read()
+    kernels = dict(re.findall(r"^(_Z\w+):.*?\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M))
+    split = {k: v for k, v in kernels.items() if "conv0_split_kernel" in k or re.search(r"conv_stage(_pipe)?_kernelI.*Lb[01]ELb[01]ELb[01]ELi1ELi[234]E", k)}
+    exact = {k: v for k, v in kernels.items() if re.search(r"conv_stage(_pipe)?_kernelI.*Lb[01]ELb[01]ELb[01]ELi0ELi3E", k)}
+    assert len(split) >= 4 + 6 and len(exact) >= 8, (len(split), len(exact))
+    for name, body in split.items():
+        assert not re.search(r"v_pk_(fma|mul|add)_f32", body), name
+        assert "_dpp" not in body and "row_shl" not in body and "quad_perm" not in body, name
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0", body) and "scratch_" not in body, name
+    # the last stage at factor 3: the lane's sub-pixels of an output row leave as runs (RGBA8: 3 + 2 or 1 + 3 dwords per lane and tile row)
+    finals_u8 = [v for k, v in split.items() if re.search(r"conv_stage_pipe_kernelILi3ELi3ELb1ELb1ELb1ELi1ELi3E", k)]
+    assert len(finals_u8) == 1 and "global_store_dwordx3" in finals_u8[0] and "global_store_dwordx2" in finals_u8[0]
+    assert any(re.search(r"v_pk_(fma|mul|add)_f32", body) for body in exact.values())
+
+
 def test_parameter_free_kernels_keep_their_loads_global():
     """What made the round-5 kernels of sr_aux.hip fast is visible in their assembly, and easy to lose in an edit: the pixel
     windows must be read with global_load (an integer cast back to a pointer turns them into flat_load, and then every wait the
