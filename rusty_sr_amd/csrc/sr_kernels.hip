@@ -1169,11 +1169,14 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], f32x16 (&accx)[
 // What happens to a finished tile of the EXACT mode (32x32 accumulators: lane = output channel, registers = pixels): bias + BeLU -> the
 // node's feature map, or, for the final stage, + expand_bias, depth-to-space (Expand, network.rs:39) and optionally the u8 quantiser.
 // (The split-half mode's tiles: stage_epilogue_h16, stage_epilogue_final_t; the exact mode's last stage on 8-row tiles: stage_epilogue_quad.)
+// Every epilogue returns how many store instructions this wave has CERTAINLY issued (wave-uniform conditions only; fewer is safe, more is not):
+// tile_body counts them among the wave's memory operations, see step_advance.
 template <int TH, int T, int NTN, bool FINAL, bool OUT_U8, int FACTOR>
-__device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)[NTN * T], const float (&bias)[NTN], float beta, int n, int x0, int y0,
-                                               int wave, int lane) {
+__device__ __forceinline__ int stage_epilogue(const StageArgs& a, f32x16 (&acc)[NTN * T], const float (&bias)[NTN], float beta, int n, int x0, int y0,
+                                              int wave, int lane) {
     const int i = lane & 31, h = lane >> 5;
     const bool full_x = x0 + kTW <= a.W;
+    int stores = 0;
     if constexpr (!FINAL) {
 #pragma unroll
         for (int m = 0; m < T; ++m) {
@@ -1182,6 +1185,7 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
             float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
             if (full_x) {
                 store_belu_tile(base, acc[m], bias[0], beta);
+                stores += 16;
             } else {
                 for_each_acc_row([&](int r, int row) {
                     if (x0 + 4 * h + row < a.W) base[row * 32] = belu(__fadd_rn(acc[m][r], bias[0]), beta);
@@ -1268,6 +1272,7 @@ __device__ __forceinline__ void stage_epilogue(const StageArgs& a, f32x16 (&acc)
             }
         }
     }
+    return stores;
 }
 
 // n consecutive dwords (n a constant after unrolling) at a 4-byte-aligned address, as the widest stores there are
@@ -1296,12 +1301,18 @@ __device__ __forceinline__ void store_run_dwords(char* o, const uint32_t* w, int
 // Depth-to-space and the RGBA packing are lane-local (no DPP), a lane's sub-pixels of one output row are contiguous and stored together,
 // consecutive lanes continue the row.  Same arithmetic per value as stage_epilogue.
 template <int T, int NTN, bool OUT_U8, int FACTOR>
-__device__ __forceinline__ void stage_epilogue_final_t(const StageArgs& a, f32x16 (&accm)[NTN * T], f32x16 (&accx)[NTN * T], const f32x4 (&fbias)[NTN][4],
-                                                       int n, int x0, int y0, int wave, int lane) {
+__device__ __forceinline__ int stage_epilogue_final_t(const StageArgs& a, f32x16 (&accm)[NTN * T], f32x16 (&accx)[NTN * T], const f32x4 (&fbias)[NTN][4],
+                                                      int n, int x0, int y0, int wave, int lane) {
     const int i = lane & 31, h = lane >> 5;
     const int OW = a.W * FACTOR, h_band = a.y_end - a.y_begin;
     constexpr int OPX = OUT_U8 ? 4 : 12;  // bytes per output pixel
-    if (x0 + i >= a.W) return;
+    // (certain stores: a full-width tile's rows inside the band issue at least two run stores per N-tile over the two lane halves)
+    int stores = 0;
+    if (x0 + kTW <= a.W) {
+#pragma unroll
+        for (int m = 0; m < T; ++m) stores += (y0 + wave * T + m < a.y_end) ? 2 * NTN : 0;
+    }
+    if (x0 + i >= a.W) return stores;
     // output row of the wave's first tile row, sub-row 0, at the lane's pixel
     char* lbase = (char*)a.out + (((size_t)n * h_band + (size_t)(y0 + wave * T - a.y_begin)) * FACTOR * OW + (size_t)(x0 + i) * FACTOR) * OPX;
     auto body = [&](auto hc) {
@@ -1366,6 +1377,7 @@ __device__ __forceinline__ void stage_epilogue_final_t(const StageArgs& a, f32x1
     };
     if (h == 0) body(std::integral_constant<int, 0>{});
     else body(std::integral_constant<int, 1>{});
+    return stores;
 }
 
 // ... of a tile computed in the quad form: the lane holds every expand channel of ITS pixel (x0 + lane % 32, tile row 2 wave + lane / 32),
@@ -1373,9 +1385,11 @@ __device__ __forceinline__ void stage_epilogue_final_t(const StageArgs& a, f32x1
 // value as stage_epilogue (so the same bits); the f sub-pixels of an output row are contiguous in the lane (RGBA: f dwords, f32: 3 f
 // floats) and consecutive lanes continue the row, every store inside one lane-masked region.
 template <int NTN, bool OUT_U8, int FACTOR>
-__device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc (&acc)[NTN], const float (&bias)[3 * FACTOR * FACTOR], int n, int x0, int y0,
-                                                    int wave, int lane) {
+__device__ __forceinline__ int stage_epilogue_quad(const StageArgs& a, QuadAcc (&acc)[NTN], const float (&bias)[3 * FACTOR * FACTOR], int n, int x0, int y0,
+                                                   int wave, int lane) {
     const int x = x0 + (lane & 31), y = y0 + wave * 2 + (lane >> 5);
+    // (certain stores: with every lane's pixel inside the image, one store per output sub-row at least)
+    const int stores = (x0 + kTW <= a.W && y0 + wave * 2 + 1 < a.y_end) ? FACTOR : 0;
     const int OW = a.W * FACTOR, h_band = a.y_end - a.y_begin;
     struct __attribute__((packed, aligned(4))) RowU8 { uint32_t px[FACTOR]; };
     struct __attribute__((packed, aligned(4))) RowF32 { float v[3 * FACTOR]; };
@@ -1426,14 +1440,16 @@ __device__ __forceinline__ void stage_epilogue_quad(const StageArgs& a, QuadAcc 
             }
         }
     }
+    return stores;
 }
 
 // ... of a tile computed on 16x16 accumulators (kH16; row-planar split-half map; channels in registers, see half_steps_h16): lane l holds
 // output channels 16 ch + 4 (l >> 4) + (0..3) of pixel 16 ph + (l & 15) of tile row m.  BeLU, the hi / lo split, then one 8-byte store of the
 // four hi halves and one of the four lo halves: half a 16-byte cell of channel group 2 ch + (l >> 5) each (lanes l and l ^ 16 complete it).
 template <int T>
-__device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&accm)[T][2][2], f32x4 (&accx)[T][2][2],
-                                                   const f32x4 (&beta)[2], int n, int x0, int y0, int wave, int lane, uint32_t& dom) {
+__device__ __forceinline__ int stage_epilogue_h16(const StageArgs& a, f32x4 (&accm)[T][2][2], f32x4 (&accx)[T][2][2],
+                                                  const f32x4 (&beta)[2], int n, int x0, int y0, int wave, int lane, uint32_t& dom) {
+    int stores = 0;
     const int p16 = lane & 15, g = lane >> 4;
     const bool full_x = x0 + kTW <= a.W;
     const long lo_off = (long)a.pitch * 64;  // the lo group's row: four channel groups further on
@@ -1441,6 +1457,7 @@ __device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&a
     for (int m = 0; m < T; ++m) {
         const int y = y0 + wave * T + m;
         if (y >= a.y_end) continue;
+        if (full_x) stores += 8;  // (2 channel halves x 2 pixel halves x hi / lo)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             // channel group 2 ch + (g >> 1), bytes 8 (g & 1) .. + 7 of the pixel's 16-byte cell
@@ -1463,6 +1480,7 @@ __device__ __forceinline__ void stage_epilogue_h16(const StageArgs& a, f32x4 (&a
             }
         }
     }
+    return stores;
 }
 
 // Dynamic tile queue of the persistent forms.  A launch has `nbig` 8-row tiles and `nsmall` 4-row tiles (either may be
@@ -1633,15 +1651,22 @@ __global__ __launch_bounds__(256, 2) void conv_stage_kernel(StageArgs a) {
 // branches whatever the number.  Fewer than `pending` in flight is always safe, so the index is min(pending, 15), and a negative
 // number (never produced) waits for everything.
 #define SR_WAIT_ROW(k, extra) "s_waitcnt vmcnt(" #k ")" extra "\n\ts_branch .Lsrwait%=\n\t"
+#define SR_WAIT_ROWS10(b, extra)                                                                                              \
+    SR_WAIT_ROW(b##0, extra) SR_WAIT_ROW(b##1, extra) SR_WAIT_ROW(b##2, extra) SR_WAIT_ROW(b##3, extra) SR_WAIT_ROW(b##4, extra) \
+    SR_WAIT_ROW(b##5, extra) SR_WAIT_ROW(b##6, extra) SR_WAIT_ROW(b##7, extra) SR_WAIT_ROW(b##8, extra) SR_WAIT_ROW(b##9, extra)
+#define SR_WAIT_JUMP(maxn)                                                                                                   \
+    "s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, " #maxn "\n\ts_lshl_b32 %0, %0, 3\n\ts_add_u32 %0, %0, 12\n\t"                 \
+    "s_getpc_b64 vcc\n\ts_add_u32 vcc_lo, vcc_lo, %0\n\ts_addc_u32 vcc_hi, vcc_hi, 0\n\ts_setpc_b64 vcc\n\t"
 #define SR_WAIT_TABLE(extra)                                                                                                \
-    "s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, 15\n\ts_lshl_b32 %0, %0, 3\n\ts_add_u32 %0, %0, 12\n\t"                        \
-    "s_getpc_b64 vcc\n\ts_add_u32 vcc_lo, vcc_lo, %0\n\ts_addc_u32 vcc_hi, vcc_hi, 0\n\ts_setpc_b64 vcc\n\t"                \
-    SR_WAIT_ROW(0, extra) SR_WAIT_ROW(1, extra) SR_WAIT_ROW(2, extra) SR_WAIT_ROW(3, extra) SR_WAIT_ROW(4, extra)              \
-    SR_WAIT_ROW(5, extra) SR_WAIT_ROW(6, extra) SR_WAIT_ROW(7, extra) SR_WAIT_ROW(8, extra) SR_WAIT_ROW(9, extra)              \
-    SR_WAIT_ROW(10, extra) SR_WAIT_ROW(11, extra) SR_WAIT_ROW(12, extra) SR_WAIT_ROW(13, extra) SR_WAIT_ROW(14, extra)         \
-    SR_WAIT_ROW(15, extra) ".Lsrwait%=:"
-template <bool LGKM>
-__device__ __forceinline__ void wait_vm_n(int pending) {  // s_waitcnt vmcnt(min(pending, 15)) [lgkmcnt(0)]
+    SR_WAIT_JUMP(15) SR_WAIT_ROWS10(, extra) SR_WAIT_ROW(10, extra) SR_WAIT_ROW(11, extra) SR_WAIT_ROW(12, extra)               \
+    SR_WAIT_ROW(13, extra) SR_WAIT_ROW(14, extra) SR_WAIT_ROW(15, extra) ".Lsrwait%=:"
+// ... and the same with all 64 values of the counter (512 bytes): only for the waits that follow an epilogue, see step_advance
+#define SR_WAIT_TABLE64(extra)                                                                                              \
+    SR_WAIT_JUMP(63) SR_WAIT_ROWS10(, extra) SR_WAIT_ROWS10(1, extra) SR_WAIT_ROWS10(2, extra) SR_WAIT_ROWS10(3, extra)         \
+    SR_WAIT_ROWS10(4, extra) SR_WAIT_ROWS10(5, extra) SR_WAIT_ROW(60, extra) SR_WAIT_ROW(61, extra) SR_WAIT_ROW(62, extra)      \
+    SR_WAIT_ROW(63, extra) ".Lsrwait%=:"
+template <bool LGKM, bool WIDE = false>
+__device__ __forceinline__ void wait_vm_n(int pending) {  // s_waitcnt vmcnt(min(pending, 15 or 63)) [lgkmcnt(0)]
     if (__builtin_constant_p(pending)) {  // (resolved after inlining and unrolling: many steps know their number at compile time)
         switch (pending < 0 ? 0 : pending) {
 #define SR_CASE(k) case k: if constexpr (LGKM) asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
@@ -1654,12 +1679,17 @@ __device__ __forceinline__ void wait_vm_n(int pending) {  // s_waitcnt vmcnt(min
     }
     const int p = __builtin_amdgcn_readfirstlane(pending);
     int t;
-    if constexpr (LGKM) asm volatile(SR_WAIT_TABLE(" lgkmcnt(0)") : "=&s"(t) : "s"(p) : "vcc", "scc", "memory");
-    else asm volatile(SR_WAIT_TABLE("") : "=&s"(t) : "s"(p) : "vcc", "scc", "memory");
+    if constexpr (WIDE) {
+        if constexpr (LGKM) asm volatile(SR_WAIT_TABLE64(" lgkmcnt(0)") : "=&s"(t) : "s"(p) : "vcc", "scc", "memory");
+        else asm volatile(SR_WAIT_TABLE64("") : "=&s"(t) : "s"(p) : "vcc", "scc", "memory");
+    } else {
+        if constexpr (LGKM) asm volatile(SR_WAIT_TABLE(" lgkmcnt(0)") : "=&s"(t) : "s"(p) : "vcc", "scc", "memory");
+        else asm volatile(SR_WAIT_TABLE("") : "=&s"(t) : "s"(p) : "vcc", "scc", "memory");
+    }
 }
-template <bool LGKM>
+template <bool LGKM, bool WIDE = false>
 __device__ __forceinline__ void wait_vm_barrier(int pending) {
-    wait_vm_n<LGKM>(pending);
+    wait_vm_n<LGKM, WIDE>(pending);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -1714,7 +1744,7 @@ struct HalfTile {
 
 // Bookkeeping of the pipe form's DMA traffic.  Every LDS-DMA instruction a wave issues gets a sequence number;
 // loads complete in issue order, so "everything up to number q has landed" is s_waitcnt vmcnt(issued - q).
-// (Stores and plain loads issued in between only make that wait stricter, never weaker.)
+// (Stores and plain loads issued in between and not counted only make that wait stricter, never weaker.)
 // Weight chunks: step gs of a tile uses chunk gs; it is requested kRingAhead steps earlier, wrapping into the
 // next tile.  Half tiles: requested piecemeal over the first steps of the previous half (a burst of gathers
 // stalls the issuing wave for ~250 cycles per instruction), needed at its end.
@@ -1722,7 +1752,7 @@ struct StepStream {
     int slot;            // ring slot of the current step's chunk
     int nsteps;          // steps per tile
     bool have_next;      // another tile follows (its chunks are requested by the last steps of this one)
-    int issued;          // DMA instructions issued so far by this wave
+    int issued;          // DMA instructions issued so far by this wave (+ the epilogues' stores, as far as they are certain: tile_body)
     int q[kRingAhead];   // sequence numbers of the requests of chunks gs + 1 .. gs + kRingAhead
     int tile_seq;        // sequence number of the newest half-tile DMA
 };
@@ -1747,12 +1777,19 @@ __device__ __forceinline__ void step_request(StepStream& st, int gs, uint32_t ri
     st.q[kRingAhead - 1] = st.issued;  // nothing requested: nothing newer to wait for either
 }
 // End of a step.  On return chunk gs + 1 + EXTRA has landed; with `tile` also every half-tile DMA issued so far.
+// `wide` (a constant after unrolling): one of a tile's first steps.  The chunk such a step waits for was requested BEFORE the previous tile's
+// epilogue, whose stores sit behind it in the wave's one in-order memory counter (gfx9 has no separate store counter): they are counted
+// (StepStream::issued, see tile_body) so that the wait lets them stay in flight -- which takes a number beyond 15, the 64-row table.
+// Uncounted, the first barriers of every split-half tile sat out the write acknowledgement of the whole epilogue (its steps are a few
+// hundred cycles): 0.8 % of a frame, profiles/r6_ab_store_shadow.txt.
 template <int EXTRA>
-__device__ __forceinline__ void step_advance(StepStream& st, bool tile) {
+__device__ __forceinline__ void step_advance(StepStream& st, bool tile, bool wide = false) {
     // after this step's step_request, q[k] is the request of chunk gs + 1 + k
     int need = st.q[EXTRA];
     if (tile && st.tile_seq > need) need = st.tile_seq;
-    wait_vm_barrier<EXTRA == 0>(st.issued - need);  // (EXTRA = 1: the split-half loop, which reads a step ahead)
+    // (EXTRA = 1: the split-half loop, which reads a step ahead)
+    if (wide) wait_vm_barrier<EXTRA == 0, true>(st.issued - need);
+    else wait_vm_barrier<EXTRA == 0>(st.issued - need);
     st.slot = st.slot == kRingSlots - 1 ? 0 : st.slot + 1;
 }
 
@@ -1929,7 +1966,7 @@ struct PipeStream {
     template <int EXTRA> __device__ __forceinline__ void end_step(bool last) {
         if (last) last_step_hook();
         if (last && mailbox) queue_publish(a, xcd, wave, lane, st, qs, mailbox);
-        step_advance<EXTRA>(st, last);
+        step_advance<EXTRA>(st, last, PREC == 1 && gs0 + step_no <= kRingAhead);  // (step_no counts this step already: the tile's steps 0 .. kRingAhead - 1)
     }
 };
 
@@ -2159,10 +2196,16 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
                 asm volatile("" ::: "memory");
             }
         }
-        if constexpr (H16) stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
-        else if constexpr (QUAD) stage_epilogue_quad<NTN, OUT_U8, FACTOR>(a, qa, qbias, n, x0, y0, wave, lane);
-        else if constexpr (kFinalT) stage_epilogue_final_t<T, NTN, OUT_U8, FACTOR>(a, acc, accx, fbias, n, x0, y0, wave, lane);
-        else stage_epilogue<TH, T, NTN, FINAL, OUT_U8, FACTOR>(a, acc, bias, beta, n, x0, y0, wave, lane);
+        // The epilogue's stores are memory operations of this wave like its DMAs, returning in issue order with them: counted (as far as they
+        // are certain), the next tile's first waits -- for chunks requested before them -- let them stay in flight (step_advance).
+        int stores;
+        if constexpr (H16) stores = stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
+        else if constexpr (QUAD) stores = stage_epilogue_quad<NTN, OUT_U8, FACTOR>(a, qa, qbias, n, x0, y0, wave, lane);
+        else if constexpr (kFinalT) stores = stage_epilogue_final_t<T, NTN, OUT_U8, FACTOR>(a, acc, accx, fbias, n, x0, y0, wave, lane);
+        else stores = stage_epilogue<TH, T, NTN, FINAL, OUT_U8, FACTOR>(a, acc, bias, beta, n, x0, y0, wave, lane);
+        // (Split-half mode only: its steps are shorter than a write acknowledgement takes, so the uncounted stores stalled each tile's first
+        // barriers -- 0.8 % of a frame.  An exact-mode step is ten times longer and never saw it: measured, no change, its code is left as it was.)
+        if constexpr (PREC == 1) st.issued += stores;
     };
 
     // The 48 expand channels of factor 4 are two N-tiles: in the split-half mode an 8-row tile body would hold 128 accumulator registers

@@ -123,7 +123,7 @@ def main():
                         break  # the register is given a new value: the old result is dead on this path
     print(f"{checked} asynchronous asm results checked, {bad} read too early")
     tables, bad_layout = check_encoded_layouts(lines)
-    print(f"{tables[0]} wait tables and {tables[1]} LDS-DMA m0 writes checked, {bad_layout} with an unexpected layout")
+    print(f"{tables[0]} wait tables and {tables[1]} LDS-DMA m0 writes checked, {bad_layout} with an unexpected layout ({tables[2]} tables of 64 rows)")
     return 1 if bad or bad_layout or not tables[0] else 0
 
 
@@ -131,7 +131,7 @@ def check_encoded_layouts(lines):
     """See the module docstring: the computed jump into the s_waitcnt table, and the wait state behind a write of m0."""
     code = [(i, l.split(";")[0].strip()) for i, l in enumerate(lines)]
     code = [(i, t) for i, t in code if t and not t.endswith(":") and not t.startswith((".", "#"))]
-    n_tab = n_m0 = bad = 0
+    n_tab = n_m0 = bad = n_wide = 0
     for k, (i, t) in enumerate(code):
         if t.startswith("s_getpc_b64"):
             # (a kernel of more than 128 KB makes the COMPILER relax far branches into s_getpc_b64 sN / s_add_u32 ... (.LBB - .Lpost_getpc) /
@@ -139,13 +139,20 @@ def check_encoded_layouts(lines):
             if re.search(r"\.Lpost_getpc\d+\)", " ".join(x[1] for x in code[k + 1:k + 3])):
                 continue
             n_tab += 1
+            # the index arithmetic in front of it: clamp to the table's last row (15, or 63 in the 64-row table), << 3 (8-byte rows), + 12 (the
+            # three instructions behind s_getpc)
+            prev = [x[1] for x in code[max(0, k - 4):k]]
+            clamp = [int(m.group(1)) for x in prev for m in [re.match(r"s_min_i32 s\d+, s\d+, (\d+)$", x)] if m]
+            rows = clamp[0] + 1 if clamp and clamp[0] in (15, 63) else 0
             want = [r"s_add_u32 vcc_lo, vcc_lo, s\d+$", r"s_addc_u32 vcc_hi, vcc_hi, 0$", r"s_setpc_b64 vcc$"]
-            for row in range(16):
+            for row in range(rows):
                 want += [r"s_waitcnt vmcnt\(%d\)( lgkmcnt\(0\))?$" % row, r"s_branch \S+$"]
             got = [x[1] for x in code[k + 1:k + 1 + len(want)]]
-            ok = t == "s_getpc_b64 vcc" and len(got) == len(want) and all(re.match(w, g) for w, g in zip(want, got))
-            # the index arithmetic in front of it: ... << 3 (8-byte rows), + 12 (the three instructions behind s_getpc)
-            prev = [x[1] for x in code[max(0, k - 4):k]]
+            ok = rows and t == "s_getpc_b64 vcc" and len(got) == len(want) and all(re.match(w, g) for w, g in zip(want, got))
+            # ... and the row behind the last one is not another row of a longer table
+            nxt = code[k + 1 + len(want)][1] if k + 1 + len(want) < len(code) else ""
+            ok = ok and not re.match(r"s_waitcnt vmcnt\(%d\)" % rows, nxt)
+            n_wide += rows == 64
             ok = ok and any(re.match(r"s_lshl_b32 s\d+, s\d+, 3$", x) for x in prev) and any(re.match(r"s_add_u32 s\d+, s\d+, 12$", x) for x in prev)
             if not ok:
                 print(f"line {i + 1}: the s_waitcnt table behind `{t}` does not have the layout its computed jump assumes")
@@ -157,7 +164,7 @@ def check_encoded_layouts(lines):
             elif any(x.startswith("global_load_lds") for x in nxt):
                 print(f"line {i + 1}: `{t}` is not followed by an s_nop before its global_load_lds")
                 bad += 1
-    return (n_tab, n_m0), bad
+    return (n_tab, n_m0, n_wide), bad
 
 
 if __name__ == "__main__":
