@@ -58,7 +58,7 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // A pair of values worked on with TWO scalar instructions per operation.  The split-half mode's epilogues run beside the partner wave's f16
 // MFMAs, where a packed f32 instruction (v_pk_fma_f32 ...) costs more than the two scalar ones it replaces (MI355X_MICROARCH.md "price of
-// one filler beside MFMAs"; profiles/r6_ab_epilogue_scalar.txt: -1.2 % at 1080p).  The file is built with -fno-slp-vectorize so that the
+// one filler beside MFMAs"; profiles/r6_ab_split_transposed.txt: -1.2 % at 1080p).  The file is built with -fno-slp-vectorize so that the
 // compiler does not pack them again.  (The exact mode keeps f32x2: there every vector instruction is paid in f32-MFMA time, so fewer is better.)
 struct f32p { float x, y; };
 __device__ __forceinline__ f32p operator+(f32p a, f32p b) { return f32p{a.x + b.x, a.y + b.y}; }
@@ -244,6 +244,9 @@ __device__ __forceinline__ void store_belu_tile_split_cr(char* base, const f32x1
     }
 }
 
+// Store the 16 accumulator rows of one 32x32 MFMA tile at `base + row*stride`
+// (row = (r&3) + 8*(r>>2); the lane's +4*h is already in `base`): compile-time
+// offsets, so each store is one instruction with an immediate.
 template <typename F>
 __device__ __forceinline__ void for_each_acc_row(F&& f) {
 #pragma unroll
@@ -1293,6 +1296,7 @@ __device__ __forceinline__ void store_run_dwords(char* o, const uint32_t* w, int
     else if (n == 6) store_run_n<6>(o, w);
     else if (n == 9) store_run_n<9>(o, w);
     else if (n == 12) store_run_n<12>(o, w);
+    else __builtin_trap();  // (no other run length exists for factors 2-4; n is a constant at every call, so this leg compiles away)
 }
 // ... of the split-half mode's last stage (transposed accumulators, see half_steps_h): lane (i, h) holds, of pixel x0 + i of tile row m, the
 // sixteen output slots 8 (r >> 2) + 4 h + (r & 3), r = 0..15, of every N-tile -- and the host packs the expand channels so that those are
