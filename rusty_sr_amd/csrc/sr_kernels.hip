@@ -148,6 +148,27 @@ __device__ __forceinline__ void store_belu_tile(float* base, const f32x16& acc, 
     }
 }
 
+// The same tile row through LDS (pipe form, round 6): the 32 store instructions of a tile and wave are what the epilogue costs (1.6 % of a stage
+// in issue alone, profiles/r6_ab_store_shadow.txt), and a lane cannot hold four consecutive channels of a pixel without paying for it elsewhere.
+// So the wave writes the row's 32 pixels x 128 bytes into a 4 KB scratch of its own in LDS as it produces them (lane = channel: sixteen
+// conflict-free ds_write_b32), reads them back linearly (four ds_read_b128) and leaves with FOUR global_store_dwordx4, each 1 KB contiguous --
+// a tile row of a pixel-major map is contiguous in memory.  `stage`: this wave's scratch; `grow`: the row's first pixel in the map.
+__device__ __forceinline__ void store_belu_tile_lds(float* grow, float* stage, const f32x16& acc, float bias, float beta, int lane) {
+    float* sp = stage + (4 * (lane >> 5)) * 32 + (lane & 31);  // pixel 4 h + row, channel i
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 bb = {bias, bias};
+        const f32x2 o = belu2(f32x2{acc[r], acc[r + 1]} + bb, beta);
+        const int row = (r & 3) + 8 * (r >> 2);
+        sp[row * 32] = o.x;
+        sp[(row + 1) * 32] = o.y;
+    }
+    const f32x4* lp = (const f32x4*)stage + lane;
+    const f32x4 v0 = lp[0], v1 = lp[64], v2 = lp[128], v3 = lp[192];
+    f32x4* gp = (f32x4*)grow + lane;
+    gp[0] = v0; gp[64] = v1; gp[128] = v2; gp[192] = v3;
+}
+
 // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each
 // XCD one contiguous run of tiles so neighbouring tiles (which share halo rows
 // and columns) hit the same 4 MiB L2.  Bijective for any grid size.
@@ -1176,7 +1197,7 @@ __device__ __forceinline__ void lin_taps(f32x16 (&acc)[NTN * T], f32x16 (&accx)[
 // tile_body counts them among the wave's memory operations, see step_advance.
 template <int TH, int T, int NTN, bool FINAL, bool OUT_U8, int FACTOR>
 __device__ __forceinline__ int stage_epilogue(const StageArgs& a, f32x16 (&acc)[NTN * T], const float (&bias)[NTN], float beta, int n, int x0, int y0,
-                                              int wave, int lane) {
+                                              int wave, int lane, float* stage_lds = nullptr) {
     const int i = lane & 31, h = lane >> 5;
     const bool full_x = x0 + kTW <= a.W;
     int stores = 0;
@@ -1186,7 +1207,10 @@ __device__ __forceinline__ int stage_epilogue(const StageArgs& a, f32x16 (&acc)[
             const int y = y0 + wave * T + m;
             if (y >= a.y_end) continue;
             float* base = a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0 + 4 * h) * 32 + i;
-            if (full_x) {
+            if (full_x && stage_lds) {  // (pipe form: the row leaves through the wave's LDS scratch as four 1 KB stores, store_belu_tile_lds)
+                store_belu_tile_lds(a.dst + ((size_t)n * a.img_stride + (long)y * a.pitch + x0) * 32, stage_lds, acc[m], bias[0], beta, lane);
+                stores += 4;
+            } else if (full_x) {
                 store_belu_tile(base, acc[m], bias[0], beta);
                 stores += 16;
             } else {
@@ -2206,7 +2230,12 @@ __global__ __launch_bounds__(256, 2) void conv_stage_pipe_kernel(StageArgs a) {
         if constexpr (H16) stores = stage_epilogue_h16<T>(a, qm, qx, beta2, n, x0, y0, wave, lane, dom);
         else if constexpr (QUAD) stores = stage_epilogue_quad<NTN, OUT_U8, FACTOR>(a, qa, qbias, n, x0, y0, wave, lane);
         else if constexpr (kFinalT) stores = stage_epilogue_final_t<T, NTN, OUT_U8, FACTOR>(a, acc, accx, fbias, n, x0, y0, wave, lane);
-        else stores = stage_epilogue<TH, T, NTN, FINAL, OUT_U8, FACTOR>(a, acc, bias, beta, n, x0, y0, wave, lane);
+        else {
+            // (stages 1-3: the buffer the tile's LAST half has just left -- every wave is past that half's last barrier, the next tile's second
+            // half is requested into it by the steps to come -- lends each wave its own plane as the epilogue's scratch)
+            float* scratch = FINAL ? nullptr : (float*)(smem + ((NH - 1) & 1) * HB + wave * H0::G::PLANE);
+            stores = stage_epilogue<TH, T, NTN, FINAL, OUT_U8, FACTOR>(a, acc, bias, beta, n, x0, y0, wave, lane, scratch);
+        }
         // (Split-half mode only: its steps are shorter than a write acknowledgement takes, so the uncounted stores stalled each tile's first
         // barriers -- 0.8 % of a frame.  An exact-mode step is ten times longer and never saw it: measured, no change, its code is left as it was.)
         if constexpr (PREC == 1) st.issued += stores;
