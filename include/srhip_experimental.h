@@ -26,9 +26,19 @@ extern "C" {
  * shrink them geometrically; "halo": what a sharded call (sr_upscale_sharded_*) exchanges -- "" / "input": 7 input rows per
  * neighbour, the overlap recomputed; "layers": additionally the edge rows of every layer's output after its stage
  * (f 2 rows, l1 / l2 / l3 one each), nothing recomputed (8(e)(ii)); every context of a call must say the same.
+ * "fork": a lone image through a device entry point as two row bands on two streams -- "" automatic, "0" never, "1" always, N > 1 always
+ * with N rows in the first band; "forkshare" / "forkmin": the first band's share of the rows, the automatic rule's threshold in rounds of
+ * tiles; "forktune": "" / "1" -- for mid-size shapes (0.55-12 rounds of tiles) the automatic choice is MEASURED on the caller's own calls
+ * (four undivided, four forked, timed by event pairs that are queried, never waited for; then the faster plan stays for that shape),
+ * "0" -- the rule alone; setting it forgets what was measured.
  * Defaults come from SRHIP_TH / SRHIP_TAIL / SRHIP_PIPE / SRHIP_BW / SRHIP_BANDS / SRHIP_ROWS / SRHIP_GEO / SRHIP_HALO, read once in sr_create.
  * Unknown key: SR_E_INVALID. */
 int sr_set_experiment(sr_ctx* ctx, const char* key, const char* value);
+
+/* What a switch has learned, as text (NUL-terminated, into buf[cap]).  key "forktune": one line per shape the fork tuner has met,
+ * "HxW+halo_top+halo_bot precision io state undivided_ms forked_ms" with state measuring | undivided | forked (0.0000: not measured yet).
+ * Unknown key, or a buffer too small: SR_E_INVALID. */
+int sr_get_experiment(sr_ctx* ctx, const char* key, char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

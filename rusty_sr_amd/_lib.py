@@ -69,6 +69,7 @@ SYMBOLS = {
 # include/srhip_experimental.h: A/B tuning switches (no result bit depends on them), outside the drop-in ABI
 EXPERIMENTAL = {
     "sr_set_experiment": (_i, [_vp, C.c_char_p, C.c_char_p]),
+    "sr_get_experiment": (_i, [_vp, C.c_char_p, C.c_char_p, _sz]),
 }
 
 _lib = None

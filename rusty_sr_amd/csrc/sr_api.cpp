@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstring>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -309,9 +310,9 @@ int sr_create_graph(sr_ctx** out, int graph, const float* params, size_t n_param
     c->graph = graph;
     c->factor = factor;
     // experiment switches: the environment gives the defaults, read here once; sr_set_experiment changes them
-    static const char* const kSwitch[11][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
+    static const char* const kSwitch[12][2] = {{"th", "SRHIP_TH"}, {"pipe", "SRHIP_PIPE"}, {"bw", "SRHIP_BW"}, {"tail", "SRHIP_TAIL"},
                                                {"bands", "SRHIP_BANDS"}, {"geo", "SRHIP_GEO"}, {"rows", "SRHIP_ROWS"}, {"fork", "SRHIP_FORK"},
-                                               {"forkshare", "SRHIP_FORKSHARE"}, {"forkmin", "SRHIP_FORKMIN"}, {"halo", "SRHIP_HALO"}};
+                                               {"forkshare", "SRHIP_FORKSHARE"}, {"forkmin", "SRHIP_FORKMIN"}, {"forktune", "SRHIP_FORKTUNE"}, {"halo", "SRHIP_HALO"}};
     for (const auto& sw : kSwitch)
         if (const char* e = getenv(sw[1])) (void)sr_set_experiment(c, sw[0], e);
     {   // FNV-1a over the parameter bits: contexts that share a sharded call must hold the same parameters
@@ -444,6 +445,7 @@ void sr_destroy(sr_ctx* c) {
     for (auto& p : c->d_out) if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_fork) if (e) (void)hipEventDestroy(e);
+    sr_fork_tune_clear(c);
     for (auto& e : c->pool) if (e) (void)hipEventDestroy(e);
     if (c->copy_in) { (void)hipStreamSynchronize(c->copy_in); (void)hipStreamDestroy(c->copy_in); }
     if (c->copy_out) { (void)hipStreamSynchronize(c->copy_out); (void)hipStreamDestroy(c->copy_out); }
@@ -501,6 +503,11 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
         c->fork_share = *v ? std::min(0.9, std::max(0.1, atof(v))) : 0.5;
     } else if (!strcmp(key, "forkmin")) {  // ... automatic rule: fork from this many rounds of tiles on
         c->fork_min_rounds = *v ? atof(v) : 3.5;
+    } else if (!strcmp(key, "forktune")) {  // ... automatic rule, mid-size shapes: "" / "1": measure both plans on the caller's calls and keep the faster (ForkTune); "0": the rule alone; either forgets what was measured
+        c->fork_autotune = strcmp(v, "0") != 0;
+        sr_device_guard restore_device;
+        (void)hipSetDevice(c->device);
+        sr_fork_tune_clear(c);
     } else if (!strcmp(key, "halo")) {  // sharded calls: "" / "input": 7 input rows per neighbour, the overlap recomputed; "layers": feature rows after every stage
         c->layer_halos = !strcmp(v, "layers");
     } else if (!strcmp(key, "bw")) {   // tile-order column-block width in tiles; "" / negative: automatic, 0: plain row-major
@@ -508,6 +515,25 @@ int sr_set_experiment(sr_ctx* c, const char* key, const char* value) {
     } else {
         return SR_E_INVALID;
     }
+    return SR_OK;
+}
+
+int sr_get_experiment(sr_ctx* c, const char* key, char* buf, size_t cap) {
+    if (!c || !key || !buf || cap == 0) return SR_E_INVALID;
+    std::string out;
+    if (!strcmp(key, "forktune")) {  // one line per shape the tuner has met: "HxW prec io state undivided_ms forked_ms"
+        char line[160];
+        for (const auto& t : c->fork_tune) {
+            snprintf(line, sizeof line, "%dx%d+%d+%d %s %s %s %.4f %.4f\n", t.H, t.W, t.top, t.bot, t.precision == SR_PRECISION_F32 ? "f32" : "split_f16",
+                     t.img_u8 ? "u8" : "f32", t.decided < 0 ? "measuring" : (t.decided ? "forked" : "undivided"),
+                     t.best[0] < 1e29f ? t.best[0] : 0.f, t.best[1] < 1e29f ? t.best[1] : 0.f);
+            out += line;
+        }
+    } else {
+        return SR_E_INVALID;
+    }
+    if (out.size() + 1 > cap) return SR_E_INVALID;
+    memcpy(buf, out.c_str(), out.size() + 1);
     return SR_OK;
 }
 
@@ -890,12 +916,13 @@ void sr_band_pass_end(sr_band_pass* p) { delete p; }
 namespace {
 
 // Whether a device call of this shape runs as two bands (the automatic rule or sr_set_experiment("fork")), and the first band's rows.
-bool plan_fork(const sr_ctx* c, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot, int* rows_a_out) {
+// `mode`: c->env_fork (-1: the automatic rule, 0: never, 1: always, > 1: always, that many rows first) -- or the tuner's 0 / 1.
+bool plan_fork(const sr_ctx* c, int mode, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot, int* rows_a_out) {
     const int own = H - halo_top - halo_bot;
-    bool fork = c->graph == SR_GRAPH_SR_NET && n == 1 && !c->profiling && c->env_fork != 0 && W > 0 && own >= 4 * SR_HALO &&
+    bool fork = c->graph == SR_GRAPH_SR_NET && n == 1 && !c->profiling && mode != 0 && W > 0 && own >= 4 * SR_HALO &&
                 (!img_u8 || img_ch == 3 || img_ch == 4) &&   // (anything sr_run_stack would refuse is left for it to refuse)
                 halo_top >= 0 && halo_bot >= 0 && (halo_top == 0 || halo_top >= SR_HALO) && (halo_bot == 0 || halo_bot >= SR_HALO);
-    if (fork && c->env_fork < 0) {
+    if (fork && mode < 0) {
         // automatic: where the launches have enough rounds of tiles for two bands to fill the chip each (measured)
         const int cus = c->cus > 0 ? c->cus : 256;
         const double rounds = (double)((W + 31) / 32) * ((own + 7) / 8) / (2.0 * cus);
@@ -909,9 +936,9 @@ bool plan_fork(const sr_ctx* c, bool img_u8, int img_ch, int n, int H, int W, in
     // The first band's own rows: near the requested share, at the cut (within +-8 rows of it) that wastes the least matrix work in
     // partly filled tile rows.  Stage s of the first band computes rows_a + margin rows from the band's top, of the second band
     // own - rows_a + margin rows; a remainder of 1-4 rows costs a row of 4-row tiles (0.52 of an 8-row one), 5-7 rows a full one.
-    int rows_a = c->env_fork > 1 ? c->env_fork : (int)(own * c->fork_share);
+    int rows_a = mode > 1 ? mode : (int)(own * c->fork_share);
     rows_a = std::max(2 * SR_HALO, std::min(rows_a, own - 2 * SR_HALO));
-    if (c->env_fork <= 1) {
+    if (mode <= 1) {
         static const int margin[5] = {5, 3, 2, 1, 0};
         static const double weight[5] = {0.0, 25600.0, 34816.0, 44032.0, 28800.0};  // issued MACs per pixel of stages 1-4 (conv0: negligible)
         const bool fours = c->precision == SR_PRECISION_F32;
@@ -934,7 +961,70 @@ bool plan_fork(const sr_ctx* c, bool img_u8, int img_ch, int n, int H, int W, in
     return true;
 }
 
+// ---- the fork decision measured on the caller's own calls (sr_internal.h ForkTune) ----------------------------------------------
+constexpr int kForkTuneBlock = 4;     // calls per plan: one dropped (the workspace meets a new geometry, first-use allocations), three timed
+constexpr size_t kForkTuneShapes = 8;  // shapes remembered per context
+constexpr double kForkTuneMinRounds = 0.55, kForkTuneMaxRounds = 12.0;  // outside: the rule (256x256 = 0.5 rounds: never; 1920x1080 = 15.8: exact f32 always)
+constexpr float kForkTuneGain = 0.985f;  // the fork must win by 1.5 % to be chosen: it costs a second workspace
+
+bool fork_tunable(const sr_ctx* c, int n, int H, int W, int halo_top, int halo_bot, const sr_halo_gate* gate) {
+    if (!c->fork_autotune || c->env_fork >= 0 || c->graph != SR_GRAPH_SR_NET || n != 1 || c->profiling || gate || W <= 0) return false;
+    const int own = H - halo_top - halo_bot;
+    if (own < 4 * SR_HALO) return false;
+    const int cus = c->cus > 0 ? c->cus : 256;
+    const double rounds = (double)((W + 31) / 32) * ((own + 7) / 8) / (2.0 * cus);
+    return rounds >= kForkTuneMinRounds && rounds < kForkTuneMaxRounds;
+}
+
+void fork_tune_release(sr_ctx::ForkTune& t) {
+    for (auto& e : t.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+}
+
+// The entry of this shape (created, with its two timing events, on first sight; the one used longest ago makes room).  Null: no tuning.
+sr_ctx::ForkTune* fork_tune_entry(sr_ctx* c, bool img_u8, bool out_u8, int img_ch, int H, int W, int halo_top, int halo_bot) {
+    ++c->fork_tune_clock;
+    for (auto& t : c->fork_tune)
+        if (t.H == H && t.W == W && t.top == halo_top && t.bot == halo_bot && t.img_u8 == img_u8 && t.out_u8 == out_u8 &&
+            t.img_ch == (img_u8 ? img_ch : 3) && t.precision == c->precision) { t.used = c->fork_tune_clock; return &t; }
+    if (c->fork_tune.size() >= kForkTuneShapes) {
+        size_t oldest = 0;
+        for (size_t k = 1; k < c->fork_tune.size(); ++k) if (c->fork_tune[k].used < c->fork_tune[oldest].used) oldest = k;
+        fork_tune_release(c->fork_tune[oldest]);  // (an event still in flight is released when it completes: hipEventDestroy's contract)
+        c->fork_tune.erase(c->fork_tune.begin() + (long)oldest);
+    }
+    sr_ctx::ForkTune t;
+    t.H = H; t.W = W; t.top = halo_top; t.bot = halo_bot; t.img_u8 = img_u8; t.out_u8 = out_u8; t.img_ch = img_u8 ? img_ch : 3; t.precision = c->precision;
+    t.used = c->fork_tune_clock;
+    for (auto& e : t.ev)
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); fork_tune_release(t); return nullptr; }
+    c->fork_tune.push_back(t);
+    return &c->fork_tune.back();
+}
+
+// Read the sample in flight if it has finished -- a query, never a wait.  A sample that cannot be read (a capturing stream, a device
+// error) ends the measurement in favour of the rule.
+void fork_tune_harvest(sr_ctx::ForkTune& t, int rule) {
+    if (!t.pending) return;
+    const hipError_t q = hipEventQuery(t.ev[1]);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return; }
+    float ms = 0.f;
+    if (q != hipSuccess || hipEventElapsedTime(&ms, t.ev[0], t.ev[1]) != hipSuccess || !(ms > 0.f)) {
+        (void)hipGetLastError();
+        t.pending = false; t.decided = rule;
+        return;
+    }
+    t.pending = false;
+    const int plan = t.taken < kForkTuneBlock ? 0 : 1;
+    if (t.taken % kForkTuneBlock != 0) t.best[plan] = std::min(t.best[plan], ms);
+    if (++t.taken >= 2 * kForkTuneBlock) t.decided = t.best[1] < kForkTuneGain * t.best[0] ? 1 : 0;
+}
+
 }  // namespace
+
+void sr_fork_tune_clear(sr_ctx* c) {
+    for (auto& t : c->fork_tune) fork_tune_release(t);
+    c->fork_tune.clear();
+}
 
 int sr_ensure_fork_resources(sr_ctx* c) {
     if (!c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -947,9 +1037,36 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
     if (!c || !d_img || !d_out) return SR_E_INVALID;
     c->band_pending = false;  // (the event pairs of an earlier sharded call are not this call's: sr_comm.cpp sets the flag again behind its own)
     int rows_a = 0;
-    if (!plan_fork(c, img_u8, img_ch, n, H, W, halo_top, halo_bot, &rows_a))
-        return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s, 0, gate);
     sr_device_guard restore_device;
+    int mode = c->env_fork;
+    sr_ctx::ForkTune* tune = nullptr;
+    bool sample = false;
+    if (fork_tunable(c, n, H, W, halo_top, halo_bot, gate)) {
+        HIPCHK(c, hipSetDevice(c->device));
+        tune = fork_tune_entry(c, img_u8, out_u8, img_ch, H, W, halo_top, halo_bot);
+        if (tune) {
+            int rows_rule = 0;
+            const int rule = plan_fork(c, -1, img_u8, img_ch, n, H, W, halo_top, halo_bot, &rows_rule) ? 1 : 0;
+            if (tune->decided < 0) fork_tune_harvest(*tune, rule);
+            if (tune->decided >= 0) {
+                mode = tune->decided;
+            } else {
+                mode = tune->taken < kForkTuneBlock ? 0 : 1;  // this block's plan; timed unless the last sample is still in flight
+                sample = !tune->pending;
+            }
+        }
+    }
+    if (sample && hipEventRecord(tune->ev[0], s) != hipSuccess) { (void)hipGetLastError(); sample = false; }
+    auto sampled = [&](int rc) {  // the closing event of a timed call, on the caller's stream (behind the join of a forked one)
+        if (sample && rc == SR_OK) {
+            if (hipEventRecord(tune->ev[1], s) == hipSuccess) tune->pending = true; else (void)hipGetLastError();
+        }
+        return rc;
+    };
+    if (!plan_fork(c, mode, img_u8, img_ch, n, H, W, halo_top, halo_bot, &rows_a)) {
+        if (tune && tune->decided < 0 && mode == 1) tune->decided = 0;  // (cannot be forked at all)
+        return sampled(sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s, 0, gate));
+    }
     HIPCHK(c, hipSetDevice(c->device));
     {
         const int rc = sr_ensure_fork_resources(c);
@@ -980,6 +1097,8 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
     if (rc == SR_E_NOMEM) {  // the second workspace is the optimisation's: give back what of it exists and run undivided on the first
         for (auto& p : c->ws[1].d_feat) { if (p) (void)hipFree(p); p = nullptr; }
         c->ws[1].feat_cap_px = 0; c->ws[1].geo_n = 0;
+        if (tune && tune->decided < 0) tune->decided = 0;  // (no room for the fork's second workspace)
+        sample = false;
         return sr_run_stack(c, d_img, img_u8, img_ch, n, H, W, halo_top, halo_bot, d_out, out_u8, s, 0, gate);
     }
     for (int st = 0; st < 5 && rc == SR_OK; ++st) {
@@ -992,7 +1111,7 @@ int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int
     if (rc != SR_OK) return rc;
     HIPCHK(c, e1); HIPCHK(c, e2);
     c->last_h = c->last_w = 0;  // each workspace holds one band: sr_read_feature refuses
-    return SR_OK;
+    return sampled(SR_OK);
 }
 
 namespace {
@@ -1335,7 +1454,8 @@ int sr_upscale_band_rgba8_dev(sr_ctx* c, const uint8_t* d_in, int in_channels, i
 // otherwise happen, synchronously, inside the first "asynchronous" sr_upscale_*_dev call after the reserve.
 static int reserve_fork(sr_ctx* c, bool img_u8, int img_ch, int n, int h, int w) {
     int rows_a = 0;
-    if (!plan_fork(c, img_u8, img_ch, n, h, w, 0, 0, &rows_a)) return SR_OK;
+    // (a shape the fork tuner will measure runs both ways: what the forked calls need is created here too)
+    if (!plan_fork(c, fork_tunable(c, n, h, w, 0, 0, nullptr) ? 1 : c->env_fork, img_u8, img_ch, n, h, w, 0, 0, &rows_a)) return SR_OK;
     sr_device_guard restore_device;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = sr_ensure_streams(c, false);

@@ -63,6 +63,24 @@ struct sr_ctx {
     double fork_max_rounds = 1e9;     //   ... and below this many (no upper bound by default)
     double fork_share = 0.5;          //   the first band's share of the rows
     hipEvent_t ev_fork[2] = {nullptr, nullptr};  // fork (caller's stream -> stream2) and join (stream2 -> caller's stream)
+    // Mid-size shapes (0.55-12 rounds of 8-row tiles): whether the fork pays depends on how the tiles of the image and of its two bands
+    // happen to fill the chip's last round -- -15 ... +20 % from one shape to the next (profiles/r6_fork_tune.txt), which no rule in
+    // `rounds` predicts.  So it is MEASURED, per shape and context, on the caller's own calls: a block of undivided calls, then a block of
+    // forked ones, each timed by an event pair on the caller's stream that is read -- never waited for -- at a later call of that shape;
+    // then the faster plan stays.  Results do not depend on the plan (bit-identical), only the time does.  sr_set_experiment "forktune".
+    struct ForkTune {
+        int H = 0, W = 0, top = 0, bot = 0, img_ch = 0, precision = 0;
+        bool img_u8 = false, out_u8 = false;
+        int taken = 0;                    // samples read so far: [0, kForkTuneBlock) undivided, [kForkTuneBlock, 2 kForkTuneBlock) forked; a block's first is dropped (warm-up)
+        float best[2] = {1e30f, 1e30f};   // fastest sample of either plan, ms
+        int decided = -1;                 // -1: still measuring, 0: undivided, 1: forked
+        bool pending = false;             // ev[] bracket a call whose time has not been read yet
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        unsigned long long used = 0;      // for eviction: the entry used longest ago goes
+    };
+    std::vector<ForkTune> fork_tune;
+    bool fork_autotune = true;
+    unsigned long long fork_tune_clock = 0;
     int env_bands = 0;                // host pipeline: forced number of row bands (0: automatic)
     std::vector<int> env_rows;        // host pipeline: forced band heights (empty: automatic)
     bool env_rows_two = false;        //   ... computed on alternating streams instead of in order
@@ -128,6 +146,7 @@ int sr_run_stack(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, i
 int sr_run_stack_auto(sr_ctx* c, const void* d_img, bool img_u8, int img_ch, int n, int H, int W, int halo_top, int halo_bot,
                       void* d_out, bool out_u8, hipStream_t s, const sr_halo_gate* gate = nullptr);
 int sr_ensure_fork_resources(sr_ctx* c);  // the second stream + the fork / join events
+void sr_fork_tune_clear(sr_ctx* c);      // forget what the fork tuner has measured (its events with it); the context's device is current
 
 // One pass of the conv stack over a band, stage by stage -- for a caller that has something to do BETWEEN the stages (sr_comm.cpp:
 // the per-layer feature-halo exchange).  `layers`: every stage computes the band's OWN rows only (no recompute

@@ -258,6 +258,12 @@ class Engine:
         """sr_set_experiment: "th" / "pipe" / "bw" A/B switches (results do not depend on them)."""
         _lib.check(self._L.sr_set_experiment(self._ctx, key.encode(), value.encode()))
 
+    def get_experiment(self, key: str) -> str:
+        """sr_get_experiment: what a switch has learned ("forktune": one line per shape the fork tuner has met)."""
+        buf = C.create_string_buffer(4096)
+        _lib.check(self._L.sr_get_experiment(self._ctx, key.encode(), buf, len(buf)))
+        return buf.value.decode()
+
     def set_profiling(self, on: bool):
         _lib.check(self._L.sr_set_profiling(self._ctx, int(on)))
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/srhip.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "python binding table out of sync with the header"
     experimental = _header_functions("srhip_experimental.h")
-    assert experimental == sorted(_lib.EXPERIMENTAL) == ["sr_set_experiment"]
+    assert experimental == sorted(_lib.EXPERIMENTAL) == ["sr_get_experiment", "sr_set_experiment"]
     for name in experimental:
         assert hasattr(L, name), f"{name} declared in include/srhip_experimental.h but not exported"
     assert not set(experimental) & set(declared)

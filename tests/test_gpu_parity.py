@@ -668,6 +668,60 @@ def test_forked_device_call_is_bit_identical(engines):
         eng.set_experiment("fork", "")
 
 
+def test_fork_tuner_measures_both_plans_and_never_changes_a_byte(engines):
+    """Mid-size shapes: whether a lone image runs undivided or as two bands is MEASURED on the caller's own calls (sr_internal.h ForkTune:
+    four undivided calls, four forked, timed by event pairs that are queried, never waited for; then the faster plan stays).  Every call
+    of the measurement and after it returns the undivided pass's bytes; the tuner settles after eight read samples when the caller fences
+    between calls, goes on working under a deep queue of unfenced calls, leaves shapes outside its range to the rule (256x256, 1920x1080)
+    and forgets on request."""
+    import torch
+    eng = engines["imagenet"]
+    rng = np.random.default_rng(78)
+    try:
+        eng.set_experiment("forktune", "1")
+        for (h, w) in ((448, 448), (300, 515)):
+            px = torch.from_numpy(rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)).cuda()
+            x = px.to(torch.float32) / 255.0
+            seen = len(eng.get_experiment("forktune").splitlines())
+            eng.set_experiment("fork", "0")
+            want8, want32 = eng.upscale_rgba8_dev(px), eng.upscale_f32_dev(x)
+            torch.cuda.synchronize()
+            eng.set_experiment("fork", "")
+            assert len(eng.get_experiment("forktune").splitlines()) == seen  # (a forced plan is not the tuner's business)
+            for k in range(10):
+                assert torch.equal(eng.upscale_rgba8_dev(px), want8), (h, w, k)
+                torch.cuda.synchronize()
+            lines = [l.split() for l in eng.get_experiment("forktune").splitlines()]
+            mine = [l for l in lines if l[0] == f"{h}x{w}+0+0" and l[2] == "u8"]
+            assert len(mine) == 1 and mine[0][3] in ("undivided", "forked"), lines
+            assert float(mine[0][4]) > 0 and float(mine[0][5]) > 0
+            for k in range(3):
+                assert torch.equal(eng.upscale_rgba8_dev(px), want8)
+            # the f32 entry point is a shape of its own, met here under a deep queue: no fence between the calls
+            outs = [eng.upscale_f32_dev(x) for _ in range(24)]
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, want32) for o in outs)
+            del outs
+        n_seen = len(eng.get_experiment("forktune").splitlines())
+        assert n_seen == 4
+        for (h, w) in ((256, 256), (1080, 1920)):  # 0.5 and 15.8 rounds of tiles: the rule's
+            px = torch.from_numpy(rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)).cuda()
+            eng.upscale_rgba8_dev(px)
+        torch.cuda.synchronize()
+        assert len(eng.get_experiment("forktune").splitlines()) == n_seen
+        eng.set_experiment("forktune", "0")
+        assert eng.get_experiment("forktune") == ""
+        px = torch.from_numpy(rng.integers(0, 256, (1, 448, 448, 3), dtype=np.uint8)).cuda()
+        eng.upscale_rgba8_dev(px)
+        torch.cuda.synchronize()
+        assert eng.get_experiment("forktune") == ""
+        with pytest.raises(Exception):
+            eng.get_experiment("no such key")
+    finally:
+        eng.set_experiment("fork", "")
+        eng.set_experiment("forktune", "")
+
+
 def test_reference_image_pins_through_the_gpu(engines, params):
     """The docs images the reference ships, fed to the ENGINE (tests/test_oracle_golden.py holds the same pins for the oracle, so
     that no fixture is seen by the oracle alone): `-p bilinear` against logo_lin.png (made by an older alumina whose data_to_img
