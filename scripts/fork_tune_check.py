@@ -20,6 +20,7 @@ ap.add_argument("--prec", default="f32,split_f16")
 ap.add_argument("--sizes", default="272x272,320x320,384x384,448x448,512x512,576x576,640x480,720x576,540x960,768x768,720x1280")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--learn", default="fenced", choices=["fenced", "queued"], help="how the tuner meets the shape: a fence after every call, or bursts of 16 calls queued back to back")
 a = ap.parse_args()
 
 import torch  # noqa: E402
@@ -43,9 +44,15 @@ for prec in a.prec.split(","):
         eng.set_experiment("fork", "")
         eng.set_experiment("forktune", "1")
         tuned_out = eng.upscale_rgba8_dev(x)
-        for _ in range(12):
-            eng.upscale_rgba8_dev(x, out=tuned_out)
-            torch.cuda.synchronize()
+        if a.learn == "fenced":
+            for _ in range(12):
+                eng.upscale_rgba8_dev(x, out=tuned_out)
+                torch.cuda.synchronize()
+        else:
+            for _ in range(12):  # (a sample is read at the first call that finds it finished: about one per burst)
+                for _ in range(16):
+                    eng.upscale_rgba8_dev(x, out=tuned_out)
+                torch.cuda.synchronize()
         learned = eng.get_experiment("forktune").strip()
         decision = learned.split()[3] if learned else "rule"
         ms_u, ms_f = (float(learned.split()[4]), float(learned.split()[5])) if learned else (0.0, 0.0)
@@ -76,7 +83,7 @@ for prec in a.prec.split(","):
         eng.set_experiment("fork", "")
         med = {v: float(np.median(times[v])) for v in variants}
         print(json.dumps({"prec": prec, "image": [H, W], "rounds_of_tiles": round(math.ceil(W / 32) * math.ceil(H / 8) / 512, 2),
-                          "decision": decision, "tuner_ms": [ms_u, ms_f], **{v + "_ms": round(med[v], 4) for v in variants},
+                          "learned": a.learn, "decision": decision, "tuner_ms": [ms_u, ms_f], **{v + "_ms": round(med[v], 4) for v in variants},
                           "tuned_vs_rule": round(med["tuned"] / med["rule"], 4), "best_fixed_vs_rule": round(min(med["undivided"], med["forked"]) / med["rule"], 4),
                           "same_bytes": all(bool(torch.equal(outs[v], outs["undivided"])) for v in variants)}), flush=True)
         eng_rule.close()
