@@ -898,6 +898,43 @@ def main():
                 result["config_A"] = {"error": str(ex)[:300]}
 
             try:
+                # Mid-size lone frames (0.6-3 rounds of tiles): whether one runs undivided or as two bands on two streams is measured by the
+                # library on the caller's own calls (sr_ctx::ForkTune).  Per shape: a context with the tuner off (the rule alone) against
+                # one that has met the shape under a queue, interleaved bursts, same bytes.
+                if u8:
+                    e_rule = r.Engine(params, device=local, precision=args.precision)
+                    e_rule.set_experiment("forktune", "0")
+                    mids = []
+                    for (mh, mw) in ((320, 320), (360, 640), (480, 854)):
+                        xm = torch.from_numpy(synth_u8(3, mh, mw)).to(dev)[None]
+                        o_rule, o_tuned = e_rule.upscale_rgba8_dev(xm), eng.upscale_rgba8_dev(xm)
+                        for _ in range(12):  # the tuner reads about one sample per fenced burst
+                            for _ in range(16):
+                                eng.upscale_rgba8_dev(xm, out=o_tuned)
+                                e_rule.upscale_rgba8_dev(xm, out=o_rule)
+                            torch.cuda.synchronize()
+                        t_m = {"rule": [], "tuned": []}
+                        for _ in range(3):
+                            for name, e, o in (("rule", e_rule, o_rule), ("tuned", eng, o_tuned)):
+                                torch.cuda.synchronize()
+                                t0 = time.perf_counter()
+                                for _ in range(100):
+                                    e.upscale_rgba8_dev(xm, out=o)
+                                torch.cuda.synchronize()
+                                t_m[name].append((time.perf_counter() - t0) / 100 * 1e3)
+                        state = [l.split() for l in eng.get_experiment("forktune").splitlines() if l.startswith(f"{mh}x{mw}+")]
+                        ms_r, ms_t = float(np.median(t_m["rule"])), float(np.median(t_m["tuned"]))
+                        mids.append({"image": [mh, mw], "rule_ms": round(ms_r, 4), "tuned_ms": round(ms_t, 4), "plan": state[0][3] if state else "rule",
+                                     "whole_call_frac": round(mh * mw * FLOP_PER_PX / (ms_t / 1e3) / 1e12 / peak_here, 4),
+                                     "same_bytes": bool(torch.equal(o_rule, o_tuned))})
+                        del xm, o_rule, o_tuned
+                    e_rule.close()
+                    result["mid_size_frames"] = {"entries": mids, "note": "lone frames of 0.6-3 rounds of tiles: the fork decision measured on the caller's "
+                                                 "own calls (DESIGN.md 4e, profiles/r6_fork_tune.txt) against the fixed rule; BASELINE's shapes are outside the tuner's range"}
+            except Exception as ex:  # noqa: BLE001
+                result["mid_size_frames"] = {"error": str(ex)[:300]}
+
+            try:
                 # the two parameter-free graphs (`-p bilinear`, `-d`), HBM-bound elementwise kernels
                 result["aux_graphs"] = {"entries": aux_entries(r, torch, ((H, W), (3 * H, 3 * W)), 100, local),
                                         "note": "bilinear_net x3 / downsample_net /3 (network.rs:111-138), device-resident; GBps counts compulsory I/O only "

@@ -56,6 +56,10 @@ def test_bench_single_gpu_contract():
         # ... and projected with per-layer feature halos (nothing recomputed): the kernel work of the band's own rows
         assert 0 < e["layer_halos"]["kernel_ms_per_band"] <= e["ms_per_band"] * 1.02 and e["useful_roofline_frac"] * 0.98 <= e["layer_halos"]["useful_roofline_frac"] < 1
     assert 0 < d["config_A"]["whole_call_frac"] < 1
+    # mid-size lone frames: the measured fork decision against the fixed rule -- same bytes, never meaningfully slower
+    mid = d["mid_size_frames"]
+    assert "error" not in mid and len(mid["entries"]) == 3
+    assert all(e["same_bytes"] and e["plan"] in ("undivided", "forked") and 0 < e["tuned_ms"] <= 1.05 * e["rule_ms"] for e in mid["entries"]), mid
     # the split-half mode beside the headline: its dominant kernel against BOTH denominators (the nominal f16 peak and the rate a bare
     # random-operand stream of its instruction sustains on this part), on issued FLOPs (three f16 products per algorithmic one)
     orf = d["other_precision"]["roofline"]
