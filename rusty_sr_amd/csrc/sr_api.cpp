@@ -1158,7 +1158,20 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
     const bool part = y_lo > 0 || y_hi < h;  // a share of the image: always in band form (halo rows from the image itself)
     const int span = y_hi - y_lo;
     std::vector<int> rows;  // rows of each band, top to bottom
-    if (pipe && n == 1 && c->graph == SR_GRAPH_SR_NET && (size_t)span * w >= ((size_t)1 << 19)) {
+    int forced_sum = 0;
+    for (int rk : c->env_rows) forced_sum += rk;
+    const bool forced_plan = (!c->env_rows.empty() && forced_sum == span) || c->env_bands > 0;  // (sr_set_experiment "rows" / "bands": at any size)
+    // Below 2^19 px a lone frame used to go as ONE chunk: upload, kernels, download, nothing overlapping.  Round 6, u8 output, from
+    // ~200K px on: TWO bands in order on one stream -- the first band's download runs under the second band's kernels, which is worth more
+    // than the second band's 7 recomputed rows and five launches cost (scripts/host_plan_sweep.py, profiles/r6_host_mid_plans.txt: exact f32,
+    // 70 / 30: 640x480 0.970 -> 0.873 ms, 854x480 1.311 -> 1.138, 800x600 1.420 -> 1.330, 720x576 1.312 -> 1.186, 960x540 1.479 -> 1.342;
+    // the split-half mode, whose kernels are shorter beside the same download, 60 / 40: 640x480 0.536 -> 0.468, 800x600 0.792 -> 0.660,
+    // 960x540 0.837 -> 0.701; at 320x320 neither mode gains).  Equal bands on alternating streams are within 2 % of these on most shapes
+    // and 6 % better on some (800x600), 6 % worse on others: the in-order plan is the even-tempered one.
+    // (from 200K px in exact f32 -- 448x448 -5.4 %, 640x360 -6.5 %, 640x480 -5.5 % against one chunk measured alternately, but 430x419 +3 % -- and
+    // from 180K px in the split-half mode: 430x419 -4 %, 448x448 -11 %)
+    const bool mid_size = out_px_bytes == 4 && (size_t)span * w >= (c->precision == SR_PRECISION_SPLIT_F16 ? 180000u : 200000u) && (size_t)span * w < ((size_t)1 << 19);
+    if (pipe && n == 1 && c->graph == SR_GRAPH_SR_NET && (forced_plan || mid_size || (size_t)span * w >= ((size_t)1 << 19))) {
         // Kernel and download time per input pixel decide the shape of the plan (measured, page-locked buffers, PCIe 5 x16):
         const double kern_ns = (c->precision == SR_PRECISION_SPLIT_F16 ? 0.9 : 2.0) * (f == 4 ? 1.2 : 1.0);
         const double d2h_ns = (double)out_px_bytes * f * f / 52.0;
@@ -1171,6 +1184,9 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
         } else if (c->env_bands > 0) {  // sr_set_experiment("bands"): that many equal bands
             const int nb = std::min(c->env_bands, span / (2 * SR_HALO));
             for (int k = 0; k < nb; ++k) rows.push_back((span * (k + 1)) / nb - (span * k) / nb);
+        } else if (mid_size) {
+            const int first = (int)(span * (c->precision == SR_PRECISION_SPLIT_F16 ? 0.6 : 0.7)) / 8 * 8;
+            if (first >= 2 * SR_HALO && span - first >= 2 * SR_HALO) { rows = {first, span - first}; *in_order = true; }
         } else {
             // Compute-bound (f32 arithmetic, u8 output: rho = 2.9): only the LAST band's download is exposed, and band
             // i's download hides under band i+1's kernels as long as band i+1 is at least 1/rho of it -- bands that
@@ -1211,7 +1227,7 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
                 }
             }
         }
-        if (rows.empty()) {
+        if (rows.empty() && !mid_size) {
             // Download-bound or balanced (f32 output, the split-half mode): equal bands.  Few expose the first upload
             // and the last download, many pay 14 recomputed rows and five launches each.  Measured, f32 1080p
             // 1 / 2 / 4 / 5 / 8 bands = 5.96 / 5.14 / 4.93 / 5.12 / 5.22 ms; the split-half mode computes 2.2x faster

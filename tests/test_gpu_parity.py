@@ -271,6 +271,37 @@ def test_host_pipeline_bands_are_bit_identical(engines, h, w):
     np.testing.assert_array_equal(got8p, want8)
 
 
+@pytest.mark.parametrize("h,w", [(480, 640), (448, 448), (540, 960), (450, 446), (333, 911)])
+def test_host_call_of_a_mid_size_frame_runs_as_two_bands_bit_identically(engines, h, w):
+    """sr_upscale_rgba8 on host pointers, 200K (split-half mode: 180K) ... 524K px: two bands in order on one stream (70 / 30 in exact
+    f32, 60 / 40 in the split-half mode), the first band's download under the second band's kernels (450x446 = 200 700 px is just above
+    the threshold); below it (300x515 here, 256x256 elsewhere) one chunk as before.  Bytes equal the undivided pass's; the call leaves
+    a band's maps behind, so sr_read_feature refuses."""
+    import rusty_sr_amd as r
+    from rusty_sr_amd.engine import host_alloc
+    eng = engines["imagenet"]
+    px = synth_u8(h * w, 1, h, w)[0]
+    try:
+        eng.set_pipeline(False)
+        want8 = eng.upscale_rgba8(px)
+        assert eng.read_feature(0, h, w).shape == (h, w, 32)
+        eng.set_pipeline(True)
+        got8 = eng.upscale_rgba8(px)
+        with pytest.raises(r.SrError):
+            eng.read_feature(0, h, w)
+        pin_in, pin_out = host_alloc((h, w, 3)), host_alloc((3 * h, 3 * w, 4))
+        pin_in.array[...] = px
+        got8p = eng.upscale_rgba8(pin_in.array, out=pin_out.array).copy()
+        pin_in.close(); pin_out.close()
+        small = synth_u8(7, 1, 300, 515)[0]   # 154 500 px: one chunk
+        eng.upscale_rgba8(small)
+        assert eng.read_feature(0, 300, 515).shape == (300, 515, 32)
+    finally:
+        eng.set_pipeline(True)
+    np.testing.assert_array_equal(got8, want8)
+    np.testing.assert_array_equal(got8p, want8)
+
+
 def test_reserve_allocates_and_warms_without_touching_results(params):
     """sr_reserve_*: the allocations and one pass of the kernels of a later sr_upscale_* call of that shape, on whatever
     the staging buffers hold.  Results of the real calls are what a context that never reserved gives -- also when the
@@ -387,15 +418,16 @@ def test_pipe_form_equals_first_form_bit_for_bit(engines, params):
             x = oracle.img_to_data(px)
             eng.set_experiment("th", "8")
             eng.set_experiment("pipe", "all")
-            pipe32, pipe8 = eng.upscale_f32(x), eng.upscale_rgba8(px)
+            # (the f32 call LAST before every feature read: a u8 host call of 180K px or more runs as two bands, and a band's maps are not the image's)
+            pipe8, pipe32 = eng.upscale_rgba8(px), eng.upscale_f32(x)
             feats = [eng.read_feature(k, h, w) for k in range(4)]
             for bw in ("0", "3", "16"):
                 eng.set_experiment("bw", bw)
                 np.testing.assert_array_equal(eng.upscale_f32(x), pipe32, err_msg=f"tile order bw={bw} {(n, h, w)}")
             eng.set_experiment("bw", "")
             eng.set_experiment("th", "4")  # the pipe form on 4-row tiles only
-            np.testing.assert_array_equal(eng.upscale_f32(x), pipe32, err_msg=f"pipe form, 4-row tiles {(n, h, w)}")
             np.testing.assert_array_equal(eng.upscale_rgba8(px), pipe8, err_msg=f"pipe form, 4-row tiles, u8 {(n, h, w)}")
+            np.testing.assert_array_equal(eng.upscale_f32(x), pipe32, err_msg=f"pipe form, 4-row tiles {(n, h, w)}")
             for k in range(4):
                 np.testing.assert_array_equal(feats[k], eng.read_feature(k, h, w), err_msg=f"feature {k}, 4-row tiles {(n, h, w)}")
             eng.set_experiment("th", "")   # automatic: both classes in one launch, for several tail lengths
