@@ -1170,7 +1170,15 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
     // and 6 % better on some (800x600), 6 % worse on others: the in-order plan is the even-tempered one.
     // (from 200K px in exact f32 -- 448x448 -5.4 %, 640x360 -6.5 %, 640x480 -5.5 % against one chunk measured alternately, but 430x419 +3 % -- and
     // from 180K px in the split-half mode: 430x419 -4 %, 448x448 -11 %)
-    const bool mid_size = out_px_bytes == 4 && (size_t)span * w >= (c->precision == SR_PRECISION_SPLIT_F16 ? 180000u : 200000u) && (size_t)span * w < ((size_t)1 << 19);
+    // f32 OUTPUT (three times the download, as long as the kernels or longer): in-order bands pay more still -- exact f32 60 / 40: 448x448
+    // 0.982 -> 0.801 ms, 640x480 1.379 -> 1.143; three equal bands from 400K px: 800x600 2.186 -> 1.556, 960x540 2.253 -> 1.784; split-half
+    // two equal bands: 448x448 0.686 -> 0.603, three from 300K px: 640x480 0.974 -> 0.845, 800x600 1.472 -> 1.234, 960x540 1.582 -> 1.328.
+    const bool split_mode = c->precision == SR_PRECISION_SPLIT_F16;
+    const size_t px_span = (size_t)span * w;
+    // (f32 output, smaller frames: exact f32 60 / 40 at 384x384 0.737 -> 0.621, at 320x320 0.578 -> 0.500; split-half 50 / 50 at 384x384 0.523 -> 0.483,
+    // at 320x320 -3 %: from 100K / 140K px)
+    const size_t mid_lo = out_px_bytes == 4 ? (split_mode ? 180000u : 200000u) : (split_mode ? 140000u : 100000u);
+    const bool mid_size = px_span >= mid_lo && px_span < ((size_t)1 << 19);
     if (pipe && n == 1 && c->graph == SR_GRAPH_SR_NET && (forced_plan || mid_size || (size_t)span * w >= ((size_t)1 << 19))) {
         // Kernel and download time per input pixel decide the shape of the plan (measured, page-locked buffers, PCIe 5 x16):
         const double kern_ns = (c->precision == SR_PRECISION_SPLIT_F16 ? 0.9 : 2.0) * (f == 4 ? 1.2 : 1.0);
@@ -1185,8 +1193,16 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
             const int nb = std::min(c->env_bands, span / (2 * SR_HALO));
             for (int k = 0; k < nb; ++k) rows.push_back((span * (k + 1)) / nb - (span * k) / nb);
         } else if (mid_size) {
-            const int first = (int)(span * (c->precision == SR_PRECISION_SPLIT_F16 ? 0.6 : 0.7)) / 8 * 8;
-            if (first >= 2 * SR_HALO && span - first >= 2 * SR_HALO) { rows = {first, span - first}; *in_order = true; }
+            const bool u8_out = out_px_bytes == 4;
+            if (!u8_out && px_span >= (split_mode ? 300000u : 400000u) && span >= 6 * SR_HALO) {
+                const int third = span / 3 / 8 * 8;
+                rows = {third, third, span - 2 * third};
+            } else {
+                const double share = u8_out ? (split_mode ? 0.6 : 0.7) : (split_mode ? 0.5 : 0.6);
+                const int first = (int)(span * share) / 8 * 8;
+                if (first >= 2 * SR_HALO && span - first >= 2 * SR_HALO) rows = {first, span - first};
+            }
+            *in_order = !rows.empty();
         } else {
             // Compute-bound (f32 arithmetic, u8 output: rho = 2.9): only the LAST band's download is exposed, and band
             // i's download hides under band i+1's kernels as long as band i+1 is at least 1/rho of it -- bands that

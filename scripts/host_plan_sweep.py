@@ -20,8 +20,17 @@ def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
     H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1080, 1920)
     eng = r.Engine(r.rsr.builtin("imagenet"), device=0, precision=prec)
-    pin_in, pin_out = host_alloc((H, W, 3)), host_alloc((3 * H, 3 * W, 4))
-    pin_in.array[...] = synth_u8(2, H, W)
+    f32io = os.environ.get("SWEEP_IO") == "f32"  # SWEEP_IO=f32: sr_upscale_f32 (f32 in, f32 out: three times the download)
+    if f32io:
+        pin_in, pin_out = host_alloc((H, W, 3), np.float32), host_alloc((3 * H, 3 * W, 3), np.float32)
+        pin_in.array[...] = r.img_to_data(synth_u8(2, H, W))
+        import ctypes as C
+        fp = C.POINTER(C.c_float)
+        call = lambda: r._lib.check(eng._L.sr_upscale_f32(eng._ctx, pin_in.array.ctypes.data_as(fp), 1, H, W, pin_out.array.ctypes.data_as(fp)), eng._ctx)
+    else:
+        pin_in, pin_out = host_alloc((H, W, 3)), host_alloc((3 * H, 3 * W, 4))
+        pin_in.array[...] = synth_u8(2, H, W)
+        call = lambda: eng.upscale_rgba8(pin_in.array, out=pin_out.array)
     plans = [""] + (sys.argv[4:] if len(sys.argv) > 4 else [])
     if len(plans) == 1:
         def cut(fracs):
@@ -40,16 +49,16 @@ def main():
     for plan in plans:
         eng.set_experiment("rows", plan)
         for _ in range(3):
-            eng.upscale_rgba8(pin_in.array, out=pin_out.array)
+            call()
         per = []
         for _ in range(25):
             t0 = time.perf_counter()
-            eng.upscale_rgba8(pin_in.array, out=pin_out.array)
+            call()
             per.append((time.perf_counter() - t0) * 1e3)
         t = eng.last_timing()
         if want is None:
             want = pin_out.array.copy()
-        print(json.dumps({"prec": prec, "image": [H, W], "rows": plan or "auto", "ms_median": round(float(np.median(per)), 4), "ms_min": round(min(per), 4),
+        print(json.dumps({"prec": prec, "io": "f32" if f32io else "rgba8", "image": [H, W], "rows": plan or "auto", "ms_median": round(float(np.median(per)), 4), "ms_min": round(min(per), 4),
                           "kernel_ms": round(t["total_ms"], 4), "d2h_ms": round(t["d2h_ms"], 4), "chunks": t.get("chunks"),
                           "same_bytes": bool(np.array_equal(want, pin_out.array))}), flush=True)
     eng.set_experiment("rows", "")

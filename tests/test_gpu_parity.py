@@ -282,20 +282,28 @@ def test_host_call_of_a_mid_size_frame_runs_as_two_bands_bit_identically(engines
     eng = engines["imagenet"]
     px = synth_u8(h * w, 1, h, w)[0]
     try:
+        x = oracle.img_to_data(px)
         eng.set_pipeline(False)
-        want8 = eng.upscale_rgba8(px)
+        want8, want32 = eng.upscale_rgba8(px), eng.upscale_f32(x)
         assert eng.read_feature(0, h, w).shape == (h, w, 32)
         eng.set_pipeline(True)
         got8 = eng.upscale_rgba8(px)
         with pytest.raises(r.SrError):
             eng.read_feature(0, h, w)
+        got32 = eng.upscale_f32(x)   # f32 output: three times the download -- two bands (three from 400K / 300K px) in order
+        with pytest.raises(r.SrError):
+            eng.read_feature(0, h, w)
+        np.testing.assert_array_equal(got32, want32)
         pin_in, pin_out = host_alloc((h, w, 3)), host_alloc((3 * h, 3 * w, 4))
         pin_in.array[...] = px
         got8p = eng.upscale_rgba8(pin_in.array, out=pin_out.array).copy()
         pin_in.close(); pin_out.close()
-        small = synth_u8(7, 1, 300, 515)[0]   # 154 500 px: one chunk
+        small = synth_u8(7, 1, 300, 515)[0]   # 154 500 px: one chunk with u8 output
         eng.upscale_rgba8(small)
         assert eng.read_feature(0, 300, 515).shape == (300, 515, 32)
+        tiny = oracle.img_to_data(synth_u8(8, 1, 200, 333)[0])   # 66 600 px: one chunk with f32 output too
+        eng.upscale_f32(tiny)
+        assert eng.read_feature(0, 200, 333).shape == (200, 333, 32)
     finally:
         eng.set_pipeline(True)
     np.testing.assert_array_equal(got8, want8)
@@ -413,12 +421,12 @@ def test_pipe_form_equals_first_form_bit_for_bit(engines, params):
     shapes = [(1, 8, 32), (1, 9, 33), (2, 40, 70), (1, 64, 1024), (3, 37, 129), (1, 130, 700), (1, 300, 515), (1, 2000, 40), (1, 16, 3000),
               (1, 250, 2080), (2, 333, 640)]
     try:
+        eng.set_pipeline(False)  # one chunk per host call: a lone frame of 100K px or more otherwise runs as bands, and a band's maps are not the image's (the feature reads below)
         for (n, h, w) in shapes:
             px = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
             x = oracle.img_to_data(px)
             eng.set_experiment("th", "8")
             eng.set_experiment("pipe", "all")
-            # (the f32 call LAST before every feature read: a u8 host call of 180K px or more runs as two bands, and a band's maps are not the image's)
             pipe8, pipe32 = eng.upscale_rgba8(px), eng.upscale_f32(x)
             feats = [eng.read_feature(k, h, w) for k in range(4)]
             for bw in ("0", "3", "16"):
@@ -456,6 +464,7 @@ def test_pipe_form_equals_first_form_bit_for_bit(engines, params):
             if n * h * w <= 40 * 70 * 2:
                 assert np.abs(pipe32 - oracle.forward(params["imagenet"], x)).max() < TIGHT
     finally:
+        eng.set_pipeline(True)
         for key in ("th", "pipe", "bw", "tail"):
             eng.set_experiment(key, "")
 
