@@ -929,7 +929,28 @@ def main():
                                      "same_bytes": bool(torch.equal(o_rule, o_tuned))})
                         del xm, o_rule, o_tuned
                     e_rule.close()
-                    result["mid_size_frames"] = {"entries": mids, "note": "lone frames of 0.6-3 rounds of tiles: the fork decision measured on the caller's "
+                    # ... and the host-pointer call of such a frame (what a drop-in caller's 640x480 picture takes): two bands in order, the first
+                    # band's download under the second band's kernels, against one chunk (upload, kernels, download in sequence)
+                    from rusty_sr_amd.engine import host_alloc
+                    hin, hout = host_alloc((480, 640, 3)), host_alloc((1440, 1920, 4))
+                    hin.array[...] = synth_u8(3, 480, 640)
+                    host_ms = {}
+                    for rnd in range(3):
+                        for name, on in (("one_chunk", False), ("two_bands", True)):
+                            eng.set_pipeline(on)
+                            for _ in range(3):
+                                eng.upscale_rgba8(hin.array, out=hout.array)
+                            per = []
+                            for _ in range(20):
+                                t0 = time.perf_counter()
+                                eng.upscale_rgba8(hin.array, out=hout.array)
+                                per.append((time.perf_counter() - t0) * 1e3)
+                            host_ms.setdefault(name, []).append(float(np.median(per)))
+                    eng.set_pipeline(True)
+                    hin.close(); hout.close()
+                    host_entry = {"image": [480, 640], "one_chunk_ms": round(float(np.median(host_ms["one_chunk"])), 4),
+                                  "ms": round(float(np.median(host_ms["two_bands"])), 4), "note": "sr_upscale_rgba8, page-locked buffers, PCIe-inclusive"}
+                    result["mid_size_frames"] = {"entries": mids, "host_call": host_entry, "note": "lone frames of 0.6-3 rounds of tiles: the fork decision measured on the caller's "
                                                  "own calls (DESIGN.md 4e, profiles/r6_fork_tune.txt) against the fixed rule; BASELINE's shapes are outside the tuner's range"}
             except Exception as ex:  # noqa: BLE001
                 result["mid_size_frames"] = {"error": str(ex)[:300]}

@@ -60,6 +60,7 @@ def test_bench_single_gpu_contract():
     mid = d["mid_size_frames"]
     assert "error" not in mid and len(mid["entries"]) == 3
     assert all(e["same_bytes"] and e["plan"] in ("undivided", "forked") and 0 < e["tuned_ms"] <= 1.05 * e["rule_ms"] for e in mid["entries"]), mid
+    assert 0 < mid["host_call"]["ms"] <= 1.05 * mid["host_call"]["one_chunk_ms"], mid["host_call"]
     # the split-half mode beside the headline: its dominant kernel against BOTH denominators (the nominal f16 peak and the rate a bare
     # random-operand stream of its instruction sustains on this part), on issued FLOPs (three f16 products per algorithmic one)
     orf = d["other_precision"]["roofline"]
