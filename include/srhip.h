@@ -142,8 +142,8 @@ int sr_upscale_rgba8_batch_multi(sr_ctx* const* ctxs, int n_ctx, const uint8_t* 
 
 /* The host-pointer entry points (sr_upscale_f32 / sr_upscale_rgba8 and their _multi forms) run upload / conv stack / download as a software
  * pipeline on up to four HIP streams of the context's own, created on first need (a call that is one chunk uses one): a batch goes in
- * chunks of whole images, one large sr_net image as row bands with SR_HALO halo rows (bit-identical to the undivided pass, see
- * sr_upscale_band_*).  Results do not depend on the setting; 0 = one upload, one pass, one download.  The reference has no counterpart
+ * chunks of whole images, one sr_net image of about 200K pixels or more (100K with f32 output) as two or more row bands with SR_HALO
+ * halo rows, so that a band's download runs under the next band's kernels (bit-identical to the undivided pass, see sr_upscale_band_*).  Results do not depend on the setting; 0 = one upload, one pass, one download.  The reference has no counterpart
  * (its tensors never leave host memory, main.rs:168-175); buffers from sr_host_alloc are page-locked, which lets the copies run at
  * PCIe rate and truly overlap -- any host memory is accepted.
  * (The device-pointer entry points below run on the CALLER'S stream; where they cut one image into two bands they also use one stream
@@ -258,7 +258,8 @@ int sr_check_domain(sr_ctx* ctx);
 
 /* Test hook: copy the post-activation feature maps of the most recent call
  * (image 0) to host: which = 0..3 -> f, l1, l2, l3 (h*w*32 f32 each).  The
- * reference exposes the same values as graph node data (network.rs:30,43-48). */
+ * reference exposes the same values as graph node data (network.rs:30,43-48).  Refused (SR_E_INVALID) after a call that ran the image
+ * as bands -- a pipelined host call, a forked device call: sr_set_pipeline(ctx, 0) / the undivided device call leave whole maps. */
 int sr_read_feature(sr_ctx* ctx, int which, float* out_host, size_t cap_floats);
 
 /* Device time of the most recent call, measured with HIP events on the stream
