@@ -772,6 +772,9 @@ def main():
                         ext = torch.from_numpy(r.img_to_data(ext.cpu().numpy())).to(dev)
                     ob = torch.empty((3 * rows_b, 3 * WC, 4 if u8 else 3), dtype=dt_in, device=dev)
                     fnb = eng.upscale_band_rgba8_dev if u8 else eng.upscale_band_f32_dev
+                    # (the plan a rank of the real split runs: its sharded call follows the fork RULE -- the halo gate takes a band out of the
+                    # fork tuner's hands -- so the projection does too)
+                    eng.set_experiment("forktune", "0")
                     for _ in range(3):
                         fnb(ext, topb, botb, out=ob)
                     torch.cuda.synchronize()
@@ -806,6 +809,7 @@ def main():
                                         "useful_roofline_frac": round(rows_b * WC * FLOP_PER_PX / (best_l / 1e3) / 1e12 / peak_here, 4),
                                         "exchanged_bytes_per_neighbour": int((2 + 3) * (32 * ((WC + 31) // 32) + 4) * 128)}}
                     del ext, ob, own
+                    eng.set_experiment("forktune", "")
                 preview["rows"], preview["halo_rows"] = 270, 14  # (the 8-way entry under its round-2 keys)
                 preview["ms_per_band"] = preview["8_way"]["ms_per_band"]
                 preview["eight_bands_in_parallel_would_be"] = preview["8_way"]["n_bands_in_parallel_would_be"]
