@@ -905,7 +905,7 @@ def main():
                 # Mid-size lone frames (0.6-3 rounds of tiles): whether one runs undivided or as two bands on two streams is measured by the
                 # library on the caller's own calls (sr_ctx::ForkTune).  Per shape: a context with the tuner off (the rule alone) against
                 # one that has met the shape under a queue, interleaved bursts, same bytes.
-                if u8:
+                if u8 and os.environ.get("SRHIP_BENCH_MID", "1") != "0":
                     e_rule = r.Engine(params, device=local, precision=args.precision)
                     e_rule.set_experiment("forktune", "0")
                     mids = []
@@ -1044,6 +1044,42 @@ def main():
                                            "t_e2e_device_ms": round(ms_h, 4), "t_e2e_device_ms_min": round(min(per_call), 4), "value": round(9 * H * W / 1e6 / (ms_h / 1e3), 2), "unit": "output MP/s",
                                            "t_kernel_ms": round(t["total_ms"], 4), "h2d_ms": round(t["h2d_ms"], 4), "d2h_ms": round(t["d2h_ms"], 4),
                                            "note": "PCIe-inclusive (6.2 MB up, 74.6 MB down): never `value`"}
+                    # diagnostic (SRHIP_BENCH_HOST_PLANS="rows;rows;..."): the same call under explicit band plans IN THIS PROCESS -- a host call's
+                    # wall time depends on the process's history in ways a fresh process does not show (profiles/r6_host_mid_plans.txt 7.)
+                    if os.environ.get("SRHIP_BENCH_HOST_PLANS"):
+                        alt = {}
+                        for plan in os.environ["SRHIP_BENCH_HOST_PLANS"].split(";") + [""]:
+                            eng.set_experiment("rows", plan)
+                            for _ in range(3):
+                                call()
+                            per = []
+                            for _ in range(12):
+                                t0 = time.perf_counter()
+                                call()
+                                per.append((time.perf_counter() - t0) * 1e3)
+                            alt[plan or "auto"] = round(float(np.median(per)), 4)
+                        eng.set_experiment("rows", "")
+                        result["host_call"]["plans"] = alt
+                    if os.environ.get("SRHIP_BENCH_HOST_F32OUT"):  # diagnostic: the f32-output call (sr_upscale_f32), first use in this process, then explicit plans
+                        import ctypes as C
+                        fp = C.POINTER(C.c_float)
+                        fin, fout = host_alloc((H, W, 3), np.float32), host_alloc((3 * H, 3 * W, 3), np.float32)
+                        fin.array[...] = r.img_to_data(px)
+                        fcall = lambda: r._lib.check(eng._L.sr_upscale_f32(eng._ctx, fin.array.ctypes.data_as(fp), 1, H, W, fout.array.ctypes.data_as(fp)), eng._ctx)
+                        alt = {}
+                        for plan in ["first use"] + os.environ["SRHIP_BENCH_HOST_F32OUT"].split(";") + [""]:
+                            eng.set_experiment("rows", "" if plan == "first use" else plan)
+                            for _ in range(3):
+                                fcall()
+                            per = []
+                            for _ in range(12):
+                                t0 = time.perf_counter()
+                                fcall()
+                                per.append((time.perf_counter() - t0) * 1e3)
+                            alt[plan or "auto"] = round(float(np.median(per)), 4)
+                        eng.set_experiment("rows", "")
+                        result["host_call"]["f32_output_plans"] = alt
+                        fin.close(); fout.close()
                     pin_in.close(); pin_out.close()
             except Exception as ex:  # noqa: BLE001
                 result["host_call"] = {"error": str(ex)[:300]}

@@ -1248,38 +1248,20 @@ std::vector<Chunk> plan_chunks(const sr_ctx* c, Deal deal, int h, int w, size_t 
             // and the last download, many pay 14 recomputed rows and five launches each.  Measured, f32 1080p
             // 1 / 2 / 4 / 5 / 8 bands = 5.96 / 5.14 / 4.93 / 5.12 / 5.22 ms; the split-half mode computes 2.2x faster
             // than the bus drains its output and prefers more: 4 / 5 / 6 / 8 bands = 3.77 / 2.7-3.4 / 2.82 / 3.05 ms.
-            // Round 6, re-measured on this round's kernels (the split-half frame went 3.2 -> 1.46 ms since those plans were drawn;
-            // scripts/host_plan_sweep.py, profiles/r6_host_mid_plans.txt 6.): bands IN ORDER on one stream now beat equal bands on alternating
-            // streams in both of these regimes --
-            //  * f32 output (the download is as long as the kernels, or 3x as long): five equal bands, eight from 3 M px -- exact f32 1280x720
-            //    3.53 -> 2.70 ms, 1920x1080 6.23 -> 5.68, 3840x2160 21.1 -> 20.2; split-half 2.28 -> 2.17, 4.74 -> 4.52, 18.0 -> 17.2;
-            //  * the split-half mode with u8 output (kernels about as long as the download): three / four / five bands that shrink by 0.85
-            //    from one to the next (below 1.5 M / below 6 M px / above), so that each band's download ends under the next band's kernels and
-            //    the exposed last download is a small one: 1280x720 1.17 -> 1.11 ms, 1920x1080 2.30 -> 2.12, 2560x1440 3.70 -> 3.48,
-            //    3840x2160 7.58 -> 7.24.
-            // (Exact f32 with u8 output between 2^19 and 0.8 M px keeps its two equal bands on alternating streams: 1024x600 1.52 against 1.60.)
-            const int most = std::max(1, span / (2 * SR_HALO));
+            // Round 6, f32 OUTPUT re-measured on this round's kernels (scripts/host_plan_sweep.py, profiles/r6_host_mid_plans.txt 6.): five equal bands
+            // IN ORDER on one stream, eight from 3 M px, beat the equal bands on alternating streams of rounds 2-3 in a process of its own (a C / Rust
+            // host) -- exact f32 1280x720 3.53 -> 2.71 ms, 1920x1080 6.25 -> 5.69, 3840x2160 21.1 -> 19.9; split-half 2.29 -> 2.17, 4.74 -> 4.60,
+            // 17.8 -> 17.2 -- and are within +-6 % of them inside bench.py's long-lived torch process (exact f32 1920x1080 6.17 against 5.85, split-half
+            // 4.60 against 4.93: 7.).
+            // The split-half mode with u8 output keeps its equal bands on alternating streams: bands in order that shrink by 0.85 are 3-6 % faster
+            // in a fresh process (1920x1080 2.30 -> 2.12 ms) but read 3.37 ms for the first dozens of calls inside bench.py's process -- no overlap at
+            // all between the one compute stream and the download stream, which two compute streams never lose entirely (7.); not adopted.
             if (out_px_bytes != 4) {
-                const int nb = std::min(px_span < 3000000u ? 5 : 8, most);
+                const int nb = std::min(px_span < 3000000u ? 5 : 8, std::max(1, span / (2 * SR_HALO)));
                 for (int k = 0; k < nb; ++k) rows.push_back((span * (k + 1)) / nb - (span * k) / nb);
                 *in_order = true;
-            } else if (split_mode) {
-                const int nb = std::min(px_span < 1500000u ? 3 : (px_span < 6000000u ? 4 : 5), most);
-                double sum = 0.0, term = 1.0;
-                for (int k = 0; k < nb; ++k) { sum += term; term *= 0.85; }
-                int left = span;
-                term = 1.0;
-                for (int k = 0; k < nb - 1; ++k) {
-                    int rk = (int)((double)span * term / sum) / 8 * 8;
-                    rk = std::max(2 * SR_HALO, std::min(rk, left - 2 * SR_HALO * (nb - 1 - k)));
-                    rows.push_back(rk);
-                    left -= rk;
-                    term *= 0.85;
-                }
-                rows.push_back(left);
-                *in_order = true;
             } else {
-                int nb = span / 256;
+                int nb = span / (split_mode ? 176 : 256);
                 if (nb > 8) nb = 8;
                 for (int k = 0; k < nb; ++k) rows.push_back((span * (k + 1)) / nb - (span * k) / nb);
             }
